@@ -1,0 +1,13 @@
+"""MI355X-native rank-array / interleave path of bwt-merge.
+
+The product is the C-ABI library libbwtm.so (csrc/, include/bwtm.h) plus the C++ facade and
+the bwt_merge CLI in csrc/host; this Python package only binds the C ABI for tests and bench.
+"""
+from . import build as _build          # noqa: F401
+from . import capi                      # noqa: F401
+from .capi import (BwtmError, Index, RankArray, init, interleave, merge, profile_enable,  # noqa: F401
+                   profile_read, profile_reset, ra_buffer_bytes, synchronize)
+
+
+def build(force=False, verbose=False):
+    return _build.build(force=force, verbose=verbose)

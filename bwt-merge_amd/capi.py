@@ -1,0 +1,279 @@
+"""ctypes binding of the C ABI in include/bwtm.h (the same stub a maintainer of another host
+language would write).  There is no CPU fallback: if libbwtm.so is
+missing or no GPU is usable, calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbwtm.so")
+SIGMA = 6
+
+u64 = C.c_uint64
+p_u8 = C.POINTER(C.c_uint8)
+p_u64 = C.POINTER(C.c_uint64)
+vp = C.c_void_p
+
+# Every symbol include/bwtm.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("bwtm_init", C.c_int, [C.c_int]),
+    ("bwtm_last_error", C.c_char_p, []),
+    ("bwtm_synchronize", C.c_int, []),
+    ("bwtm_index_upload", C.c_int, [p_u8, u64, u64, u64, p_u64, C.POINTER(vp)]),
+    ("bwtm_index_from_device", C.c_int, [vp, u64, u64, u64, p_u64, C.POINTER(vp)]),
+    ("bwtm_index_from_symbols_device", C.c_int, [vp, u64, C.POINTER(vp)]),
+    ("bwtm_index_free", None, [vp]),
+    ("bwtm_index_bases", u64, [vp]),
+    ("bwtm_index_sequences", u64, [vp]),
+    ("bwtm_index_bytes", u64, [vp]),
+    ("bwtm_index_blocks", u64, [vp]),
+    ("bwtm_index_C", None, [vp, p_u64]),
+    ("bwtm_index_encode", C.c_int, [vp]),
+    ("bwtm_index_drop_native", C.c_int, [vp]),
+    ("bwtm_index_download_data", C.c_int, [vp, p_u8, u64]),
+    ("bwtm_index_download_samples", C.c_int, [vp, p_u64, p_u64]),
+    ("bwtm_rank_batch", C.c_int, [vp, p_u64, p_u8, u64, p_u64]),
+    ("bwtm_inverse_select_batch", C.c_int, [vp, p_u64, u64, p_u64, p_u8]),
+    ("bwtm_extract", C.c_int, [vp, u64, u64, p_u8]),
+    ("bwtm_ra_create", C.c_int, [vp, vp, C.POINTER(vp)]),
+    ("bwtm_ra_buffer_bytes", u64, [vp, vp]),
+    ("bwtm_ra_create_on", C.c_int, [vp, vp, vp, u64, C.POINTER(vp)]),
+    ("bwtm_ra_free", None, [vp]),
+    ("bwtm_search", C.c_int, [vp, vp, u64, u64, vp]),
+    ("bwtm_ra_device_buffer", C.c_int, [vp, C.POINTER(vp), p_u64]),
+    ("bwtm_ra_finalize", C.c_int, [vp]),
+    ("bwtm_ra_values", u64, [vp]),
+    ("bwtm_ra_download", C.c_int, [vp, p_u64, u64]),
+    ("bwtm_ra_download_bits", C.c_int, [vp, p_u64, u64]),
+    ("bwtm_interleave", C.c_int, [vp, vp, vp, C.POINTER(vp)]),
+    ("bwtm_merge", C.c_int, [vp, vp, C.POINTER(vp)]),
+    ("bwtm_profile_enable", C.c_int, [C.c_int]),
+    ("bwtm_profile_reset", C.c_int, []),
+    ("bwtm_profile_read", C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), p_u64, C.c_int]),
+]
+
+
+class BwtmError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Loads libbwtm.so; raises (loudly) when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BwtmError("HIP extension %s is missing: run `python __graft_entry__.py build` "
+                            "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            f = getattr(L, name)       # AttributeError if the library does not export it
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise BwtmError("bwtm error %d: %s" % (rc, lib().bwtm_last_error().decode()))
+
+
+def init(device=0):
+    check(lib().bwtm_init(device))
+
+
+def synchronize():
+    check(lib().bwtm_synchronize())
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data_as(p_u8)
+
+
+def _u64(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a, a.ctypes.data_as(p_u64)
+
+
+class Index:
+    """Device-resident FM-index (handle on bwtm_index)."""
+
+    def __init__(self, handle):
+        self.h = vp(handle) if not isinstance(handle, vp) else handle
+
+    def free(self):
+        if self.h:
+            lib().bwtm_index_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    @staticmethod
+    def upload(data, sequences, bases, C_array=None):
+        data, dp = _u8(data)
+        out = vp()
+        cp = None
+        if C_array is not None:
+            C_array, cp = _u64(C_array)
+        check(lib().bwtm_index_upload(dp, data.size, sequences, bases, cp, C.byref(out)))
+        return Index(out)
+
+    @staticmethod
+    def from_device(ptr, nbytes, sequences, bases, C_array=None):
+        out = vp()
+        cp = None
+        if C_array is not None:
+            C_array, cp = _u64(C_array)
+        check(lib().bwtm_index_from_device(vp(ptr), nbytes, sequences, bases, cp, C.byref(out)))
+        return Index(out)
+
+    @staticmethod
+    def from_symbols_device(ptr, bases):
+        out = vp()
+        check(lib().bwtm_index_from_symbols_device(vp(ptr), bases, C.byref(out)))
+        return Index(out)
+
+    bases = property(lambda s: int(lib().bwtm_index_bases(s.h)))
+    sequences = property(lambda s: int(lib().bwtm_index_sequences(s.h)))
+    nbytes = property(lambda s: int(lib().bwtm_index_bytes(s.h)))
+    blocks = property(lambda s: int(lib().bwtm_index_blocks(s.h)))
+
+    @property
+    def C(self):
+        out = np.zeros(SIGMA + 1, dtype=np.uint64)
+        lib().bwtm_index_C(self.h, out.ctypes.data_as(p_u64))
+        return out
+
+    def encode(self):
+        check(lib().bwtm_index_encode(self.h))
+        return self
+
+    def drop_native(self):
+        check(lib().bwtm_index_drop_native(self.h))
+        return self
+
+    def data(self):
+        out = np.zeros(self.nbytes, dtype=np.uint8)
+        check(lib().bwtm_index_download_data(self.h, out.ctypes.data_as(p_u8), out.size))
+        return out
+
+    def samples(self):
+        nb = self.blocks
+        be = np.zeros(nb, dtype=np.uint64)
+        cum = np.zeros((SIGMA, nb + 1), dtype=np.uint64)
+        check(lib().bwtm_index_download_samples(self.h, be.ctypes.data_as(p_u64), cum.ctypes.data_as(p_u64)))
+        return be, cum
+
+    def rank(self, positions, comps):
+        positions, pp = _u64(positions)
+        comps, cp = _u8(comps)
+        out = np.zeros(positions.size, dtype=np.uint64)
+        check(lib().bwtm_rank_batch(self.h, pp, cp, positions.size, out.ctypes.data_as(p_u64)))
+        return out
+
+    def inverse_select(self, positions):
+        positions, pp = _u64(positions)
+        r = np.zeros(positions.size, dtype=np.uint64)
+        c = np.zeros(positions.size, dtype=np.uint8)
+        check(lib().bwtm_inverse_select_batch(self.h, pp, positions.size, r.ctypes.data_as(p_u64), c.ctypes.data_as(p_u8)))
+        return r, c
+
+    def extract(self, first, count):
+        out = np.zeros(count, dtype=np.uint8)
+        check(lib().bwtm_extract(self.h, first, count, out.ctypes.data_as(p_u8)))
+        return out
+
+
+class RankArray:
+    """Device-resident rank array (handle on bwtm_ra)."""
+
+    def __init__(self, a, b, device_buffer=None, nbytes=0):
+        out = vp()
+        if device_buffer is None:
+            check(lib().bwtm_ra_create(a.h, b.h, C.byref(out)))
+        else:
+            check(lib().bwtm_ra_create_on(a.h, b.h, vp(device_buffer), nbytes, C.byref(out)))
+        self.h = out
+        self.n_out = a.bases + b.bases
+        self.nb = b.bases
+
+    def free(self):
+        if self.h:
+            lib().bwtm_ra_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def search(self, a, b, seq_first, seq_last):
+        check(lib().bwtm_search(a.h, b.h, seq_first, seq_last, self.h))
+
+    def device_buffer(self):
+        ptr = vp()
+        n = u64(0)
+        check(lib().bwtm_ra_device_buffer(self.h, C.byref(ptr), C.byref(n)))
+        return int(ptr.value), int(n.value)
+
+    def finalize(self):
+        check(lib().bwtm_ra_finalize(self.h))
+        return self
+
+    values = property(lambda s: int(lib().bwtm_ra_values(s.h)))
+
+    def download(self):
+        out = np.zeros(self.nb, dtype=np.uint64)
+        check(lib().bwtm_ra_download(self.h, out.ctypes.data_as(p_u64), out.size))
+        return out
+
+    def bits(self):
+        words = (self.n_out + 63) // 64
+        out = np.zeros(words, dtype=np.uint64)
+        check(lib().bwtm_ra_download_bits(self.h, out.ctypes.data_as(p_u64), out.size))
+        return out
+
+
+def ra_buffer_bytes(a, b):
+    return int(lib().bwtm_ra_buffer_bytes(a.h, b.h))
+
+
+def interleave(a, b, ra):
+    out = vp()
+    check(lib().bwtm_interleave(a.h, b.h, ra.h, C.byref(out)))
+    return Index(out)
+
+
+def merge(a, b):
+    """FMI::FMI(a, b): search + finalize + interleave + encode + samples on the device."""
+    out = vp()
+    check(lib().bwtm_merge(a.h, b.h, C.byref(out)))
+    return Index(out)
+
+
+def profile_enable(on=True):
+    check(lib().bwtm_profile_enable(1 if on else 0))
+
+
+def profile_reset():
+    check(lib().bwtm_profile_reset())
+
+
+def profile_read():
+    """{kernel name: (total_ms, launches)} since the last reset."""
+    cap = 64
+    names = (C.c_char_p * cap)()
+    ms = (C.c_double * cap)()
+    n = (u64 * cap)()
+    k = lib().bwtm_profile_read(names, ms, n, cap)
+    return {names[i].decode(): (ms[i], int(n[i])) for i in range(min(k, cap))}

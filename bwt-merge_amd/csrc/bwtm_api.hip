@@ -1,0 +1,675 @@
+/*
+  bwtm_api.hip -- implementation of the C ABI declared in include/bwtm.h: host-side
+  orchestration of the gfx950 kernels in bwtm_kernels.hip.h.  No CPU fallback exists: every
+  entry point fails with BWTM_ENODEV when no HIP device is usable.
+*/
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/bwtm.h"
+#include "bwtm_kernels.hip.h"
+
+using namespace bwtm;
+
+//------------------------------------------------------------------------------
+// Context, errors, profiling.
+
+namespace
+{
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...)
+{
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+struct Context
+{
+  bool ready = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  bool profiling = false;
+  struct Pending { const char* name; hipEvent_t start, stop; };
+  std::vector<Pending> pending;
+  std::map<std::string, std::pair<double, uint64_t>> totals;
+  std::vector<const char*> order;
+};
+
+Context g_ctx;
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if(e_ != hipSuccess) { \
+  return fail(e_ == hipErrorOutOfMemory ? BWTM_ENOMEM : BWTM_ENODEV, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } } while(0)
+
+#define TRY(expr) do { int rc_ = (expr); if(rc_ != BWTM_OK) { return rc_; } } while(0)
+
+int ensure_ready()
+{
+  if(g_ctx.ready) { return BWTM_OK; }
+  return bwtm_init(0);
+}
+
+void profile_begin(const char* name)
+{
+  if(!g_ctx.profiling) { return; }
+  Context::Pending p; p.name = name;
+  (void)hipEventCreate(&p.start); (void)hipEventCreate(&p.stop);
+  (void)hipEventRecord(p.start, g_ctx.stream);
+  g_ctx.pending.push_back(p);
+}
+
+void profile_end()
+{
+  if(!g_ctx.profiling) { return; }
+  (void)hipEventRecord(g_ctx.pending.back().stop, g_ctx.stream);
+}
+
+void profile_collect()
+{
+  if(g_ctx.pending.empty()) { return; }
+  (void)hipStreamSynchronize(g_ctx.stream);
+  for(auto& p : g_ctx.pending)
+  {
+    float ms = 0; (void)hipEventElapsedTime(&ms, p.start, p.stop);
+    auto it = g_ctx.totals.find(p.name);
+    if(it == g_ctx.totals.end()) { g_ctx.totals[p.name] = std::make_pair((double)ms, (uint64_t)1); g_ctx.order.push_back(p.name); }
+    else { it->second.first += ms; it->second.second += 1; }
+    (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop);
+  }
+  g_ctx.pending.clear();
+}
+
+#define LAUNCH(name, kernel, grid, block, ...) do { \
+  profile_begin(name); \
+  hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, g_ctx.stream, __VA_ARGS__); \
+  profile_end(); \
+  hipError_t le_ = hipGetLastError(); \
+  if(le_ != hipSuccess) { return fail(BWTM_ENODEV, "launch of %s failed: %s", name, hipGetErrorString(le_)); } } while(0)
+
+inline u64 div_up(u64 a, u64 b) { return (a + b - 1) / b; }
+
+// RAII device buffer.
+struct DevBuf
+{
+  void* p = nullptr; u64 bytes = 0;
+  DevBuf() {}
+  DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() { if(p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+  int alloc(u64 n, bool zero = false)
+  {
+    release();
+    if(n == 0) { n = 8; }
+    hipError_t e = hipMalloc(&p, n);
+    if(e != hipSuccess) { p = nullptr; return fail(BWTM_ENOMEM, "hipMalloc(%llu bytes) failed: %s", (unsigned long long)n, hipGetErrorString(e)); }
+    bytes = n;
+    if(zero) { e = hipMemsetAsync(p, 0, n, g_ctx.stream); if(e != hipSuccess) { return fail(BWTM_ENODEV, "hipMemsetAsync failed: %s", hipGetErrorString(e)); } }
+    return BWTM_OK;
+  }
+  template<class T> T* as() const { return (T*)p; }
+  void swap(DevBuf& o) { std::swap(p, o.p); std::swap(bytes, o.bytes); }
+};
+
+// Exclusive scan of n u64 items (in place allowed).  OP 0 = sum, 1 = max.
+template<int OP>
+int device_scan(const u64* in, u64* out, u64 n)
+{
+  if(n == 0) { return BWTM_OK; }
+  u64 tiles = div_up(n, SCAN_TILE);
+  if(tiles == 1)
+  {
+    LAUNCH("scan_apply", k_scan_apply<OP>, 1, BLOCK_THREADS, in, out, (const u64*)nullptr, n);
+    return BWTM_OK;
+  }
+  DevBuf partial; TRY(partial.alloc(tiles * sizeof(u64)));
+  LAUNCH("scan_reduce", k_scan_reduce<OP>, tiles, BLOCK_THREADS, in, partial.as<u64>(), n);
+  TRY(device_scan<OP>(partial.as<u64>(), partial.as<u64>(), tiles));
+  LAUNCH("scan_apply", k_scan_apply<OP>, tiles, BLOCK_THREADS, in, out, (const u64*)partial.as<u64>(), n);
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));     // `partial` is released on return
+  return BWTM_OK;
+}
+
+} // namespace
+
+//------------------------------------------------------------------------------
+// Handles.
+
+struct bwtm_index
+{
+  u64 n = 0, m = 0;
+  u64 C[8] = {};
+  DevBuf recs; u64 nrecs = 0;        // device rank structure
+  DevBuf sup;  u64 nsup = 0;
+  // Native form (present after upload or encode):
+  bool has_native = false;
+  DevBuf data; u64 nbytes = 0; u64 nblocks = 0;
+  DevBuf cum;                         // 6 x (nblocks + 1) u64: cumulative symbol counts at block starts
+  DevBuf block_start;                 // nblocks + 1 u64
+
+  IndexView view() const
+  {
+    IndexView v;
+    v.recs = recs.as<const uint4>(); v.sup = sup.as<const u64>();
+    v.n = n; v.m = m; v.nrecs = nrecs;
+    for(int c = 0; c < 8; c++) { v.C[c] = C[c]; }
+    return v;
+  }
+};
+
+struct bwtm_ra
+{
+  u64 na = 0, nb = 0, n_out = 0;
+  u64 nrecs_out = 0, nchunks = 0;
+  DevBuf owned_bits;                  // nchunks * CHUNK_WORDS u64 words (unless caller-owned)
+  void* bits_ptr = nullptr;
+  template<class T> T* bits_as() const { return (T*)bits_ptr; }
+  DevBuf chunk_base;                  // nchunks + 1 u64 (exclusive scan of chunk popcounts)
+  bool finalized = false;
+  u64 values = 0;
+};
+
+//------------------------------------------------------------------------------
+// Internal pipeline stages.
+
+namespace
+{
+
+// Per-block statistics + scans of a native byte stream: fills cum and block_start.
+int native_samples(bwtm_index* x)
+{
+  x->nblocks = div_up(x->nbytes, RLE_BLOCK);
+  u64 stride = x->nblocks + 1;
+  TRY(x->cum.alloc(6 * stride * sizeof(u64), true));
+  TRY(x->block_start.alloc(stride * sizeof(u64)));
+  if(x->nblocks > 0)
+  {
+    LAUNCH("block_stats", k_block_stats, div_up(x->nblocks, BLOCK_THREADS), BLOCK_THREADS,
+      x->data.as<const u8>(), x->nbytes, x->nblocks, x->cum.as<u64>(), stride);
+  }
+  for(int c = 0; c < 6; c++) { TRY(device_scan<0>(x->cum.as<u64>() + c * stride, x->cum.as<u64>() + c * stride, stride)); }
+  LAUNCH("block_start", k_block_start, div_up(stride, BLOCK_THREADS), BLOCK_THREADS,
+    x->cum.as<const u64>(), stride, stride, x->block_start.as<u64>());
+  return BWTM_OK;
+}
+
+// Records + super table from the native stream.
+int transcode(bwtm_index* x)
+{
+  x->nrecs = num_records(x->n); x->nsup = num_supers(x->n);
+  TRY(x->recs.alloc(x->nrecs * 64));
+  TRY(x->sup.alloc(x->nsup * SUP_STRIDE * sizeof(u64)));
+  u64 stride = x->nblocks + 1;
+  LAUNCH("build_sup", k_build_sup, div_up(x->nsup, BLOCK_THREADS), BLOCK_THREADS,
+    x->data.as<const u8>(), x->nbytes, x->block_start.as<const u64>(), x->cum.as<const u64>(), stride, x->nblocks, x->n,
+    x->sup.as<u64>(), x->nsup);
+  LAUNCH("build_recs", k_build_recs, div_up(x->nrecs, BLOCK_THREADS), BLOCK_THREADS,
+    x->data.as<const u8>(), x->nbytes, x->block_start.as<const u64>(), x->cum.as<const u64>(), stride, x->nblocks, x->n,
+    x->sup.as<const u64>(), x->recs.as<uint4>(), x->nrecs);
+  return BWTM_OK;
+}
+
+int finish_native_index(bwtm_index* x, uint64_t sequences, uint64_t bases, const uint64_t* C)
+{
+  x->n = bases; x->m = sequences;
+  TRY(native_samples(x));
+  // Validate the header against the stream and derive C (Alphabet(counts), support.cpp:84-91).
+  u64 stride = x->nblocks + 1;
+  u64 totals[6];
+  for(int c = 0; c < 6; c++)
+  {
+    HIP_TRY(hipMemcpyAsync(&totals[c], x->cum.as<u64>() + c * stride + x->nblocks, sizeof(u64), hipMemcpyDeviceToHost, g_ctx.stream));
+  }
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  u64 sum = 0; for(int c = 0; c < 6; c++) { sum += totals[c]; }
+  if(sum != bases) { return fail(BWTM_EINVAL, "native stream decodes to %llu positions, header says %llu", (unsigned long long)sum, (unsigned long long)bases); }
+  if(totals[0] != sequences) { return fail(BWTM_EINVAL, "native stream holds %llu endmarkers, header says %llu sequences", (unsigned long long)totals[0], (unsigned long long)sequences); }
+  x->C[0] = 0;
+  for(int c = 0; c < 6; c++) { x->C[c + 1] = x->C[c] + totals[c]; }
+  x->C[7] = x->C[6];
+  if(C) { for(int c = 0; c <= 6; c++) { x->C[c] = C[c]; } }
+  x->has_native = true;
+  TRY(transcode(x));
+  return BWTM_OK;
+}
+
+} // namespace
+
+//------------------------------------------------------------------------------
+// Library.
+
+extern "C" int bwtm_init(int device)
+{
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if(e != hipSuccess || count <= 0) { return fail(BWTM_ENODEV, "no HIP device available (%s)", hipGetErrorString(e)); }
+  if(device < 0 || device >= count) { return fail(BWTM_EINVAL, "device %d out of range (%d devices)", device, count); }
+  HIP_TRY(hipSetDevice(device));
+  if(g_ctx.ready && g_ctx.device == device) { return BWTM_OK; }
+  if(g_ctx.stream) { (void)hipStreamDestroy(g_ctx.stream); g_ctx.stream = nullptr; }
+  HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+  g_ctx.device = device; g_ctx.ready = true;
+  return BWTM_OK;
+}
+
+extern "C" const char* bwtm_last_error(void) { return g_error.c_str(); }
+
+extern "C" int bwtm_synchronize(void)
+{
+  TRY(ensure_ready());
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return BWTM_OK;
+}
+
+//------------------------------------------------------------------------------
+// Index.
+
+extern "C" int bwtm_index_upload(const uint8_t* data, uint64_t nbytes, uint64_t sequences, uint64_t bases,
+  const uint64_t* C, bwtm_index** out)
+{
+  TRY(ensure_ready());
+  if(!out || (nbytes > 0 && !data)) { return fail(BWTM_EINVAL, "bwtm_index_upload: null argument"); }
+  bwtm_index* x = new bwtm_index();
+  x->nbytes = nbytes;
+  int rc = x->data.alloc(nbytes + 16, true);      // padding keeps the last partial block readable
+  if(rc == BWTM_OK && nbytes > 0)
+  {
+    hipError_t e = hipMemcpyAsync(x->data.p, data, nbytes, hipMemcpyHostToDevice, g_ctx.stream);
+    if(e != hipSuccess) { rc = fail(BWTM_ENODEV, "H2D copy failed: %s", hipGetErrorString(e)); }
+  }
+  if(rc == BWTM_OK) { rc = finish_native_index(x, sequences, bases, C); }
+  if(rc != BWTM_OK) { delete x; return rc; }
+  *out = x;
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_index_from_device(const void* device_data, uint64_t nbytes, uint64_t sequences, uint64_t bases,
+  const uint64_t* C, bwtm_index** out)
+{
+  TRY(ensure_ready());
+  if(!out || (nbytes > 0 && !device_data)) { return fail(BWTM_EINVAL, "bwtm_index_from_device: null argument"); }
+  bwtm_index* x = new bwtm_index();
+  x->nbytes = nbytes;
+  int rc = x->data.alloc(nbytes + 16, true);
+  if(rc == BWTM_OK && nbytes > 0)
+  {
+    hipError_t e = hipMemcpyAsync(x->data.p, device_data, nbytes, hipMemcpyDeviceToDevice, g_ctx.stream);
+    if(e != hipSuccess) { rc = fail(BWTM_ENODEV, "D2D copy failed: %s", hipGetErrorString(e)); }
+  }
+  if(rc == BWTM_OK) { rc = finish_native_index(x, sequences, bases, C); }
+  if(rc != BWTM_OK) { delete x; return rc; }
+  *out = x;
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_index_from_symbols_device(const void* device_symbols, uint64_t bases, bwtm_index** out)
+{
+  TRY(ensure_ready());
+  if(!out || (bases > 0 && !device_symbols)) { return fail(BWTM_EINVAL, "bwtm_index_from_symbols_device: null argument"); }
+  bwtm_index* x = new bwtm_index();
+  auto body = [&]() -> int
+  {
+    x->n = bases;
+    x->nrecs = num_records(bases); x->nsup = num_supers(bases);
+    u64 stride = x->nrecs + 1;
+    DevBuf cnt; TRY(cnt.alloc(6 * stride * sizeof(u64), true));
+    LAUNCH("sym_counts", k_sym_counts, div_up(x->nrecs, BLOCK_THREADS), BLOCK_THREADS,
+      (const u8*)device_symbols, bases, x->nrecs, cnt.as<u64>(), stride);
+    for(int c = 0; c < 6; c++) { TRY(device_scan<0>(cnt.as<u64>() + c * stride, cnt.as<u64>() + c * stride, stride)); }
+    u64 totals[6];
+    for(int c = 0; c < 6; c++)
+    {
+      HIP_TRY(hipMemcpyAsync(&totals[c], cnt.as<u64>() + c * stride + x->nrecs, sizeof(u64), hipMemcpyDeviceToHost, g_ctx.stream));
+    }
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    x->m = totals[0];
+    x->C[0] = 0; for(int c = 0; c < 6; c++) { x->C[c + 1] = x->C[c] + totals[c]; } x->C[7] = x->C[6];
+    TRY(x->recs.alloc(x->nrecs * 64));
+    TRY(x->sup.alloc(x->nsup * SUP_STRIDE * sizeof(u64)));
+    LAUNCH("sym_sup", k_sym_sup, div_up(x->nsup, BLOCK_THREADS), BLOCK_THREADS, cnt.as<const u64>(), stride, x->nrecs, x->sup.as<u64>(), x->nsup);
+    LAUNCH("sym_recs", k_sym_recs, div_up(x->nrecs, BLOCK_THREADS), BLOCK_THREADS,
+      (const u8*)device_symbols, bases, cnt.as<const u64>(), stride, x->sup.as<const u64>(), x->recs.as<uint4>(), x->nrecs);
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    return BWTM_OK;
+  };
+  int rc = body();
+  if(rc != BWTM_OK) { delete x; return rc; }
+  *out = x;
+  return BWTM_OK;
+}
+
+extern "C" void bwtm_index_free(bwtm_index* index)
+{
+  if(!index) { return; }
+  if(g_ctx.stream) { (void)hipStreamSynchronize(g_ctx.stream); }
+  delete index;
+}
+
+extern "C" uint64_t bwtm_index_bases(const bwtm_index* x)     { return x ? x->n : 0; }
+extern "C" uint64_t bwtm_index_sequences(const bwtm_index* x) { return x ? x->m : 0; }
+extern "C" uint64_t bwtm_index_bytes(const bwtm_index* x)     { return (x && x->has_native) ? x->nbytes : 0; }
+extern "C" uint64_t bwtm_index_blocks(const bwtm_index* x)    { return (x && x->has_native) ? x->nblocks : 0; }
+extern "C" void bwtm_index_C(const bwtm_index* x, uint64_t* C) { for(int c = 0; c <= 6; c++) { C[c] = x->C[c]; } }
+
+extern "C" int bwtm_index_drop_native(bwtm_index* x)
+{
+  if(!x) { return fail(BWTM_EINVAL, "null index"); }
+  if(g_ctx.stream) { (void)hipStreamSynchronize(g_ctx.stream); }
+  x->data.release(); x->cum.release(); x->block_start.release();
+  x->has_native = false; x->nbytes = 0; x->nblocks = 0;
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_index_encode(bwtm_index* x)
+{
+  TRY(ensure_ready());
+  if(!x) { return fail(BWTM_EINVAL, "null index"); }
+  if(x->has_native) { return BWTM_OK; }
+  x->nbytes = 0; x->nblocks = 0;
+  if(x->n > 0)
+  {
+    u64 ntiles = (x->n >> 6) + 1;
+    u64 nseg = div_up(ntiles, SEG_TILES);
+    u64 ngroups = div_up(nseg, FOLD_GROUP);
+    DevBuf lasthead, table, group_table, group_base, seg_base;
+    TRY(lasthead.alloc(nseg * sizeof(u64)));
+    TRY(table.alloc(nseg * 64 * sizeof(u32)));
+    TRY(group_table.alloc(ngroups * 64 * sizeof(u64)));
+    TRY(group_base.alloc((ngroups + 1) * sizeof(u64)));
+    TRY(seg_base.alloc(nseg * sizeof(u64)));
+    u64 wave_grid = div_up(nseg * WAVE, BLOCK_THREADS);
+    LAUNCH("enc_lasthead", k_enc_lasthead, wave_grid, BLOCK_THREADS, x->recs.as<const uint4>(), x->nrecs, x->n, ntiles, nseg, lasthead.as<u64>());
+    TRY(device_scan<1>(lasthead.as<u64>(), lasthead.as<u64>(), nseg));       // -> (last head before the segment) + 1
+    LAUNCH("enc_size", k_enc_size, wave_grid, BLOCK_THREADS, x->recs.as<const uint4>(), x->nrecs, x->n, ntiles, nseg,
+      lasthead.as<const u64>(), table.as<u32>());
+    LAUNCH("fold_group", k_fold_group, ngroups, WAVE, table.as<const u32>(), nseg, group_table.as<u64>());
+    LAUNCH("fold_top", k_fold_top, 1, WAVE, group_table.as<const u64>(), ngroups, group_base.as<u64>());
+    LAUNCH("fold_seg", k_fold_seg, ngroups, WAVE, table.as<const u32>(), nseg, group_base.as<const u64>(), seg_base.as<u64>());
+    u64 total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, group_base.as<u64>() + ngroups, sizeof(u64), hipMemcpyDeviceToHost, g_ctx.stream));
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    x->nbytes = total;
+    TRY(x->data.alloc(total + 16, true));
+    LAUNCH("enc_emit", k_enc_emit, wave_grid, BLOCK_THREADS, x->recs.as<const uint4>(), x->nrecs, x->n, ntiles, nseg,
+      lasthead.as<const u64>(), seg_base.as<const u64>(), x->data.as<u8>());
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  }
+  else { TRY(x->data.alloc(16, true)); }
+  TRY(native_samples(x));                       // BWT::build, bwt.cpp:476-512
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  x->has_native = true;
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_index_download_data(bwtm_index* x, uint8_t* out, uint64_t capacity)
+{
+  TRY(ensure_ready());
+  if(!x || !x->has_native) { return fail(BWTM_EINVAL, "index has no native byte stream (call bwtm_index_encode first)"); }
+  if(capacity < x->nbytes) { return fail(BWTM_EINVAL, "buffer too small: %llu < %llu", (unsigned long long)capacity, (unsigned long long)x->nbytes); }
+  if(x->nbytes > 0) { HIP_TRY(hipMemcpyAsync(out, x->data.p, x->nbytes, hipMemcpyDeviceToHost, g_ctx.stream)); }
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_index_download_samples(bwtm_index* x, uint64_t* block_end, uint64_t* cum)
+{
+  TRY(ensure_ready());
+  if(!x || !x->has_native) { return fail(BWTM_EINVAL, "index has no native samples (call bwtm_index_encode first)"); }
+  u64 stride = x->nblocks + 1;
+  if(x->nblocks > 0)
+  {
+    DevBuf be; TRY(be.alloc(x->nblocks * sizeof(u64)));
+    LAUNCH("block_end", k_block_end, div_up(x->nblocks, BLOCK_THREADS), BLOCK_THREADS, x->block_start.as<const u64>(), x->nblocks, be.as<u64>());
+    HIP_TRY(hipMemcpyAsync(block_end, be.p, x->nblocks * sizeof(u64), hipMemcpyDeviceToHost, g_ctx.stream));
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  }
+  HIP_TRY(hipMemcpyAsync(cum, x->cum.p, 6 * stride * sizeof(u64), hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_rank_batch(const bwtm_index* x, const uint64_t* positions, const uint8_t* comps, uint64_t count, uint64_t* out_ranks)
+{
+  TRY(ensure_ready());
+  if(!x || !positions || !comps || !out_ranks) { return fail(BWTM_EINVAL, "bwtm_rank_batch: null argument"); }
+  if(count == 0) { return BWTM_OK; }
+  DevBuf dp, dc, dr;
+  TRY(dp.alloc(count * 8)); TRY(dc.alloc(count)); TRY(dr.alloc(count * 8));
+  HIP_TRY(hipMemcpyAsync(dp.p, positions, count * 8, hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(hipMemcpyAsync(dc.p, comps, count, hipMemcpyHostToDevice, g_ctx.stream));
+  LAUNCH("rank_batch", k_rank_batch, div_up(count, BLOCK_THREADS), BLOCK_THREADS, x->view(), dp.as<const u64>(), dc.as<const u8>(), count, dr.as<u64>());
+  HIP_TRY(hipMemcpyAsync(out_ranks, dr.p, count * 8, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_inverse_select_batch(const bwtm_index* x, const uint64_t* positions, uint64_t count, uint64_t* out_ranks, uint8_t* out_comps)
+{
+  TRY(ensure_ready());
+  if(!x || !positions || !out_ranks || !out_comps) { return fail(BWTM_EINVAL, "bwtm_inverse_select_batch: null argument"); }
+  if(count == 0) { return BWTM_OK; }
+  DevBuf dp, dc, dr;
+  TRY(dp.alloc(count * 8)); TRY(dc.alloc(count)); TRY(dr.alloc(count * 8));
+  HIP_TRY(hipMemcpyAsync(dp.p, positions, count * 8, hipMemcpyHostToDevice, g_ctx.stream));
+  LAUNCH("inverse_select_batch", k_inverse_select_batch, div_up(count, BLOCK_THREADS), BLOCK_THREADS, x->view(), dp.as<const u64>(), count, dr.as<u64>(), dc.as<u8>());
+  HIP_TRY(hipMemcpyAsync(out_ranks, dr.p, count * 8, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipMemcpyAsync(out_comps, dc.p, count, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_extract(const bwtm_index* x, uint64_t first, uint64_t count, uint8_t* out)
+{
+  TRY(ensure_ready());
+  if(!x || !out) { return fail(BWTM_EINVAL, "bwtm_extract: null argument"); }
+  if(first + count > x->n) { return fail(BWTM_EINVAL, "bwtm_extract: range past the end"); }   // bwt.h:137
+  if(count == 0) { return BWTM_OK; }
+  DevBuf d; TRY(d.alloc(count));
+  LAUNCH("extract", k_extract, div_up(count, BLOCK_THREADS), BLOCK_THREADS, x->view(), first, count, d.as<u8>());
+  HIP_TRY(hipMemcpyAsync(out, d.p, count, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return BWTM_OK;
+}
+
+//------------------------------------------------------------------------------
+// Rank array.
+
+extern "C" uint64_t bwtm_ra_buffer_bytes(const bwtm_index* a, const bwtm_index* b)
+{
+  if(!a || !b) { return 0; }
+  return div_up(num_records(a->n + b->n), 64) * CHUNK_WORDS * sizeof(u64);
+}
+
+extern "C" int bwtm_ra_create_on(const bwtm_index* a, const bwtm_index* b, void* device_buffer, uint64_t nbytes, bwtm_ra** out)
+{
+  TRY(ensure_ready());
+  if(!a || !b || !out) { return fail(BWTM_EINVAL, "bwtm_ra_create: null argument"); }
+  bwtm_ra* ra = new bwtm_ra();
+  ra->na = a->n; ra->nb = b->n; ra->n_out = a->n + b->n;
+  ra->nrecs_out = num_records(ra->n_out);
+  ra->nchunks = div_up(ra->nrecs_out, 64);
+  u64 need = ra->nchunks * CHUNK_WORDS * sizeof(u64);
+  int rc = BWTM_OK;
+  if(device_buffer)
+  {
+    if(nbytes < need) { rc = fail(BWTM_EINVAL, "bwtm_ra_create_on: buffer of %llu bytes, need %llu", (unsigned long long)nbytes, (unsigned long long)need); }
+    ra->bits_ptr = device_buffer;
+  }
+  else
+  {
+    rc = ra->owned_bits.alloc(need, true);
+    ra->bits_ptr = ra->owned_bits.p;
+  }
+  if(rc == BWTM_OK) { rc = ra->chunk_base.alloc((ra->nchunks + 1) * sizeof(u64), true); }
+  if(rc != BWTM_OK) { delete ra; return rc; }
+  *out = ra;
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_ra_create(const bwtm_index* a, const bwtm_index* b, bwtm_ra** out)
+{
+  return bwtm_ra_create_on(a, b, nullptr, 0, out);
+}
+
+extern "C" void bwtm_ra_free(bwtm_ra* ra)
+{
+  if(!ra) { return; }
+  if(g_ctx.stream) { (void)hipStreamSynchronize(g_ctx.stream); }
+  delete ra;
+}
+
+extern "C" int bwtm_search(const bwtm_index* a, const bwtm_index* b, uint64_t seq_first, uint64_t seq_last, bwtm_ra* ra)
+{
+  TRY(ensure_ready());
+  if(!a || !b || !ra) { return fail(BWTM_EINVAL, "bwtm_search: null argument"); }
+  if(ra->na != a->n || ra->nb != b->n) { return fail(BWTM_EINVAL, "bwtm_search: rank array was created for other inputs"); }
+  if(ra->finalized) { return fail(BWTM_EINVAL, "bwtm_search: rank array already finalized"); }
+  if(b->m == 0 || seq_first > seq_last) { return BWTM_OK; }       // empty range (utils.h:80-83)
+  if(seq_last >= b->m) { return fail(BWTM_EINVAL, "bwtm_search: sequence %llu out of range (%llu sequences)", (unsigned long long)seq_last, (unsigned long long)b->m); }
+  u64 count = seq_last - seq_first + 1;
+  // Enough resident waves to fill the chip, every lane taking sequences in a grid stride.
+  u64 blocks = div_up(count, BLOCK_THREADS);
+  const u64 max_blocks = 256 * 8;
+  if(blocks > max_blocks) { blocks = max_blocks; }
+  LAUNCH("lf_walk", k_lf_walk, blocks, BLOCK_THREADS, a->view(), b->view(), (u64)seq_first, count, ra->bits_as<u32>());
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_ra_device_buffer(bwtm_ra* ra, void** device_ptr, uint64_t* nbytes)
+{
+  TRY(ensure_ready());
+  if(!ra || !device_ptr || !nbytes) { return fail(BWTM_EINVAL, "bwtm_ra_device_buffer: null argument"); }
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  *device_ptr = ra->bits_ptr; *nbytes = ra->nchunks * CHUNK_WORDS * sizeof(u64);
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_ra_finalize(bwtm_ra* ra)
+{
+  TRY(ensure_ready());
+  if(!ra) { return fail(BWTM_EINVAL, "null rank array"); }
+  LAUNCH("chunk_popc", k_chunk_popc, div_up(ra->nchunks * WAVE, BLOCK_THREADS), BLOCK_THREADS, ra->bits_as<const u64>(), ra->nchunks, ra->chunk_base.as<u64>());
+  TRY(device_scan<0>(ra->chunk_base.as<u64>(), ra->chunk_base.as<u64>(), ra->nchunks + 1));
+  HIP_TRY(hipMemcpyAsync(&ra->values, ra->chunk_base.as<u64>() + ra->nchunks, sizeof(u64), hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  ra->finalized = true;
+  return BWTM_OK;
+}
+
+extern "C" uint64_t bwtm_ra_values(const bwtm_ra* ra) { return ra ? ra->values : 0; }
+
+extern "C" int bwtm_ra_download(bwtm_ra* ra, uint64_t* out, uint64_t capacity)
+{
+  TRY(ensure_ready());
+  if(!ra || !out) { return fail(BWTM_EINVAL, "bwtm_ra_download: null argument"); }
+  if(!ra->finalized) { return fail(BWTM_EINVAL, "bwtm_ra_download: rank array not finalized"); }
+  if(capacity < ra->nb) { return fail(BWTM_EINVAL, "bwtm_ra_download: buffer too small"); }
+  if(ra->nb == 0) { return BWTM_OK; }
+  DevBuf d; TRY(d.alloc(ra->nb * sizeof(u64), true));
+  LAUNCH("ra_extract", k_ra_extract, div_up(ra->nchunks * WAVE, BLOCK_THREADS), BLOCK_THREADS,
+    ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), ra->nchunks, ra->nb, d.as<u64>());
+  HIP_TRY(hipMemcpyAsync(out, d.p, ra->nb * sizeof(u64), hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_ra_download_bits(bwtm_ra* ra, uint64_t* out_words, uint64_t capacity_words)
+{
+  TRY(ensure_ready());
+  if(!ra || !out_words) { return fail(BWTM_EINVAL, "bwtm_ra_download_bits: null argument"); }
+  u64 words = div_up(ra->n_out, 64);
+  if(capacity_words < words) { return fail(BWTM_EINVAL, "bwtm_ra_download_bits: buffer too small"); }
+  if(words > 0) { HIP_TRY(hipMemcpyAsync(out_words, ra->bits_ptr, words * sizeof(u64), hipMemcpyDeviceToHost, g_ctx.stream)); }
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return BWTM_OK;
+}
+
+//------------------------------------------------------------------------------
+// Interleave and the whole path.
+
+extern "C" int bwtm_interleave(const bwtm_index* a, const bwtm_index* b, bwtm_ra* ra, bwtm_index** out)
+{
+  TRY(ensure_ready());
+  if(!a || !b || !ra || !out) { return fail(BWTM_EINVAL, "bwtm_interleave: null argument"); }
+  if(!ra->finalized) { return fail(BWTM_EINVAL, "bwtm_interleave: rank array not finalized"); }
+  if(ra->na != a->n || ra->nb != b->n) { return fail(BWTM_EINVAL, "bwtm_interleave: rank array was created for other inputs"); }
+  if(ra->values != b->n) { return fail(BWTM_EINVAL, "bwtm_interleave: rank array holds %llu values, expected %llu", (unsigned long long)ra->values, (unsigned long long)b->n); }
+  bwtm_index* x = new bwtm_index();
+  auto body = [&]() -> int
+  {
+    x->n = ra->n_out; x->m = a->m + b->m;                           // bwt.cpp:305-306
+    for(int c = 0; c < 8; c++) { x->C[c] = a->C[c] + b->C[c]; }     // fmi.cpp:367-368
+    x->nrecs = ra->nrecs_out; x->nsup = num_supers(x->n);
+    TRY(x->recs.alloc(x->nrecs * 64));
+    TRY(x->sup.alloc(x->nsup * SUP_STRIDE * sizeof(u64)));
+    LAUNCH("interleave_sup", k_interleave_sup, div_up(x->nsup, BLOCK_THREADS), BLOCK_THREADS, a->view(), b->view(),
+      ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), x->n, x->sup.as<u64>(), x->nsup);
+    LAUNCH("interleave", k_interleave, div_up(ra->nchunks * WAVE, BLOCK_THREADS), BLOCK_THREADS, a->view(), b->view(),
+      ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), ra->nchunks, x->sup.as<const u64>(), x->recs.as<uint4>(), x->nrecs);
+    return BWTM_OK;
+  };
+  int rc = body();
+  if(rc != BWTM_OK) { delete x; return rc; }
+  *out = x;
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_merge(const bwtm_index* a, const bwtm_index* b, bwtm_index** out)
+{
+  TRY(ensure_ready());
+  if(!a || !b || !out) { return fail(BWTM_EINVAL, "bwtm_merge: null argument"); }
+  bwtm_ra* ra = nullptr;
+  TRY(bwtm_ra_create(a, b, &ra));
+  int rc = BWTM_OK;
+  if(b->m > 0) { rc = bwtm_search(a, b, 0, b->m - 1, ra); }
+  if(rc == BWTM_OK) { rc = bwtm_ra_finalize(ra); }
+  bwtm_index* x = nullptr;
+  if(rc == BWTM_OK) { rc = bwtm_interleave(a, b, ra, &x); }
+  if(rc == BWTM_OK) { rc = bwtm_index_encode(x); }
+  bwtm_ra_free(ra);
+  if(rc != BWTM_OK) { bwtm_index_free(x); return rc; }
+  *out = x;
+  return BWTM_OK;
+}
+
+//------------------------------------------------------------------------------
+// Measurement.
+
+extern "C" int bwtm_profile_enable(int on)
+{
+  TRY(ensure_ready());
+  profile_collect();
+  g_ctx.profiling = (on != 0);
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_profile_reset(void)
+{
+  profile_collect();
+  g_ctx.totals.clear(); g_ctx.order.clear();
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_profile_read(const char** names, double* total_ms, uint64_t* launches, int capacity)
+{
+  profile_collect();
+  int k = 0;
+  for(const char* name : g_ctx.order)
+  {
+    if(k < capacity)
+    {
+      auto& t = g_ctx.totals[name];
+      names[k] = name; total_ms[k] = t.first; launches[k] = t.second;
+    }
+    k++;
+  }
+  return k;
+}

@@ -1,0 +1,882 @@
+/*
+  bwtm_kernels.hip.h -- hand-written gfx950 (CDNA4, wave64) kernels of the rank-array /
+  interleave path.  Included by bwtm_api.hip only.
+
+  Kernel map (reference code each one replaces):
+    k_block_stats      BWT::build scan of the run stream            bwt.cpp:487-502
+    k_block_start      block_boundaries (block start positions)     bwt.cpp:496
+    k_build_sup/recs   native blocks -> device records ("transcode at upload")
+    k_sym_*            plain symbols -> device records (input tooling)
+    k_lf_walk          buildRA + BWT::inverse_select + BWT::rank    fmi.cpp:272-334, bwt.cpp:318-341, 445-464
+    k_chunk_popc       RA finalize (replaces the sort / merge-buffer / temp-file hierarchy,
+                       fmi.cpp:139-257, support.h:396-638)
+    k_interleave_*     mergeBWT                                     bwt.cpp:215-282
+    k_enc_*            RunBuffer + Run::write                       utils.h:121-142, support.h:256-282
+    k_fold_*           byte-offset carry of Run::write across segments (array.size() % 64, support.h:267)
+*/
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include "bwtm_device.h"
+
+namespace bwtm
+{
+
+constexpr int WAVE = 64;
+constexpr int BLOCK_THREADS = 256;
+
+// Read-only view of a device index for kernels.
+struct IndexView
+{
+  const uint4* recs;     // 4 x uint4 per record
+  const u64*   sup;      // SUP_STRIDE u64 per super
+  u64 n;                 // positions
+  u64 m;                 // sequences
+  u64 nrecs;
+  u64 C[8];              // C[c] = number of symbols smaller than c
+};
+
+//------------------------------------------------------------------------------
+// Wave helpers (wave64: every shuffle spans 64 lanes).
+
+__device__ inline u32 lane_id() { return threadIdx.x & 63u; }
+
+__device__ inline u64 shfl_u64(u64 v, int src)
+{
+  u32 lo = (u32)__shfl((int)(u32)v, src, WAVE);
+  u32 hi = (u32)__shfl((int)(u32)(v >> 32), src, WAVE);
+  return ((u64)hi << 32) | lo;
+}
+
+__device__ inline u64 shfl_up_u64(u64 v, int delta)
+{
+  u32 lo = (u32)__shfl_up((int)(u32)v, delta, WAVE);
+  u32 hi = (u32)__shfl_up((int)(u32)(v >> 32), delta, WAVE);
+  return ((u64)hi << 32) | lo;
+}
+
+// Inclusive prefix sum over the wave.
+__device__ inline u64 wave_incl_sum(u64 v)
+{
+#pragma unroll
+  for(int d = 1; d < WAVE; d <<= 1)
+  {
+    u64 t = shfl_up_u64(v, d);
+    if((int)lane_id() >= d) { v += t; }
+  }
+  return v;
+}
+
+__device__ inline u64 wave_incl_max(u64 v)
+{
+#pragma unroll
+  for(int d = 1; d < WAVE; d <<= 1)
+  {
+    u64 t = shfl_up_u64(v, d);
+    if((int)lane_id() >= d) { v = (t > v ? t : v); }
+  }
+  return v;
+}
+
+__device__ inline u64 wave_sum(u64 v)   { return shfl_u64(wave_incl_sum(v), WAVE - 1); }
+__device__ inline u64 wave_max(u64 v)   { return shfl_u64(wave_incl_max(v), WAVE - 1); }
+
+//------------------------------------------------------------------------------
+// Record access.
+
+__device__ inline void load_record(const uint4* recs, u64 q, u32 w[16])
+{
+  const uint4* p = recs + 4 * q;
+  uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+  w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+  w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w;
+  w[12] = d.x; w[13] = d.y; w[14] = d.z; w[15] = d.w;
+}
+
+// rank(i, c) for c in 1..5 on the device structure (BWT::rank, bwt.cpp:318-341).
+__device__ inline u64 index_rank(const IndexView& x, u64 i, u32 c)
+{
+  u32 w[16];
+  load_record(x.recs, i >> REC_SHIFT, w);
+  return x.sup[(i >> SUPER_SHIFT) * SUP_STRIDE + c] + rec_header(w, c) + rec_count(w, c, (u32)(i & (REC_POS - 1)));
+}
+
+// rank for all c in 1..5 at once (BWT::ranks, bwt.cpp:343-361); out[0] unused.
+__device__ inline void index_ranks(const IndexView& x, u64 i, u64 out[6])
+{
+  u32 w[16];
+  load_record(x.recs, i >> REC_SHIFT, w);
+  const u64* s = x.sup + (i >> SUPER_SHIFT) * SUP_STRIDE;
+  u32 j = (u32)(i & (REC_POS - 1));
+#pragma unroll
+  for(u32 c = 1; c < 6; c++) { out[c] = s[c] + rec_header(w, c) + rec_count(w, c, j); }
+}
+
+// 64-bit windows of the three bit-planes starting at sequence position pos (zero past the end).
+__device__ inline void load_window(const IndexView& x, u64 pos, u64& p0, u64& p1, u64& p2)
+{
+  u64 wi = pos >> 5;                  // global 32-position word index: record wi >> 2, chunk wi & 3
+  u32 sh = (u32)(pos & 31);
+  u64 last = 4 * x.nrecs;             // number of chunks
+  uint4 z = make_uint4(0, 0, 0, 0);
+  uint4 a = (wi     < last ? x.recs[wi]     : z);
+  uint4 b = (wi + 1 < last ? x.recs[wi + 1] : z);
+  uint4 c = (wi + 2 < last ? x.recs[wi + 2] : z);
+  u64 l0 = (u64)a.x | ((u64)b.x << 32), l1 = (u64)a.y | ((u64)b.y << 32), l2 = (u64)a.z | ((u64)b.z << 32);
+  p0 = l0 >> sh; p1 = l1 >> sh; p2 = l2 >> sh;
+  if(sh != 0)
+  {
+    p0 |= (u64)c.x << (64 - sh); p1 |= (u64)c.y << (64 - sh); p2 |= (u64)c.z << (64 - sh);
+  }
+}
+
+//------------------------------------------------------------------------------
+// Generic exclusive scans over u64 arrays (sum or max).  Three phases: per-tile reduce,
+// scan of the tile totals (recursive on the host side), per-tile scan + carry.
+
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = BLOCK_THREADS * SCAN_ITEMS;   // 2048
+
+template<int OP> __device__ inline u64 scan_op(u64 a, u64 b) { return (OP == 0 ? a + b : (a > b ? a : b)); }
+
+template<int OP>
+__device__ inline u64 block_reduce(u64 v, u64* lds)
+{
+  u64 w = (OP == 0 ? wave_sum(v) : wave_max(v));
+  if(lane_id() == 0) { lds[threadIdx.x >> 6] = w; }
+  __syncthreads();
+  u64 r = lds[0];
+  for(int k = 1; k < BLOCK_THREADS / WAVE; k++) { r = scan_op<OP>(r, lds[k]); }
+  __syncthreads();
+  return r;
+}
+
+template<int OP>
+__global__ void __launch_bounds__(BLOCK_THREADS) k_scan_reduce(const u64* in, u64* partial, u64 n)
+{
+  __shared__ u64 lds[BLOCK_THREADS / WAVE];
+  u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+  u64 acc = 0;
+  for(int k = 0; k < SCAN_ITEMS; k++) { if(base + k < n) { acc = scan_op<OP>(acc, in[base + k]); } }
+  u64 total = block_reduce<OP>(acc, lds);
+  if(threadIdx.x == 0) { partial[blockIdx.x] = total; }
+}
+
+// Exclusive scan of one tile; carry[blockIdx.x] (may be null for a single tile) is added.
+template<int OP>
+__global__ void __launch_bounds__(BLOCK_THREADS) k_scan_apply(const u64* in, u64* out, const u64* carry, u64 n)
+{
+  __shared__ u64 lds[BLOCK_THREADS / WAVE];
+  u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+  u64 item[SCAN_ITEMS];
+  u64 acc = 0;
+  for(int k = 0; k < SCAN_ITEMS; k++)
+  {
+    item[k] = (base + k < n ? in[base + k] : 0);
+    acc = scan_op<OP>(acc, item[k]);
+  }
+  u64 incl = (OP == 0 ? wave_incl_sum(acc) : wave_incl_max(acc));
+  u64 wave_total = shfl_u64(incl, WAVE - 1);
+  u64 excl = shfl_up_u64(incl, 1);
+  if(lane_id() == 0) { excl = 0; }
+  if(lane_id() == 0) { lds[threadIdx.x >> 6] = wave_total; }
+  __syncthreads();
+  u64 prefix = (carry ? carry[blockIdx.x] : 0);
+  for(int k = 0; k < (int)(threadIdx.x >> 6); k++) { prefix = scan_op<OP>(prefix, lds[k]); }
+  u64 run = scan_op<OP>(prefix, excl);
+  for(int k = 0; k < SCAN_ITEMS; k++)
+  {
+    if(base + k < n) { out[base + k] = run; }
+    run = scan_op<OP>(run, item[k]);
+  }
+}
+
+//------------------------------------------------------------------------------
+// K0a / K5: per native 64-byte block, the number of occurrences of every symbol
+// (BWT::build, bwt.cpp:487-502).  One lane per block.  cnt is SoA: cnt[c * stride + b].
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_block_stats(const u8* data, u64 nbytes, u64 nblocks, u64* cnt, u64 stride)
+{
+  u64 b = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(b >= nblocks) { return; }
+  u64 pos = b * RLE_BLOCK;
+  u64 end = pos + RLE_BLOCK; if(end > nbytes) { end = nbytes; }
+  u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+  while(pos < end)
+  {
+    u32 sym; u64 len;
+    run_decode(data, pos, sym, len);
+    c0 += (sym == 0 ? len : 0); c1 += (sym == 1 ? len : 0); c2 += (sym == 2 ? len : 0);
+    c3 += (sym == 3 ? len : 0); c4 += (sym == 4 ? len : 0); c5 += (sym == 5 ? len : 0);
+  }
+  cnt[0 * stride + b] = c0; cnt[1 * stride + b] = c1; cnt[2 * stride + b] = c2;
+  cnt[3 * stride + b] = c3; cnt[4 * stride + b] = c4; cnt[5 * stride + b] = c5;
+}
+
+// block_start[b] = sum over c of cum[c][b], b in [0, nblocks].
+__global__ void __launch_bounds__(BLOCK_THREADS) k_block_start(const u64* cum, u64 stride, u64 count, u64* block_start)
+{
+  u64 b = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(b >= count) { return; }
+  u64 s = 0;
+  for(int c = 0; c < 6; c++) { s += cum[c * stride + b]; }
+  block_start[b] = s;
+}
+
+// block_end[b] = block_start[b + 1] - 1 (the set bits of block_boundaries, bwt.cpp:496).
+__global__ void __launch_bounds__(BLOCK_THREADS) k_block_end(const u64* block_start, u64 nblocks, u64* block_end)
+{
+  u64 b = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(b < nblocks) { block_end[b] = block_start[b + 1] - 1; }
+}
+
+// Largest b in [0, nblocks) with block_start[b] <= p (p < n).
+__device__ inline u64 find_block(const u64* block_start, u64 nblocks, u64 p)
+{
+  u64 lo = 0, hi = nblocks;           // invariant: block_start[lo] <= p < block_start[hi]
+  while(hi - lo > 1)
+  {
+    u64 mid = (lo + hi) >> 1;
+    if(block_start[mid] <= p) { lo = mid; } else { hi = mid; }
+  }
+  return lo;
+}
+
+// Cursor over the native run stream positioned so that the current run covers position p.
+struct RunCursor
+{
+  const u8* data; u64 nbytes;
+  u64 rle;            // next byte to decode
+  u32 sym; u64 left;  // current run: symbol and positions left (including the one at the cursor)
+};
+
+// Positions the cursor at p (< n) and returns the counts of symbols 1..5 in [0, p).
+__device__ inline void seek_native(const u8* data, u64 nbytes, const u64* block_start, const u64* cum, u64 stride,
+  u64 nblocks, u64 p, RunCursor& cur, u64 abs[6])
+{
+  u64 b = find_block(block_start, nblocks, p);
+  u64 pos = block_start[b];
+  for(int c = 1; c < 6; c++) { abs[c] = cum[c * stride + b]; }
+  cur.data = data; cur.nbytes = nbytes; cur.rle = b * RLE_BLOCK;
+  while(true)
+  {
+    u32 sym; u64 len;
+    run_decode(data, cur.rle, sym, len);
+    u64 take = (pos + len > p ? p - pos : len);
+    abs[1] += (sym == 1 ? take : 0); abs[2] += (sym == 2 ? take : 0); abs[3] += (sym == 3 ? take : 0);
+    abs[4] += (sym == 4 ? take : 0); abs[5] += (sym == 5 ? take : 0);
+    if(pos + len > p) { cur.sym = sym; cur.left = len - take; return; }
+    pos += len;
+  }
+}
+
+// K0b: super table from the native stream.  One lane per super.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_build_sup(const u8* data, u64 nbytes, const u64* block_start,
+  const u64* cum, u64 stride, u64 nblocks, u64 n, u64* sup, u64 nsup)
+{
+  u64 s = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(s >= nsup) { return; }
+  u64 p = s << SUPER_SHIFT;
+  u64 abs[6] = {0, 0, 0, 0, 0, 0};
+  if(p >= n) { for(int c = 1; c < 6; c++) { abs[c] = cum[c * stride + nblocks]; } }
+  else { RunCursor cur; seek_native(data, nbytes, block_start, cum, stride, nblocks, p, cur, abs); }
+  for(int c = 0; c < SUP_STRIDE; c++) { sup[s * SUP_STRIDE + c] = (c >= 1 && c < 6 ? abs[c] : 0); }
+}
+
+// K0c: records from the native stream.  One lane per record.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_build_recs(const u8* data, u64 nbytes, const u64* block_start,
+  const u64* cum, u64 stride, u64 nblocks, u64 n, const u64* sup, uint4* recs, u64 nrecs)
+{
+  u64 q = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(q >= nrecs) { return; }
+  u64 p = q << REC_SHIFT;
+  u64 abs[6] = {0, 0, 0, 0, 0, 0};
+  u64 lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0, lo2 = 0, hi2 = 0;
+  if(p >= n) { for(int c = 1; c < 6; c++) { abs[c] = cum[c * stride + nblocks]; } }
+  else
+  {
+    RunCursor cur;
+    seek_native(data, nbytes, block_start, cum, stride, nblocks, p, cur, abs);
+    u32 t = 0;
+    u64 avail = n - p;                      // positions that exist from p on
+    u32 limit = (avail >= REC_POS ? (u32)REC_POS : (u32)avail);
+    while(t < limit)
+    {
+      if(cur.left == 0) { run_decode(cur.data, cur.rle, cur.sym, cur.left); }
+      u32 take = (cur.left > (u64)(limit - t) ? limit - t : (u32)cur.left);
+      u64 ml, mh; range_mask128(t, take, ml, mh);
+      if(cur.sym & 1) { lo0 |= ml; hi0 |= mh; }
+      if(cur.sym & 2) { lo1 |= ml; hi1 |= mh; }
+      if(cur.sym & 4) { lo2 |= ml; hi2 |= mh; }
+      t += take; cur.left -= take;
+    }
+  }
+  const u64* s = sup + (p >> SUPER_SHIFT) * SUP_STRIDE;
+  u32 rel[6]; u32 h[4];
+  for(int c = 1; c < 6; c++) { rel[c] = (u32)(abs[c] - s[c]); }
+  pack_header(rel, h);
+  uint4* dst = recs + 4 * q;
+  dst[0] = make_uint4((u32)lo0, (u32)lo1, (u32)lo2, h[0]);
+  dst[1] = make_uint4((u32)(lo0 >> 32), (u32)(lo1 >> 32), (u32)(lo2 >> 32), h[1]);
+  dst[2] = make_uint4((u32)hi0, (u32)hi1, (u32)hi2, h[2]);
+  dst[3] = make_uint4((u32)(hi0 >> 32), (u32)(hi1 >> 32), (u32)(hi2 >> 32), h[3]);
+}
+
+//------------------------------------------------------------------------------
+// Plain symbols (one byte each) -> records.  k_sym_counts: per-record symbol counts
+// (cnt[c * stride + q], c = 1..5 used); after an exclusive scan k_sym_recs writes the records.
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_sym_counts(const u8* sym, u64 n, u64 nrecs, u64* cnt, u64 stride)
+{
+  u64 q = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(q >= nrecs) { return; }
+  u64 p = q << REC_SHIFT;
+  u32 c[6] = {0, 0, 0, 0, 0, 0};
+  for(u32 t = 0; t < REC_POS && p + t < n; t++)
+  {
+    u32 s = sym[p + t];
+    c[0] += (s == 0); c[1] += (s == 1); c[2] += (s == 2); c[3] += (s == 3); c[4] += (s == 4); c[5] += (s == 5);
+  }
+  for(int k = 0; k < 6; k++) { cnt[k * stride + q] = c[k]; }
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_sym_sup(const u64* cum, u64 stride, u64 nrecs, u64* sup, u64 nsup)
+{
+  u64 s = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(s >= nsup) { return; }
+  u64 q = s << SUPER_REC_SHIFT; if(q > nrecs) { q = nrecs; }
+  for(int c = 0; c < SUP_STRIDE; c++) { sup[s * SUP_STRIDE + c] = (c >= 1 && c < 6 ? cum[c * stride + q] : 0); }
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_sym_recs(const u8* sym, u64 n, const u64* cum, u64 stride,
+  const u64* sup, uint4* recs, u64 nrecs)
+{
+  u64 q = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(q >= nrecs) { return; }
+  u64 p = q << REC_SHIFT;
+  u32 plane[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+  for(u32 k = 0; k < 4; k++)
+  {
+    u32 a = 0, b = 0, c = 0;
+    for(u32 t = 0; t < 32; t++)
+    {
+      u64 pos = p + 32 * k + t;
+      u32 s = (pos < n ? sym[pos] : 0);
+      a |= (s & 1u) << t; b |= ((s >> 1) & 1u) << t; c |= ((s >> 2) & 1u) << t;
+    }
+    plane[0][k] = a; plane[1][k] = b; plane[2][k] = c;
+  }
+  const u64* s = sup + (p >> SUPER_SHIFT) * SUP_STRIDE;
+  u32 rel[6]; u32 h[4];
+  for(int c = 1; c < 6; c++) { rel[c] = (u32)(cum[c * stride + q] - s[c]); }
+  pack_header(rel, h);
+  uint4* dst = recs + 4 * q;
+#pragma unroll
+  for(u32 k = 0; k < 4; k++) { dst[k] = make_uint4(plane[0][k], plane[1][k], plane[2][k], h[k]); }
+}
+
+//------------------------------------------------------------------------------
+// Batch queries (BWT::rank, BWT::inverse_select, BWT::extract) -- used by the facade and tests.
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_rank_batch(IndexView x, const u64* pos, const u8* comps, u64 count, u64* out)
+{
+  u64 k = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(k >= count) { return; }
+  u64 i = pos[k]; if(i > x.n) { i = x.n; }              // bwt.cpp:322
+  u32 c = comps[k];
+  if(c >= 6) { out[k] = 0; return; }                     // bwt.cpp:321
+  u64 r[6]; index_ranks(x, i, r);
+  u64 rest = r[1] + r[2] + r[3] + r[4] + r[5];
+  out[k] = (c == 0 ? i - rest : (c == 1 ? r[1] : (c == 2 ? r[2] : (c == 3 ? r[3] : (c == 4 ? r[4] : r[5])))));
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_inverse_select_batch(IndexView x, const u64* pos, u64 count, u64* out_rank, u8* out_comp)
+{
+  u64 k = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(k >= count) { return; }
+  u64 i = pos[k];
+  if(i >= x.n) { out_rank[k] = 0; out_comp[k] = 0; return; }   // bwt.cpp:449
+  u32 w[16]; load_record(x.recs, i >> REC_SHIFT, w);
+  u32 c = rec_symbol(w, (u32)(i & (REC_POS - 1)));
+  u64 r[6]; index_ranks(x, i, r);
+  out_comp[k] = (u8)c;
+  u64 rest = r[1] + r[2] + r[3] + r[4] + r[5];
+  out_rank[k] = (c == 0 ? i - rest : (c == 1 ? r[1] : (c == 2 ? r[2] : (c == 3 ? r[3] : (c == 4 ? r[4] : r[5])))));
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_extract(IndexView x, u64 first, u64 count, u8* out)
+{
+  u64 k = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(k >= count) { return; }
+  u64 i = first + k;
+  const u32* words = (const u32*)x.recs;
+  u64 wbase = (i >> REC_SHIFT) * REC_WORDS + ((i >> 5) & 3) * 4;
+  u32 t = (u32)(i & 31);
+  out[k] = (u8)(((words[wbase] >> t) & 1u) | (((words[wbase + 1] >> t) & 1u) << 1) | (((words[wbase + 2] >> t) & 1u) << 2));
+}
+
+//------------------------------------------------------------------------------
+// K1: the search.  Every lane walks LF over one sequence of B at a time:
+//     i = j; r = m_A; emit(i, r); loop { c = BWT_B[i]; if c == 0 stop;
+//     i = LF_B(i); r = LF_A(r, c); emit(i, r) }
+// which yields the same multiset of ranks as the reverse-trie DFS of buildRA
+// (fmi.cpp:272-334; single-position branch 296-303, which produces 93 % of the values, taken
+// for every node).  emit sets bit i + r of the interleaving bitvector: the B position i is
+// known, so the sorted rank array needs no sort at all.
+// Per step one 64-byte record of B and one of A are fetched (both addresses are known at the
+// top of the iteration, so the two HBM accesses overlap), plus two L2-resident super rows.
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_lf_walk(IndexView A, IndexView B, u64 seq_first, u64 seq_count, u32* bits)
+{
+  __shared__ u64 sC[16];
+  if(threadIdx.x == 0)
+  {
+#pragma unroll
+    for(int k = 0; k < 8; k++) { sC[k] = A.C[k]; sC[8 + k] = B.C[k]; }
+  }
+  __syncthreads();
+
+  const u64 stride = (u64)gridDim.x * BLOCK_THREADS;
+  u64 next = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  u64 i = 0, r = 0;
+  bool walking = false;
+  while(true)
+  {
+    if(!walking)
+    {
+      if(next >= seq_count) { break; }
+      i = seq_first + next; r = A.m;                          // fmi.cpp:286: trie root "$"
+      next += stride; walking = true;
+      u64 p = i + r;
+      atomicOr(bits + (p >> 5), 1u << (p & 31));
+    }
+    u32 wb[16], wa[16];
+    load_record(B.recs, i >> REC_SHIFT, wb);
+    load_record(A.recs, r >> REC_SHIFT, wa);
+    const u64* sb = B.sup + (i >> SUPER_SHIFT) * SUP_STRIDE;
+    const u64* sa = A.sup + (r >> SUPER_SHIFT) * SUP_STRIDE;
+    u64 sb1 = sb[1], sb2 = sb[2], sb3 = sb[3], sb4 = sb[4], sb5 = sb[5];
+    u64 sa1 = sa[1], sa2 = sa[2], sa3 = sa[3], sa4 = sa[4], sa5 = sa[5];
+
+    u32 jb = (u32)(i & (REC_POS - 1)), ja = (u32)(r & (REC_POS - 1));
+    u32 c = rec_symbol(wb, jb);                               // BWT_B[i]
+    if(c == 0) { walking = false; continue; }                 // fmi.cpp:299: start of the sequence
+    u64 supb = (c == 1 ? sb1 : (c == 2 ? sb2 : (c == 3 ? sb3 : (c == 4 ? sb4 : sb5))));
+    u64 supa = (c == 1 ? sa1 : (c == 2 ? sa2 : (c == 3 ? sa3 : (c == 4 ? sa4 : sa5))));
+    i = sC[8 + c] + supb + rec_header(wb, c) + rec_count(wb, c, jb);   // LF_B(i), utils.h:335-341
+    r = sC[c] + supa + rec_header(wa, c) + rec_count(wa, c, ja);       // LF_A(r, c), utils.h:343-348
+    u64 p = i + r;
+    atomicOr(bits + (p >> 5), 1u << (p & 31));
+  }
+}
+
+//------------------------------------------------------------------------------
+// K2: rank-array finalize.  A chunk is 64 output records = 8192 bits = 128 words; one wave
+// per chunk counts the set bits.  (An exclusive scan of the counts follows.)
+
+constexpr int CHUNK_WORDS = 128;
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_chunk_popc(const u64* bits, u64 nchunks, u64* cnt)
+{
+  u64 chunk = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
+  if(chunk >= nchunks) { return; }
+  const u64* w = bits + chunk * CHUNK_WORDS + 2 * lane_id();
+  u64 v = (u64)__builtin_popcountll(w[0]) + (u64)__builtin_popcountll(w[1]);
+  v = wave_sum(v);
+  if(lane_id() == 0) { cnt[chunk] = v; }
+}
+
+// RA[i] for every B position (tests / facade): one wave per chunk, one lane per record.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_ra_extract(const u64* bits, const u64* chunk_base, u64 nchunks, u64 nb, u64* ra)
+{
+  u64 chunk = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
+  if(chunk >= nchunks) { return; }
+  u64 q = chunk * 64 + lane_id();
+  u64 m0 = bits[2 * q], m1 = bits[2 * q + 1];
+  u64 mine = (u64)__builtin_popcountll(m0) + (u64)__builtin_popcountll(m1);
+  u64 incl = wave_incl_sum(mine);
+  u64 i = chunk_base[chunk] + incl - mine;
+  u64 base = q << REC_SHIFT;
+  while(m0) { u32 t = (u32)__builtin_ctzll(m0); m0 &= m0 - 1; if(i < nb) { ra[i] = base + t - i; } i++; }
+  while(m1) { u32 t = (u32)__builtin_ctzll(m1); m1 &= m1 - 1; if(i < nb) { ra[i] = base + 64 + t - i; } i++; }
+}
+
+//------------------------------------------------------------------------------
+// K3: interleave (mergeBWT, bwt.cpp:215-282).  Output position p takes the next symbol of B
+// when bit p of the interleaving bitvector is set and the next symbol of A otherwise, so
+// an output record needs b_off = rank1(bits, 128 q) and a_off = 128 q - b_off, and its
+// header is rank_A(a_off) + rank_B(b_off).  One lane per output record.
+
+// Number of set bits before output record q, given the chunk bases.
+__device__ inline u64 bits_before_record(const u64* bits, const u64* chunk_base, u64 q)
+{
+  u64 chunk = q >> 6;
+  u64 b = chunk_base[chunk];
+  for(u64 w = chunk * CHUNK_WORDS; w < 2 * q; w++) { b += (u64)__builtin_popcountll(bits[w]); }
+  return b;
+}
+
+// Super table of the output: absolute counts at the start of every super.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_interleave_sup(IndexView A, IndexView B, const u64* bits, const u64* chunk_base,
+  u64 n_out, u64* sup, u64 nsup)
+{
+  u64 s = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(s >= nsup) { return; }
+  u64 q = s << SUPER_REC_SHIFT;
+  u64 b_off = bits_before_record(bits, chunk_base, q);
+  u64 a_off = (q << REC_SHIFT) - b_off;
+  if(a_off > A.n) { a_off = A.n; }
+  if(b_off > B.n) { b_off = B.n; }
+  u64 ra[6], rb[6];
+  index_ranks(A, a_off, ra); index_ranks(B, b_off, rb);
+  for(int c = 0; c < SUP_STRIDE; c++) { sup[s * SUP_STRIDE + c] = (c >= 1 && c < 6 ? ra[c] + rb[c] : 0); }
+  (void)n_out;
+}
+
+// Deposits the next symbols of A (where the mask bit is 0) and B (where it is 1) into 64
+// output positions.  a* / b* are 64-bit windows of the source planes.
+__device__ inline void deposit64(u64 mask, u64 a0, u64 a1, u64 a2, u64 b0, u64 b1, u64 b2, u64& o0, u64& o1, u64& o2)
+{
+  o0 = 0; o1 = 0; o2 = 0;
+  for(u32 t = 0; t < 64; t++)
+  {
+    u64 bit = (mask >> t) & 1;
+    u64 sel = 0 - bit;                        // all ones when the symbol comes from B
+    o0 |= ((((b0 & sel) | (a0 & ~sel))) & 1) << t;
+    o1 |= ((((b1 & sel) | (a1 & ~sel))) & 1) << t;
+    o2 |= ((((b2 & sel) | (a2 & ~sel))) & 1) << t;
+    u32 sb = (u32)bit, sa = 1u - sb;
+    b0 >>= sb; b1 >>= sb; b2 >>= sb;
+    a0 >>= sa; a1 >>= sa; a2 >>= sa;
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_interleave(IndexView A, IndexView B, const u64* bits, const u64* chunk_base,
+  u64 nchunks, const u64* sup_out, uint4* recs_out, u64 nrecs_out)
+{
+  u64 chunk = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
+  if(chunk >= nchunks) { return; }
+  u64 q = chunk * 64 + lane_id();
+  u64 m0 = bits[2 * q], m1 = bits[2 * q + 1];
+  u64 mine = (u64)__builtin_popcountll(m0) + (u64)__builtin_popcountll(m1);
+  u64 incl = wave_incl_sum(mine);
+  if(q >= nrecs_out) { return; }
+  u64 b_off = chunk_base[chunk] + incl - mine;
+  u64 a_off = (q << REC_SHIFT) - b_off;
+
+  // Header: counts of symbols 1..5 before output position 128 q.
+  u64 ra[6], rb[6];
+  index_ranks(A, (a_off > A.n ? A.n : a_off), ra);
+  index_ranks(B, (b_off > B.n ? B.n : b_off), rb);
+  const u64* s = sup_out + (q >> SUPER_REC_SHIFT) * SUP_STRIDE;
+  u32 rel[6]; u32 h[4];
+  for(int c = 1; c < 6; c++) { rel[c] = (u32)(ra[c] + rb[c] - s[c]); }
+  pack_header(rel, h);
+
+  // Planes: two halves of 64 positions.
+  u64 a0, a1, a2, b0, b1, b2, lo0, lo1, lo2, hi0, hi1, hi2;
+  load_window(A, a_off, a0, a1, a2); load_window(B, b_off, b0, b1, b2);
+  deposit64(m0, a0, a1, a2, b0, b1, b2, lo0, lo1, lo2);
+  u64 nb0 = (u64)__builtin_popcountll(m0);
+  load_window(A, a_off + 64 - nb0, a0, a1, a2); load_window(B, b_off + nb0, b0, b1, b2);
+  deposit64(m1, a0, a1, a2, b0, b1, b2, hi0, hi1, hi2);
+
+  uint4* dst = recs_out + 4 * q;
+  dst[0] = make_uint4((u32)lo0, (u32)lo1, (u32)lo2, h[0]);
+  dst[1] = make_uint4((u32)(lo0 >> 32), (u32)(lo1 >> 32), (u32)(lo2 >> 32), h[1]);
+  dst[2] = make_uint4((u32)hi0, (u32)hi1, (u32)hi2, h[2]);
+  dst[3] = make_uint4((u32)(hi0 >> 32), (u32)(hi1 >> 32), (u32)(hi2 >> 32), h[3]);
+}
+
+//------------------------------------------------------------------------------
+// K4: canonical run encoder (RunBuffer + Run::write; utils.h:121-142, support.h:256-282).
+//
+// A "head" is a position whose symbol differs from its predecessor (position 0 is a head; a
+// virtual head sits at position n).  Every head h > 0 is an EVENT: the maximal run
+// [previous head, h) with symbol sym(h - 1) ends there and is encoded.  Events are encoded in
+// order; a run shorter than 42 is always one byte, a longer run takes a number of bytes that
+// depends on the byte offset modulo 64 (support.h:267-279).
+//
+//   tile    = 64 positions (one lane)      chunk = 64 tiles (one wave step)
+//   segment = SEG_CHUNKS chunks, processed sequentially by one wave
+//
+//   k_enc_lasthead : last head of every segment (+1; 0 = none)  -> exclusive max-scan
+//   k_enc_size     : for every segment, bytes emitted as a function of the start offset
+//                    mod 64 (lane o evaluates hypothesis o)       -> folded by k_fold_*
+//   k_enc_emit     : writes the bytes of every segment at its now known offset
+
+constexpr int SEG_CHUNKS = 16;
+constexpr u64 SEG_TILES = (u64)SEG_CHUNKS * 64;
+constexpr u64 NONE = 0;   // "position + 1" encoding: 0 means no head
+
+struct TileInfo
+{
+  u64 p0, p1, p2;    // planes of the tile
+  u32 prev;          // symbol at tile_base - 1
+  u64 H;             // heads (including position 0 and the virtual head at n)
+  u64 E;             // events (H without position 0)
+};
+
+// Planes of tile T (64 positions) of the encoded index.
+__device__ inline void load_tile(const uint4* recs, u64 nrecs, u64 T, u64& p0, u64& p1, u64& p2)
+{
+  u64 ch = 2 * T;                                 // 16-byte chunk index: record T >> 1, chunks 2 (T & 1) and + 1
+  if(ch + 1 < 4 * nrecs)
+  {
+    uint4 a = recs[ch], b = recs[ch + 1];
+    p0 = (u64)a.x | ((u64)b.x << 32); p1 = (u64)a.y | ((u64)b.y << 32); p2 = (u64)a.z | ((u64)b.z << 32);
+  }
+  else { p0 = p1 = p2 = 0; }
+}
+
+__device__ inline u32 symbol_at(const uint4* recs, u64 pos)
+{
+  const u32* words = (const u32*)recs;
+  u64 wbase = (pos >> REC_SHIFT) * REC_WORDS + ((pos >> 5) & 3) * 4;
+  u32 t = (u32)(pos & 31);
+  return ((words[wbase] >> t) & 1u) | (((words[wbase + 1] >> t) & 1u) << 1) | (((words[wbase + 2] >> t) & 1u) << 2);
+}
+
+// Heads and events of one tile.  `prev` is the symbol at tile_base - 1 (ignored for tile 0).
+__device__ inline void tile_heads(TileInfo& ti, u64 tile_base, u64 n)
+{
+  u64 q0 = (ti.p0 << 1) | (ti.prev & 1u), q1 = (ti.p1 << 1) | ((ti.prev >> 1) & 1u), q2 = (ti.p2 << 1) | ((ti.prev >> 2) & 1u);
+  u64 D = (ti.p0 ^ q0) | (ti.p1 ^ q1) | (ti.p2 ^ q2);
+  if(tile_base == 0) { D |= 1; }
+  u64 valid = (n >= tile_base + 64 ? ~0ull : (n <= tile_base ? 0ull : ((1ull << (n - tile_base)) - 1)));
+  D &= valid;
+  if(n >= tile_base && n < tile_base + 64) { D |= 1ull << (n - tile_base); }
+  ti.H = D;
+  ti.E = (tile_base == 0 ? D & ~1ull : D);
+}
+
+// Symbol of the run that ends at in-tile bit t (the symbol at position tile_base + t - 1).
+__device__ inline u32 event_symbol(const TileInfo& ti, u32 t)
+{
+  if(t == 0) { return ti.prev; }
+  u32 s = t - 1;
+  return (u32)((ti.p0 >> s) & 1) | ((u32)((ti.p1 >> s) & 1) << 1) | ((u32)((ti.p2 >> s) & 1) << 2);
+}
+
+// Loads the tiles of one chunk (lane = tile) and computes heads; `carry_prev` is the symbol
+// before the chunk (wave-uniform).  Returns the symbol at the end of the chunk for the next one.
+__device__ inline u32 chunk_tiles(const uint4* recs, u64 nrecs, u64 first_tile, u64 n, u32 carry_prev, TileInfo& ti)
+{
+  u64 T = first_tile + lane_id();
+  load_tile(recs, nrecs, T, ti.p0, ti.p1, ti.p2);
+  u32 last = (u32)((ti.p0 >> 63) & 1) | ((u32)((ti.p1 >> 63) & 1) << 1) | ((u32)((ti.p2 >> 63) & 1) << 2);
+  u32 up = (u32)__shfl_up((int)last, 1, WAVE);
+  ti.prev = (lane_id() == 0 ? carry_prev : up);
+  tile_heads(ti, T << 6, n);
+  return (u32)__shfl((int)last, WAVE - 1, WAVE);
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_enc_lasthead(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 nseg, u64* lasthead)
+{
+  u64 seg = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
+  if(seg >= nseg) { return; }
+  u64 first = seg * SEG_TILES;
+  u32 carry = (first == 0 ? 0u : symbol_at(recs, (first << 6) - 1));
+  u64 best = NONE;
+  for(int k = 0; k < SEG_CHUNKS; k++)
+  {
+    u64 ft = first + (u64)k * 64;
+    if(ft >= ntiles) { break; }
+    TileInfo ti;
+    carry = chunk_tiles(recs, nrecs, ft, n, carry, ti);
+    u64 T = ft + lane_id();
+    u64 mine = (ti.H != 0 && T < ntiles ? (T << 6) + (63 - (u64)__builtin_clzll(ti.H)) + 1 : NONE);
+    u64 m = wave_max(mine);
+    if(m > best) { best = m; }
+  }
+  if(lane_id() == 0) { lasthead[seg] = best; }
+}
+
+// Per-lane event statistics of a tile: number of events and of long events.
+// `before` = (position of the last head before this tile) + 1.
+__device__ inline void tile_event_stats(const TileInfo& ti, u64 tile_base, u64 before, u32& nev, u32& nlong)
+{
+  nev = (u32)__builtin_popcountll(ti.E); nlong = 0;
+  u64 h = ti.H;
+  u64 last = before;                 // position + 1 of the most recent head
+  while(h)
+  {
+    u32 t = (u32)__builtin_ctzll(h); h &= h - 1;
+    u64 pos = tile_base + t;
+    if(pos > 0 && (pos + 1 - last) >= MAX_RUN) { nlong++; }
+    last = pos + 1;
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_enc_size(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 nseg,
+  const u64* prevhead, u32* table)
+{
+  u64 seg = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
+  if(seg >= nseg) { return; }
+  u64 first = seg * SEG_TILES;
+  u32 carry = (first == 0 ? 0u : symbol_at(recs, (first << 6) - 1));
+  u64 last = prevhead[seg];          // (last head before the segment) + 1, wave-uniform
+  u64 acc = 0;                       // bytes emitted so far under hypothesis "start offset = lane"
+  const u32 o = lane_id();
+  for(int k = 0; k < SEG_CHUNKS; k++)
+  {
+    u64 ft = first + (u64)k * 64;
+    if(ft >= ntiles) { break; }
+    TileInfo ti;
+    carry = chunk_tiles(recs, nrecs, ft, n, carry, ti);
+    u64 T = ft + lane_id();
+    if(T >= ntiles) { ti.H = 0; ti.E = 0; }
+    u64 lh = (ti.H != 0 ? (T << 6) + (63 - (u64)__builtin_clzll(ti.H)) + 1 : NONE);
+    u64 incl = wave_incl_max(lh);
+    u64 before = shfl_up_u64(incl, 1);
+    if(lane_id() == 0) { before = NONE; }
+    if(last > before) { before = last; }
+    u32 nev, nlong;
+    tile_event_stats(ti, T << 6, before, nev, nlong);
+    u64 chunk_events = wave_sum(nev);
+    bool slow = (__ballot(nlong > 0) != 0);
+    if(!slow) { acc += chunk_events; }
+    else
+    {
+      for(int t = 0; t < WAVE; t++)
+      {
+        u32 t_nlong = (u32)__shfl((int)nlong, t, WAVE);
+        u32 t_nev = (u32)__shfl((int)nev, t, WAVE);
+        if(t_nlong == 0) { acc += t_nev; continue; }
+        u64 h = shfl_u64(ti.H, t);
+        u64 cur = shfl_u64(before, t);
+        u64 tb = (ft + (u64)t) << 6;
+        while(h)
+        {
+          u32 b = (u32)__builtin_ctzll(h); h &= h - 1;
+          u64 pos = tb + b;
+          if(pos > 0)
+          {
+            u64 len = pos + 1 - cur;
+            acc += (len < MAX_RUN ? 1 : long_run_bytes((u64)o + acc, len));
+          }
+          cur = pos + 1;
+        }
+      }
+    }
+    u64 m = shfl_u64(incl, WAVE - 1);
+    if(m > last) { last = m; }
+  }
+  table[seg * 64 + o] = (u32)acc;
+}
+
+// Fold 1: composition of the segment tables of one group (lane o = start offset hypothesis).
+constexpr int FOLD_GROUP = 256;
+
+__global__ void __launch_bounds__(WAVE) k_fold_group(const u32* table, u64 nseg, u64* group_table)
+{
+  u64 g = blockIdx.x;
+  u64 s0 = g * FOLD_GROUP, s1 = s0 + FOLD_GROUP; if(s1 > nseg) { s1 = nseg; }
+  u64 acc = 0; u32 o = lane_id();
+  for(u64 s = s0; s < s1; s++) { acc += table[s * 64 + ((o + acc) & 63)]; }
+  group_table[g * 64 + o] = acc;
+}
+
+// Fold 2: sequential pass over the groups from offset 0; group_base[ngroups] = total bytes.
+__global__ void __launch_bounds__(WAVE) k_fold_top(const u64* group_table, u64 ngroups, u64* group_base)
+{
+  if(threadIdx.x != 0) { return; }
+  u64 off = 0;
+  for(u64 g = 0; g < ngroups; g++) { group_base[g] = off; off += group_table[g * 64 + (off & 63)]; }
+  group_base[ngroups] = off;
+}
+
+// Fold 3: byte offset of every segment.
+__global__ void __launch_bounds__(WAVE) k_fold_seg(const u32* table, u64 nseg, const u64* group_base, u64* seg_base)
+{
+  if(threadIdx.x != 0) { return; }
+  u64 g = blockIdx.x;
+  u64 s0 = g * FOLD_GROUP, s1 = s0 + FOLD_GROUP; if(s1 > nseg) { s1 = nseg; }
+  u64 off = group_base[g];
+  for(u64 s = s0; s < s1; s++) { seg_base[s] = off; off += table[s * 64 + (off & 63)]; }
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 nseg,
+  const u64* prevhead, const u64* seg_base, u8* out)
+{
+  u64 seg = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
+  if(seg >= nseg) { return; }
+  u64 first = seg * SEG_TILES;
+  u32 carry = (first == 0 ? 0u : symbol_at(recs, (first << 6) - 1));
+  u64 last = prevhead[seg];
+  u64 off = seg_base[seg];           // wave-uniform byte offset
+  for(int k = 0; k < SEG_CHUNKS; k++)
+  {
+    u64 ft = first + (u64)k * 64;
+    if(ft >= ntiles) { break; }
+    TileInfo ti;
+    carry = chunk_tiles(recs, nrecs, ft, n, carry, ti);
+    u64 T = ft + lane_id();
+    if(T >= ntiles) { ti.H = 0; ti.E = 0; }
+    u64 lh = (ti.H != 0 ? (T << 6) + (63 - (u64)__builtin_clzll(ti.H)) + 1 : NONE);
+    u64 incl = wave_incl_max(lh);
+    u64 before = shfl_up_u64(incl, 1);
+    if(lane_id() == 0) { before = NONE; }
+    if(last > before) { before = last; }
+    u32 nev, nlong;
+    tile_event_stats(ti, T << 6, before, nev, nlong);
+    u64 ev_incl = wave_incl_sum(nev);
+    u64 chunk_events = shfl_u64(ev_incl, WAVE - 1);
+    bool slow = (__ballot(nlong > 0) != 0);
+    if(!slow)
+    {
+      // Every event is a run shorter than 42: one byte each, in position order.
+      u8* dst = out + off + (ev_incl - nev);
+      u64 h = ti.H, cur = before, tb = T << 6;
+      while(h)
+      {
+        u32 b = (u32)__builtin_ctzll(h); h &= h - 1;
+        u64 pos = tb + b;
+        if(pos > 0)
+        {
+          u64 len = pos + 1 - cur;
+          *dst++ = (u8)(event_symbol(ti, b) + 6 * (len - 1));     // Run::encodeBasic, support.h:231-234
+        }
+        cur = pos + 1;
+      }
+      off += chunk_events;
+    }
+    else
+    {
+      // Some run of >= 42 ends here: encode the chunk sequentially (all lanes follow, lane 0 writes).
+      for(int t = 0; t < WAVE; t++)
+      {
+        TileInfo tt;
+        tt.p0 = shfl_u64(ti.p0, t); tt.p1 = shfl_u64(ti.p1, t); tt.p2 = shfl_u64(ti.p2, t);
+        tt.prev = (u32)__shfl((int)ti.prev, t, WAVE);
+        u64 h = shfl_u64(ti.H, t);
+        u64 cur = shfl_u64(before, t);
+        u64 tb = (ft + (u64)t) << 6;
+        while(h)
+        {
+          u32 b = (u32)__builtin_ctzll(h); h &= h - 1;
+          u64 pos = tb + b;
+          if(pos > 0)
+          {
+            u64 len = pos + 1 - cur;
+            u32 sym = event_symbol(tt, b);
+            if(len < MAX_RUN) { if(lane_id() == 0) { out[off] = (u8)(sym + 6 * (len - 1)); } off += 1; }
+            else
+            {
+              u64 nb = long_run_bytes(off, len);
+              if(lane_id() == 0) { long_run_write(out, off, sym, len); }
+              off += nb;
+            }
+          }
+          cur = pos + 1;
+        }
+      }
+    }
+    u64 m = shfl_u64(incl, WAVE - 1);
+    if(m > last) { last = m; }
+  }
+}
+
+} // namespace bwtm

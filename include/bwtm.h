@@ -1,0 +1,152 @@
+/*
+  bwtm.h -- C ABI of the MI355X-native rank-array / interleave path of bwt-merge.
+
+  The reference (jltsiren/bwt-merge) has no FFI: its seam for this path is the C++ API
+      FMI::FMI(FMI& a, FMI& b, MergeParameters)          fmi.h:110, fmi.cpp:336-369
+      BWT::BWT(BWT& a, BWT& b, RankArray& ra)            bwt.h:73,  bwt.cpp:286-314
+  called from merge() in bwt_merge.cpp:287-299.  This header is the boundary a maintainer
+  binds instead; the C++ facade in bwt-merge_amd/csrc/host keeps the
+  reference's class and member names and routes them here.
+
+  Conventions
+    * Plain pointers and sizes only.  Host pointers unless a parameter says "device".
+    * Every function returns 0 on success and a non-zero BWTM_E* code on failure;
+      bwtm_last_error() returns a message for the calling thread's last failure.
+      (The reference prints to std::cerr and calls std::exit(EXIT_FAILURE); the facade and
+      the CLI convert the status codes back into that behaviour.)
+    * Calls are blocking and not re-entrant per handle; one host thread per GPU.
+    * Device buffers are owned by the library behind opaque handles; host output buffers
+      are owned by the caller (sizes are queried first).
+    * All integers are unsigned 64-bit like the reference's size_type (utils.h:44).
+*/
+#ifndef BWTM_H
+#define BWTM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BWTM_SIGMA 6            /* Run::SIGMA, support.h:228 */
+#define BWTM_RLE_BLOCK 64       /* Run::BLOCK_SIZE, support.h:227 */
+
+enum
+{
+  BWTM_OK = 0,
+  BWTM_EINVAL = 1,              /* bad argument / malformed input */
+  BWTM_ENODEV = 2,              /* no usable GPU, or HIP runtime failure */
+  BWTM_ENOMEM = 3,              /* device or host allocation failed */
+  BWTM_EALPHABET = 4            /* fmi.cpp:338-342: cannot merge BWTs with different alphabets */
+};
+
+typedef struct bwtm_index bwtm_index;   /* device-resident FM-index: replaces a loaded FMI (fmi.h:225-226) */
+typedef struct bwtm_ra    bwtm_ra;      /* device-resident rank array: replaces RankArray (support.h:576-638) */
+
+/* --- library ------------------------------------------------------------------------ */
+
+/* Selects the HIP device for the calling process and creates the library's stream. */
+int bwtm_init(int device);
+const char* bwtm_last_error(void);
+/* Blocks until all work queued by the library has finished. */
+int bwtm_synchronize(void);
+
+/* --- index: BWT::load + BWT::build (bwt.cpp:132-148, 476-512) on the device ------------ */
+
+/* Uploads a run-length encoded BWT in the native byte format (the BlockArray of
+   BWT::data, bwt.h:173) and builds the device rank structure from it.
+   `C` may be NULL (then it is derived from the symbol counts like Alphabet(counts),
+   support.cpp:84-91). */
+int bwtm_index_upload(const uint8_t* data, uint64_t nbytes, uint64_t sequences, uint64_t bases,
+                      const uint64_t C[BWTM_SIGMA + 1], bwtm_index** out);
+/* Same, from a device buffer that already holds the native bytes (the bytes are copied). */
+int bwtm_index_from_device(const void* device_data, uint64_t nbytes, uint64_t sequences, uint64_t bases,
+                           const uint64_t C[BWTM_SIGMA + 1], bwtm_index** out);
+/* Builds an index directly from a plain symbol string on the device (one comp value 0..5
+   per byte, `bases` of them; sequences = number of 0 symbols).  Used by the input tooling. */
+int bwtm_index_from_symbols_device(const void* device_symbols, uint64_t bases, bwtm_index** out);
+void bwtm_index_free(bwtm_index* index);
+
+uint64_t bwtm_index_bases(const bwtm_index* index);       /* BWT::size(),      bwt.h:108 */
+uint64_t bwtm_index_sequences(const bwtm_index* index);   /* BWT::sequences(), bwt.h:109 */
+uint64_t bwtm_index_bytes(const bwtm_index* index);       /* BWT::bytes(),     bwt.h:110 (0 until encoded) */
+uint64_t bwtm_index_blocks(const bwtm_index* index);      /* number of 64-byte blocks */
+void     bwtm_index_C(const bwtm_index* index, uint64_t C[BWTM_SIGMA + 1]);   /* Alphabet::C */
+
+/* Makes sure the native byte stream (and its samples) exist on the device: runs the
+   canonical run encoder (Run::write semantics, support.h:256-282) and the sample builder
+   (BWT::build, bwt.cpp:476-512) if the index was produced by bwtm_interleave(). */
+int bwtm_index_encode(bwtm_index* index);
+/* Drops the native byte stream and samples, keeping only the device rank structure
+   (what a chained merge needs as its next input). */
+int bwtm_index_drop_native(bwtm_index* index);
+
+/* Copies the native bytes to the host (`capacity` >= bwtm_index_bytes()). */
+int bwtm_index_download_data(bwtm_index* index, uint8_t* out, uint64_t capacity);
+/* Samples in the form BWT::build computes them: block_end[blocks] = last sequence position
+   of each block (the set bits of block_boundaries, bwt.h:176) and cum[6][blocks + 1]
+   row-major = CumulativeArray::sum(k) of samples[c] (support.h:338-343). */
+int bwtm_index_download_samples(bwtm_index* index, uint64_t* block_end, uint64_t* cum);
+
+/* Queries on the device structure (batch forms of BWT::rank, bwt.cpp:318-341, and
+   BWT::inverse_select, bwt.cpp:445-464).  Arrays are host arrays of length `count`. */
+int bwtm_rank_batch(const bwtm_index* index, const uint64_t* positions, const uint8_t* comps,
+                    uint64_t count, uint64_t* out_ranks);
+int bwtm_inverse_select_batch(const bwtm_index* index, const uint64_t* positions, uint64_t count,
+                              uint64_t* out_ranks, uint8_t* out_comps);
+/* Plain symbols [first, first + count) (BWT::extract, bwt.h:134-164), one byte each. */
+int bwtm_extract(const bwtm_index* index, uint64_t first, uint64_t count, uint8_t* out);
+
+/* --- rank array: buildRA + mergeRA + RankArray (fmi.cpp:139-334, support.h:576-638) ---- */
+
+/* An empty rank array for inserting `b` into `a`. */
+int bwtm_ra_create(const bwtm_index* a, const bwtm_index* b, bwtm_ra** out);
+/* Same, but the interleaving bitvector lives in a caller-owned, ZEROED device buffer of at
+   least bwtm_ra_buffer_bytes(a, b) bytes (e.g. a tensor that a collective library can reduce
+   in place).  The buffer must outlive the rank array. */
+uint64_t bwtm_ra_buffer_bytes(const bwtm_index* a, const bwtm_index* b);
+int bwtm_ra_create_on(const bwtm_index* a, const bwtm_index* b, void* device_buffer, uint64_t nbytes, bwtm_ra** out);
+void bwtm_ra_free(bwtm_ra* ra);
+/* Search phase for the sequences [seq_first, seq_last] of b (closed range, like the
+   sequence blocks of ParallelLoop, utils.cpp:169-209).  May be called for several
+   disjoint ranges (e.g. one range per GPU); results accumulate in `ra`. */
+int bwtm_search(const bwtm_index* a, const bwtm_index* b, uint64_t seq_first, uint64_t seq_last, bwtm_ra* ra);
+/* The device buffer that holds the rank array as the interleaving bitvector (bit i + RA[i]
+   set for every position i of b; 64-bit words, little-endian bit order) so that shards
+   computed on different GPUs can be combined with one collective (sum == or, set bits are
+   disjoint). */
+int bwtm_ra_device_buffer(bwtm_ra* ra, void** device_ptr, uint64_t* nbytes);
+/* Finishes the rank array after all bwtm_search() calls / the exchange. */
+int bwtm_ra_finalize(bwtm_ra* ra);
+uint64_t bwtm_ra_values(const bwtm_ra* ra);   /* number of set bits after finalize (must equal bases of b) */
+/* RA[i] for every position i of b (what the reference stores as (rank, count) runs). */
+int bwtm_ra_download(bwtm_ra* ra, uint64_t* out, uint64_t capacity);
+/* The raw bitvector words. */
+int bwtm_ra_download_bits(bwtm_ra* ra, uint64_t* out_words, uint64_t capacity_words);
+
+/* --- interleave: BWT::BWT(a, b, ra) (bwt.cpp:286-314) ------------------------------------ */
+
+/* Interleaves a and b according to a finalized rank array.  The result is a device index
+   (header, rank structure, C = C_a + C_b); call bwtm_index_encode() for the native bytes.
+   a, b and ra stay valid (the facade frees them to mirror "destroying them"). */
+int bwtm_interleave(const bwtm_index* a, const bwtm_index* b, bwtm_ra* ra, bwtm_index** out);
+
+/* --- the whole path: FMI::FMI(a, b, parameters) (fmi.cpp:336-369) -------------------------- */
+
+/* search over all sequences of b + finalize + interleave + encode + samples. */
+int bwtm_merge(const bwtm_index* a, const bwtm_index* b, bwtm_index** out);
+
+/* --- measurement ----------------------------------------------------------------------------- */
+
+/* When enabled, every kernel launch is bracketed by HIP events on the library's stream. */
+int bwtm_profile_enable(int on);
+int bwtm_profile_reset(void);
+/* Per-kernel totals since the last reset: returns the number of distinct kernels; fills up to
+   `capacity` entries.  names[k] points to a static string. */
+int bwtm_profile_read(const char** names, double* total_ms, uint64_t* launches, int capacity);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* BWTM_H */

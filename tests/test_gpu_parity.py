@@ -1,0 +1,201 @@
+"""Parity of the HIP path against the CPU oracle, stage by stage, through the C ABI.
+Integer / byte / index work throughout: every comparison is bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(bwtm):
+    bwtm.init(0)
+    return bwtm
+
+
+def cum_counts(sym):
+    cum = np.zeros((6, sym.size + 1), dtype=np.int64)
+    for c in range(6):
+        cum[c, 1:] = np.cumsum(sym == c)
+    return cum
+
+
+def run_symbols(rng, nruns, lengths):
+    syms = rng.integers(0, 6, nruns)
+    for k in range(1, nruns):                      # adjacent runs differ (maximal runs)
+        if syms[k] == syms[k - 1]:
+            syms[k] = (syms[k] + 1) % 6
+    lens = rng.choice(lengths, nruns)
+    return np.repeat(syms.astype(np.uint8), lens)
+
+
+def check_index(ix, sym, rng, nq=4000):
+    n = sym.size
+    assert ix.bases == n
+    got = ix.extract(0, n)
+    assert np.array_equal(got, sym)
+    cum = cum_counts(sym)
+    pos = np.concatenate([rng.integers(0, n + 1, nq), [0, n, max(n - 1, 0), min(n, 127), min(n, 128), min(n, 129)]]).astype(np.uint64)
+    for c in range(6):
+        r = ix.rank(pos, np.full(pos.size, c, dtype=np.uint8))
+        assert np.array_equal(r.astype(np.int64), cum[c, pos.astype(np.int64)]), c
+    # positions past the end clamp (bwt.cpp:322); comp >= 6 ranks 0 (bwt.cpp:321)
+    assert int(ix.rank([n + 5], [2])[0]) == int(cum[2, n])
+    assert int(ix.rank([3], [7])[0]) == 0
+    if n > 0:
+        ipos = rng.integers(0, n, nq).astype(np.uint64)
+        r, c = ix.inverse_select(ipos)
+        assert np.array_equal(c, sym[ipos.astype(np.int64)])
+        assert np.array_equal(r.astype(np.int64), cum[sym[ipos.astype(np.int64)], ipos.astype(np.int64)])
+
+
+def test_upload_builds_exact_rank_structure(gpu, oracle):
+    rng = np.random.default_rng(1)
+    for lengths in ([1, 1, 1, 2, 3], [1, 2, 41, 42, 43, 169, 170, 5000], [16425, 16426, 100000, 1, 7]):
+        sym = run_symbols(rng, 3000, lengths)
+        f = oracle.FMI.from_symbols(sym)
+        ix = gpu.Index.upload(f.data, f.sequences, f.bases)
+        assert (ix.sequences, ix.nbytes, ix.blocks) == (f.sequences, f.nbytes, f.blocks)
+        assert np.array_equal(ix.C, f.C)
+        check_index(ix, sym, rng)
+        be, cum = ix.samples()
+        obe, ocum = f.samples
+        assert np.array_equal(be, obe) and np.array_equal(cum, ocum)
+        ix.free()
+
+
+def test_upload_rejects_inconsistent_header(gpu, oracle):
+    f = oracle.FMI.from_symbols(np.array([1, 2, 0, 3, 0], dtype=np.uint8))
+    with pytest.raises(gpu.BwtmError):
+        gpu.Index.upload(f.data, f.sequences, f.bases + 1)
+    with pytest.raises(gpu.BwtmError):
+        gpu.Index.upload(f.data, f.sequences + 1, f.bases)
+
+
+def test_rank_structure_across_super_blocks(gpu, oracle):
+    # > 2^25 positions so that several super-table entries and 25-bit relative counts are used
+    rng = np.random.default_rng(2)
+    sym = run_symbols(rng, 200000, [1, 2, 3, 50, 400, 1500])
+    assert sym.size > (1 << 25) + 1000
+    f = oracle.FMI.from_symbols(sym)
+    ix = gpu.Index.upload(f.data, f.sequences, f.bases)
+    check_index(ix, sym, rng, nq=20000)
+    ix.free()
+
+
+def reads_pair(oracle, na, nb, la, lb, seed=0):
+    ta = oracle.generate_reads(1000 + seed, na, la)
+    tb = oracle.generate_reads(2000 + seed, nb, lb)
+    return oracle.FMI.from_text(ta), oracle.FMI.from_text(tb), ta, tb
+
+
+@pytest.mark.parametrize("na,nb,la,lb", [(3, 2, 4, 5), (1, 1, 1, 1), (200, 300, 30, 45), (2000, 1500, 100, 100), (800, 800, 100, 150)])
+def test_stages_match_oracle(gpu, oracle, na, nb, la, lb):
+    a, b, ta, tb = reads_pair(oracle, na, nb, la, lb, seed=na)
+    ranks, counts, _ = oracle.search(a, b, threads=2)
+    ora = oracle.ra_from_runs(ranks, counts)
+    A = gpu.Index.upload(a.data, a.sequences, a.bases)
+    B = gpu.Index.upload(b.data, b.sequences, b.bases)
+
+    # search (split in two ranges: results accumulate like shards from two GPUs)
+    ra = gpu.RankArray(A, B)
+    half = b.sequences // 2
+    if half > 0:
+        ra.search(A, B, 0, half - 1)
+    ra.search(A, B, half, b.sequences - 1)
+    ra.finalize()
+    assert ra.values == b.bases
+    assert np.array_equal(ra.download(), ora)
+    bits = np.unpackbits(ra.bits().view(np.uint8), bitorder="little")[: a.bases + b.bases]
+    expect = np.zeros(a.bases + b.bases, dtype=np.uint8)
+    expect[np.arange(b.bases, dtype=np.uint64) + ora] = 1
+    assert np.array_equal(bits, expect)
+
+    # interleave
+    merged_sym = oracle.interleave_symbols(a.symbols, b.symbols, ora)
+    M = gpu.interleave(A, B, ra)
+    rng = np.random.default_rng(3)
+    check_index(M, merged_sym, rng, nq=2000)
+    assert (M.sequences, M.bases) == (a.sequences + b.sequences, a.bases + b.bases)
+
+    # encode + samples == FMI::FMI(a, b) of the oracle == BWT of the concatenation
+    m, _ = oracle.merge(a.clone(), b.clone(), threads=2)
+    ab = oracle.FMI.from_text(np.concatenate([ta, tb]))
+    assert np.array_equal(m.data, ab.data)
+    M.encode()
+    assert M.nbytes == m.nbytes
+    assert np.array_equal(M.data(), m.data)
+    assert np.array_equal(M.C, m.C)
+    be, cum = M.samples(); obe, ocum = m.samples
+    assert np.array_equal(be, obe) and np.array_equal(cum, ocum)
+    for x in (A, B, M):
+        x.free()
+    ra.free()
+
+
+def test_merge_entry_point_and_chaining(gpu, oracle):
+    sets = [oracle.generate_reads(3000 + k, 400 + 100 * k, 100 if k != 1 else 150) for k in range(3)]
+    fm = [oracle.FMI.from_text(t) for t in sets]
+    ix = [gpu.Index.upload(f.data, f.sequences, f.bases) for f in fm]
+    m01 = gpu.merge(ix[0], ix[1])
+    m012 = gpu.merge(m01, ix[2])                    # bwt_merge.cpp:167-173: result is the next `a`
+    direct = oracle.FMI.from_text(np.concatenate(sets))
+    assert np.array_equal(m012.data(), direct.data)
+    assert np.array_equal(m012.C, direct.C)
+    assert (m012.sequences, m012.bases) == (direct.sequences, direct.bases)
+    # device-resident chaining without the native form of the intermediate
+    m01.drop_native()
+    again = gpu.merge(m01, ix[2])
+    assert np.array_equal(again.data(), direct.data)
+
+
+def test_empty_increment_and_empty_base(gpu, oracle):
+    a = oracle.FMI.from_text(oracle.generate_reads(7, 50, 20))
+    e = oracle.FMI.from_symbols(np.zeros(0, dtype=np.uint8))
+    A = gpu.Index.upload(a.data, a.sequences, a.bases)
+    E = gpu.Index.upload(e.data, 0, 0)
+    assert np.array_equal(gpu.merge(A, E).data(), a.data)
+    assert np.array_equal(gpu.merge(E, A).data(), a.data)
+
+
+@pytest.mark.parametrize("case", ["mixed", "boundaries", "giant", "tiny", "alternating"])
+def test_encoder_block_rule(gpu, oracle, case):
+    """Run::write's offset-dependent forms (support.h:256-282), including runs that end in
+    chunks far from where they start, against the oracle's encoder."""
+    import torch
+    rng = np.random.default_rng(11)
+    if case == "mixed":
+        syms = [run_symbols(rng, 20000, [1, 2, 3, 5, 41, 42, 43, 169, 170, 16425, 16426, 100000])]
+    elif case == "boundaries":
+        # many long runs so that every offset mod 64 is met by 41/42/43/169/170-length runs
+        syms = [run_symbols(rng, 60000, [41, 42, 43, 44, 168, 169, 170, 171, 1])]
+    elif case == "giant":
+        syms = [np.full(5_000_000, 3, dtype=np.uint8),
+                np.concatenate([np.full(70000, 1, np.uint8), np.full(1, 2, np.uint8), np.full(4096 * 64 * 16 + 5, 4, np.uint8)])]
+    elif case == "tiny":
+        syms = [np.array([4], np.uint8), np.array([0, 0], np.uint8), np.full(63, 2, np.uint8), np.full(64, 2, np.uint8),
+                np.full(4096, 5, np.uint8), run_symbols(rng, 3, [1])] + [run_symbols(rng, 40, [1, 2])[:k] for k in (64, 127, 128, 129)]
+    else:
+        syms = [np.tile(np.array([1, 2], np.uint8), 100000), np.tile(np.array([1, 1, 2], np.uint8), 65536)]
+    for sym in syms:
+        f = oracle.FMI.from_symbols(sym)
+        d = torch.from_numpy(sym).cuda()
+        ix = gpu.Index.from_symbols_device(d.data_ptr(), sym.size)
+        assert ix.sequences == f.sequences and np.array_equal(ix.C, f.C)
+        ix.encode()
+        assert ix.nbytes == f.nbytes, case
+        assert np.array_equal(ix.data(), f.data), case
+        be, cum = ix.samples(); obe, ocum = f.samples
+        assert np.array_equal(be, obe) and np.array_equal(cum, ocum)
+        ix.free()
+
+
+def test_config1_shape_merge(gpu, oracle):
+    """BASELINE.json configs[0] shape at reduced read count (the oracle's suffix sort bounds it)."""
+    a, b, ta, tb = reads_pair(oracle, 20000, 20000, 100, 100, seed=42)
+    A = gpu.Index.upload(a.data, a.sequences, a.bases)
+    B = gpu.Index.upload(b.data, b.sequences, b.bases)
+    M = gpu.merge(A, B)
+    m, _ = oracle.merge(a, b, threads=4)
+    assert np.array_equal(M.data(), m.data)
+    be, cum = M.samples(); obe, ocum = m.samples
+    assert np.array_equal(be, obe) and np.array_equal(cum, ocum)
