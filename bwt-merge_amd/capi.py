@@ -68,6 +68,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise BwtmError("HIP extension %s is missing: run `python __graft_entry__.py build` "
                             "(there is no CPU fallback)" % LIB_PATH)
+        # PyTorch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  Processes that use both
+        # (bench.py, torch.distributed) must share ONE HIP runtime, so torch is loaded first and
+        # libbwtm.so's NEEDED libamdhip64.so.7 then resolves to the already loaded copy.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             f = getattr(L, name)       # AttributeError if the library does not export it
