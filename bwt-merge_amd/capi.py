@@ -31,6 +31,7 @@ SYMBOLS = [
     ("bwtm_index_C", None, [vp, p_u64]),
     ("bwtm_index_encode", C.c_int, [vp]),
     ("bwtm_index_drop_native", C.c_int, [vp]),
+    ("bwtm_index_device_data", C.c_int, [vp, C.POINTER(vp), p_u64]),
     ("bwtm_index_download_data", C.c_int, [vp, p_u8, u64]),
     ("bwtm_index_download_samples", C.c_int, [vp, p_u64, p_u64]),
     ("bwtm_rank_batch", C.c_int, [vp, p_u64, p_u8, u64, p_u64]),
@@ -167,6 +168,13 @@ class Index:
     def drop_native(self):
         check(lib().bwtm_index_drop_native(self.h))
         return self
+
+    def device_data(self):
+        """(device pointer, nbytes) of the native byte stream."""
+        ptr = vp()
+        n = u64(0)
+        check(lib().bwtm_index_device_data(self.h, C.byref(ptr), C.byref(n)))
+        return int(ptr.value or 0), int(n.value)
 
     def data(self):
         out = np.zeros(self.nbytes, dtype=np.uint8)

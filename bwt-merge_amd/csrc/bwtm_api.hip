@@ -409,6 +409,16 @@ extern "C" int bwtm_index_encode(bwtm_index* x)
   return BWTM_OK;
 }
 
+extern "C" int bwtm_index_device_data(bwtm_index* x, void** device_ptr, uint64_t* nbytes)
+{
+  TRY(ensure_ready());
+  if(!x || !device_ptr || !nbytes) { return fail(BWTM_EINVAL, "bwtm_index_device_data: null argument"); }
+  if(!x->has_native) { return fail(BWTM_EINVAL, "index has no native byte stream (call bwtm_index_encode first)"); }
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  *device_ptr = x->data.p; *nbytes = x->nbytes;
+  return BWTM_OK;
+}
+
 extern "C" int bwtm_index_download_data(bwtm_index* x, uint8_t* out, uint64_t capacity)
 {
   TRY(ensure_ready());

@@ -81,6 +81,8 @@ int bwtm_index_encode(bwtm_index* index);
    (what a chained merge needs as its next input). */
 int bwtm_index_drop_native(bwtm_index* index);
 
+/* The device buffer holding the native bytes (valid until the index is freed / dropped). */
+int bwtm_index_device_data(bwtm_index* index, void** device_ptr, uint64_t* nbytes);
 /* Copies the native bytes to the host (`capacity` >= bwtm_index_bytes()). */
 int bwtm_index_download_data(bwtm_index* index, uint8_t* out, uint64_t capacity);
 /* Samples in the form BWT::build computes them: block_end[blocks] = last sequence position
