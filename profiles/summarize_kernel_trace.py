@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Summarises a rocprofv3 --kernel-trace CSV of `python3 bench.py ...` per bwtm kernel,
+restricted to the TIMED steps of the bench (the input tooling launches the same kernels).
+
+The timed region is recognised structurally: every merge step ends with the encoder
+(k_enc_emit) followed by the sample builder (..., k_block_start); the last `steps` emits are
+the timed steps.  Usage: summarize_kernel_trace.py kernel_trace.csv steps > summary.md
+"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+
+def main():
+    path, steps = sys.argv[1], int(sys.argv[2])
+    rows = []
+    for r in csv.DictReader(open(path)):
+        name = r["Kernel_Name"]
+        if "bwtm::" not in name:
+            continue
+        short = re.sub(r"<.*", "", name.split("bwtm::")[1].split("(")[0])
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short, r))
+    rows.sort()
+    emits = [k for k, r in enumerate(rows) if r[2] == "k_enc_emit"]
+    first = emits[-(steps + 1)] if len(emits) > steps else -1
+    t_begin = rows[first][1] if first >= 0 else 0
+    last_emit = emits[-1]
+    t_end = next(r[1] for r in rows[last_emit:] if r[2] == "k_block_start")
+    sel = [r for r in rows if r[0] >= t_begin and r[1] <= t_end]
+    agg = defaultdict(list)
+    for s, e, short, r in sel:
+        agg[short].append(e - s)
+    total = sum(sum(v) for v in agg.values())
+    print("| kernel | launches in %d timed steps | avg per launch (ms) | total per step (ms) | share |" % steps)
+    print("|---|---|---|---|---|")
+    for short, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        print("| %s | %d | %.3f | %.3f | %.1f %% |" % (short, len(v), sum(v) / len(v) / 1e6, sum(v) / steps / 1e6, 100.0 * sum(v) / total))
+    print("| all bwtm kernels | | | %.3f | 100 %% |" % (total / steps / 1e6))
+    print()
+    print("timed region: %.3f ms wall per step between first and last kernel" % ((t_end - t_begin) / steps / 1e6))
+    r = next(r for r in sel if r[2] == "k_lf_walk")[3]
+    print("k_lf_walk launch geometry: grid %s x workgroup %s, VGPR %s, SGPR %s, LDS %s B" %
+          (r.get("Grid_Size_X", r.get("Grid_Size")), r.get("Workgroup_Size_X", r.get("Workgroup_Size")), r.get("VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size")))
+
+
+if __name__ == "__main__":
+    main()
