@@ -81,6 +81,7 @@ def main():
         ix.encode()
         sets.append(ix)
     torch.cuda.empty_cache()
+    pkg.trim()
     A0, B0 = sets
     n_a, n_b = A0.bases, B0.bases
     ptr_a, bytes_a = A0.device_data()

@@ -6,7 +6,7 @@ the bwt_merge CLI in csrc/host; this Python package only binds the C ABI for tes
 from . import build as _build          # noqa: F401
 from . import capi                      # noqa: F401
 from .capi import (BwtmError, Index, RankArray, init, interleave, merge, profile_enable,  # noqa: F401
-                   profile_read, profile_reset, ra_buffer_bytes, synchronize)
+                   profile_read, profile_reset, ra_buffer_bytes, synchronize, trim, tune)
 
 
 def build(force=False, verbose=False):

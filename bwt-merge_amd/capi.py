@@ -20,6 +20,8 @@ SYMBOLS = [
     ("bwtm_init", C.c_int, [C.c_int]),
     ("bwtm_last_error", C.c_char_p, []),
     ("bwtm_synchronize", C.c_int, []),
+    ("bwtm_trim", C.c_int, []),
+    ("bwtm_tune", C.c_int, [C.c_char_p, C.c_longlong]),
     ("bwtm_index_upload", C.c_int, [p_u8, u64, u64, u64, p_u64, C.POINTER(vp)]),
     ("bwtm_index_from_device", C.c_int, [vp, u64, u64, u64, p_u64, C.POINTER(vp)]),
     ("bwtm_index_from_symbols_device", C.c_int, [vp, u64, C.POINTER(vp)]),
@@ -96,6 +98,14 @@ def init(device=0):
 
 def synchronize():
     check(lib().bwtm_synchronize())
+
+
+def tune(key, value):
+    check(lib().bwtm_tune(key.encode(), int(value)))
+
+
+def trim():
+    check(lib().bwtm_trim())
 
 
 def _u8(a):

@@ -47,6 +47,14 @@ struct Context
 
 Context g_ctx;
 
+// Diagnostic knobs (bwtm_tune): never change results unless documented as timing-only.
+struct Tuning
+{
+  long long walk_emit = 0;       // 0 product path; 1 / 2 timing-only variants of the emit (see k_lf_walk)
+  long long walk_blocks = 0;     // grid size override for k_lf_walk (0 = default)
+};
+Tuning g_tune;
+
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if(e_ != hipSuccess) { \
   return fail(e_ == hipErrorOutOfMemory ? BWTM_ENOMEM : BWTM_ENODEV, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } } while(0)
 
@@ -97,21 +105,61 @@ void profile_collect()
 
 inline u64 div_up(u64 a, u64 b) { return (a + b - 1) / b; }
 
-// RAII device buffer.
+// Device memory pool.  All work of the library runs on ONE stream, so a block released by a
+// handle may be handed to the next allocation immediately (stream order protects it); blocks
+// return to the driver only in bwtm_trim() or when hipMalloc runs out of memory.  A repeated
+// merge of the same shape therefore performs no hipMalloc / hipFree at all (both cost
+// milliseconds per GB and serialise with the device).
+struct Pool
+{
+  std::multimap<u64, void*> free_blocks;
+  u64 cached_bytes = 0;
+
+  static u64 round_size(u64 n)
+  {
+    if(n < 256) { n = 256; }
+    u64 g = (n >= (64ull << 20) ? (2ull << 20) : (n >= (1ull << 20) ? (64ull << 10) : 256ull));
+    return (n + g - 1) / g * g;
+  }
+  void trim()
+  {
+    if(g_ctx.stream) { (void)hipStreamSynchronize(g_ctx.stream); }
+    for(auto& kv : free_blocks) { (void)hipFree(kv.second); }
+    free_blocks.clear(); cached_bytes = 0;
+  }
+  hipError_t get(u64 n, void** p, u64* actual)
+  {
+    n = round_size(n);
+    auto it = free_blocks.lower_bound(n);
+    if(it != free_blocks.end() && it->first <= n + n / 8)
+    {
+      *p = it->second; *actual = it->first; cached_bytes -= it->first; free_blocks.erase(it);
+      return hipSuccess;
+    }
+    hipError_t e = hipMalloc(p, n);
+    if(e != hipSuccess) { (void)hipGetLastError(); trim(); e = hipMalloc(p, n); }
+    *actual = n;
+    return e;
+  }
+  void put(void* p, u64 n) { free_blocks.insert(std::make_pair(n, p)); cached_bytes += n; }
+};
+
+Pool g_pool;
+
+// RAII device buffer (pooled).
 struct DevBuf
 {
   void* p = nullptr; u64 bytes = 0;
   DevBuf() {}
   DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
-  void release() { if(p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+  void release() { if(p) { g_pool.put(p, bytes); p = nullptr; bytes = 0; } }
   int alloc(u64 n, bool zero = false)
   {
     release();
     if(n == 0) { n = 8; }
-    hipError_t e = hipMalloc(&p, n);
-    if(e != hipSuccess) { p = nullptr; return fail(BWTM_ENOMEM, "hipMalloc(%llu bytes) failed: %s", (unsigned long long)n, hipGetErrorString(e)); }
-    bytes = n;
+    hipError_t e = g_pool.get(n, &p, &bytes);
+    if(e != hipSuccess) { p = nullptr; bytes = 0; return fail(BWTM_ENOMEM, "hipMalloc(%llu bytes) failed: %s", (unsigned long long)n, hipGetErrorString(e)); }
     if(zero) { e = hipMemsetAsync(p, 0, n, g_ctx.stream); if(e != hipSuccess) { return fail(BWTM_ENODEV, "hipMemsetAsync failed: %s", hipGetErrorString(e)); } }
     return BWTM_OK;
   }
@@ -134,8 +182,7 @@ int device_scan(const u64* in, u64* out, u64 n)
   LAUNCH("scan_reduce", k_scan_reduce<OP>, tiles, BLOCK_THREADS, in, partial.as<u64>(), n);
   TRY(device_scan<OP>(partial.as<u64>(), partial.as<u64>(), tiles));
   LAUNCH("scan_apply", k_scan_apply<OP>, tiles, BLOCK_THREADS, in, out, (const u64*)partial.as<u64>(), n);
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));     // `partial` is released on return
-  return BWTM_OK;
+  return BWTM_OK;                                   // `partial` returns to the pool (stream ordered)
 }
 
 } // namespace
@@ -262,6 +309,22 @@ extern "C" int bwtm_init(int device)
 
 extern "C" const char* bwtm_last_error(void) { return g_error.c_str(); }
 
+extern "C" int bwtm_tune(const char* key, long long value)
+{
+  if(!key) { return fail(BWTM_EINVAL, "bwtm_tune: null key"); }
+  std::string k(key);
+  if(k == "walk_emit") { g_tune.walk_emit = value; }
+  else if(k == "walk_blocks") { g_tune.walk_blocks = value; }
+  else { return fail(BWTM_EINVAL, "bwtm_tune: unknown key %s", key); }
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_trim(void)
+{
+  g_pool.trim();
+  return BWTM_OK;
+}
+
 extern "C" int bwtm_synchronize(void)
 {
   TRY(ensure_ready());
@@ -337,7 +400,7 @@ extern "C" int bwtm_index_from_symbols_device(const void* device_symbols, uint64
     LAUNCH("sym_sup", k_sym_sup, div_up(x->nsup, BLOCK_THREADS), BLOCK_THREADS, cnt.as<const u64>(), stride, x->nrecs, x->sup.as<u64>(), x->nsup);
     LAUNCH("sym_recs", k_sym_recs, div_up(x->nrecs, BLOCK_THREADS), BLOCK_THREADS,
       (const u8*)device_symbols, bases, cnt.as<const u64>(), stride, x->sup.as<const u64>(), x->recs.as<uint4>(), x->nrecs);
-    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));     // the caller may release `device_symbols` on return
     return BWTM_OK;
   };
   int rc = body();
@@ -348,9 +411,7 @@ extern "C" int bwtm_index_from_symbols_device(const void* device_symbols, uint64
 
 extern "C" void bwtm_index_free(bwtm_index* index)
 {
-  if(!index) { return; }
-  if(g_ctx.stream) { (void)hipStreamSynchronize(g_ctx.stream); }
-  delete index;
+  delete index;                                     // buffers return to the pool (stream ordered)
 }
 
 extern "C" uint64_t bwtm_index_bases(const bwtm_index* x)     { return x ? x->n : 0; }
@@ -362,7 +423,6 @@ extern "C" void bwtm_index_C(const bwtm_index* x, uint64_t* C) { for(int c = 0; 
 extern "C" int bwtm_index_drop_native(bwtm_index* x)
 {
   if(!x) { return fail(BWTM_EINVAL, "null index"); }
-  if(g_ctx.stream) { (void)hipStreamSynchronize(g_ctx.stream); }
   x->data.release(); x->cum.release(); x->block_start.release();
   x->has_native = false; x->nbytes = 0; x->nblocks = 0;
   return BWTM_OK;
@@ -400,11 +460,9 @@ extern "C" int bwtm_index_encode(bwtm_index* x)
     TRY(x->data.alloc(total + 16, true));
     LAUNCH("enc_emit", k_enc_emit, wave_grid, BLOCK_THREADS, x->recs.as<const uint4>(), x->nrecs, x->n, ntiles, nseg,
       lasthead.as<const u64>(), seg_base.as<const u64>(), x->data.as<u8>());
-    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   }
   else { TRY(x->data.alloc(16, true)); }
   TRY(native_samples(x));                       // BWT::build, bwt.cpp:476-512
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   x->has_native = true;
   return BWTM_OK;
 }
@@ -532,7 +590,8 @@ extern "C" int bwtm_ra_create(const bwtm_index* a, const bwtm_index* b, bwtm_ra*
 extern "C" void bwtm_ra_free(bwtm_ra* ra)
 {
   if(!ra) { return; }
-  if(g_ctx.stream) { (void)hipStreamSynchronize(g_ctx.stream); }
+  // A caller-owned bitvector may be reused by the caller right away: drain the stream first.
+  if(!ra->owned_bits.p && g_ctx.stream) { (void)hipStreamSynchronize(g_ctx.stream); }
   delete ra;
 }
 
@@ -547,9 +606,21 @@ extern "C" int bwtm_search(const bwtm_index* a, const bwtm_index* b, uint64_t se
   u64 count = seq_last - seq_first + 1;
   // Enough resident waves to fill the chip, every lane taking sequences in a grid stride.
   u64 blocks = div_up(count, BLOCK_THREADS);
-  const u64 max_blocks = 256 * 8;
+  const u64 max_blocks = (g_tune.walk_blocks > 0 ? (u64)g_tune.walk_blocks : 256 * 8);
   if(blocks > max_blocks) { blocks = max_blocks; }
-  LAUNCH("lf_walk", k_lf_walk, blocks, BLOCK_THREADS, a->view(), b->view(), (u64)seq_first, count, ra->bits_as<u32>());
+  if(g_tune.walk_emit == 0)
+  {
+    LAUNCH("lf_walk", k_lf_walk<0>, blocks, BLOCK_THREADS, a->view(), b->view(), (u64)seq_first, count, ra->bits_as<u32>());
+  }
+  else if(g_tune.walk_emit == 1)
+  {
+    LAUNCH("lf_walk_noemit", k_lf_walk<1>, blocks, BLOCK_THREADS, a->view(), b->view(), (u64)seq_first, count, ra->bits_as<u32>());
+  }
+  else
+  {
+    DevBuf scratch; TRY(scratch.alloc(b->n * sizeof(u64) + 64));
+    LAUNCH("lf_walk_store", k_lf_walk<2>, blocks, BLOCK_THREADS, a->view(), b->view(), (u64)seq_first, count, scratch.as<u32>());
+  }
   return BWTM_OK;
 }
 

@@ -428,6 +428,17 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_extract(IndexView x, u64 firs
 // Per step one 64-byte record of B and one of A are fetched (both addresses are known at the
 // top of the iteration, so the two HBM accesses overlap), plus two L2-resident super rows.
 
+// EMIT: 0 = atomicOr into the bitvector (the product path); 1 = nothing, 2 = plain 8-byte store
+// of r at scratch[i] (diagnostic builds for pricing the emit traffic; results are not a rank array).
+template<int EMIT>
+__device__ inline void walk_emit(u32* bits, u64 i, u64 r)
+{
+  if(EMIT == 0) { u64 p = i + r; atomicOr(bits + (p >> 5), 1u << (p & 31)); }
+  else if(EMIT == 2) { ((u64*)bits)[i] = r; }
+  else { asm volatile("" :: "v"((u32)r), "v"((u32)i)); }
+}
+
+template<int EMIT>
 __global__ void __launch_bounds__(BLOCK_THREADS) k_lf_walk(IndexView A, IndexView B, u64 seq_first, u64 seq_count, u32* bits)
 {
   __shared__ u64 sC[16];
@@ -449,8 +460,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_lf_walk(IndexView A, IndexVie
       if(next >= seq_count) { break; }
       i = seq_first + next; r = A.m;                          // fmi.cpp:286: trie root "$"
       next += stride; walking = true;
-      u64 p = i + r;
-      atomicOr(bits + (p >> 5), 1u << (p & 31));
+      walk_emit<EMIT>(bits, i, r);
     }
     u32 wb[16], wa[16];
     load_record(B.recs, i >> REC_SHIFT, wb);
@@ -467,8 +477,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_lf_walk(IndexView A, IndexVie
     u64 supa = (c == 1 ? sa1 : (c == 2 ? sa2 : (c == 3 ? sa3 : (c == 4 ? sa4 : sa5))));
     i = sC[8 + c] + supb + rec_header(wb, c) + rec_count(wb, c, jb);   // LF_B(i), utils.h:335-341
     r = sC[c] + supa + rec_header(wa, c) + rec_count(wa, c, ja);       // LF_A(r, c), utils.h:343-348
-    u64 p = i + r;
-    atomicOr(bits + (p >> 5), 1u << (p & 31));
+    walk_emit<EMIT>(bits, i, r);
   }
 }
 

@@ -48,6 +48,11 @@ typedef struct bwtm_ra    bwtm_ra;      /* device-resident rank array: replaces 
 /* Selects the HIP device for the calling process and creates the library's stream. */
 int bwtm_init(int device);
 const char* bwtm_last_error(void);
+/* Diagnostic knobs for measurements (see DESIGN.md "Experiments"); defaults are the product path. */
+int bwtm_tune(const char* key, long long value);
+/* Returns the library's cached device memory to the driver (device buffers released by
+   handles are kept in a pool for reuse). */
+int bwtm_trim(void);
 /* Blocks until all work queued by the library has finished. */
 int bwtm_synchronize(void);
 

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Diagnostic: prices the parts of the search kernel on config-2-sized inputs (GPU only).
+Usage: python tools/walk_experiments.py [reads_per_set]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import _pkg
+pkg = _pkg.load()
+from bwt_merge_amd import synth
+
+reads = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
+pkg.init(0)
+dev = torch.device("cuda", 0)
+t0 = time.time()
+A = synth.build_index(pkg, 1001, reads, 100, device=dev)
+B = synth.build_index(pkg, 1002, reads, 100, device=dev)
+torch.cuda.empty_cache(); pkg.trim()
+print("inputs in %.0f s" % (time.time() - t0), flush=True)
+pkg.profile_enable(True)
+
+def run(label, emit, blocks):
+    pkg.tune("walk_emit", emit); pkg.tune("walk_blocks", blocks)
+    pkg.profile_reset()
+    for _ in range(2):
+        ra = pkg.RankArray(A, B)
+        ra.search(A, B, 0, B.sequences - 1)
+        pkg.synchronize()
+        ra.free()
+    prof = pkg.profile_read()
+    for k, (ms, n) in prof.items():
+        if k.startswith("lf_walk"):
+            print("%-34s %-16s %9.2f ms  %6.2f Gsteps/s" % (label, k, ms / n, B.bases / (ms / n) / 1e6), flush=True)
+
+mode = sys.argv[2] if len(sys.argv) > 2 else "sweep"
+if mode == "sweep":
+    for blocks in (512, 8192):
+        run("atomicOr, %d blocks" % blocks, 0, blocks)
+run("atomicOr, 2048 blocks", 0, 2048)
+run("no emit, 2048 blocks", 1, 2048)
+run("8-byte store emit, 2048 blocks", 2, 2048)
+pkg.tune("walk_emit", 0); pkg.tune("walk_blocks", 0)
