@@ -52,6 +52,7 @@ struct Tuning
 {
   long long walk_emit = 0;       // 0 product path; 1 / 2 timing-only variants of the emit (see k_lf_walk)
   long long walk_blocks = 0;     // grid size override for k_lf_walk (0 = default)
+  long long walk_kernel = 0;     // 0 = four lanes per chain (product), 1 = one lane per chain (first version, kept for A/B)
 };
 Tuning g_tune;
 
@@ -315,6 +316,7 @@ extern "C" int bwtm_tune(const char* key, long long value)
   std::string k(key);
   if(k == "walk_emit") { g_tune.walk_emit = value; }
   else if(k == "walk_blocks") { g_tune.walk_blocks = value; }
+  else if(k == "walk_kernel") { g_tune.walk_kernel = value; }
   else { return fail(BWTM_EINVAL, "bwtm_tune: unknown key %s", key); }
   return BWTM_OK;
 }
@@ -605,21 +607,24 @@ extern "C" int bwtm_search(const bwtm_index* a, const bwtm_index* b, uint64_t se
   if(seq_last >= b->m) { return fail(BWTM_EINVAL, "bwtm_search: sequence %llu out of range (%llu sequences)", (unsigned long long)seq_last, (unsigned long long)b->m); }
   u64 count = seq_last - seq_first + 1;
   // Enough resident waves to fill the chip, every lane taking sequences in a grid stride.
-  u64 blocks = div_up(count, BLOCK_THREADS);
+  const u64 lanes_per_chain = (g_tune.walk_kernel == 0 ? 4 : 1);
+  u64 blocks = div_up(count * lanes_per_chain, BLOCK_THREADS);
   const u64 max_blocks = (g_tune.walk_blocks > 0 ? (u64)g_tune.walk_blocks : 256 * 8);
   if(blocks > max_blocks) { blocks = max_blocks; }
-  if(g_tune.walk_emit == 0)
+  DevBuf scratch;
+  u32* target = ra->bits_as<u32>();
+  if(g_tune.walk_emit == 2) { TRY(scratch.alloc(b->n * sizeof(u64) + 64)); target = scratch.as<u32>(); }
+  if(g_tune.walk_kernel == 0)
   {
-    LAUNCH("lf_walk", k_lf_walk<0>, blocks, BLOCK_THREADS, a->view(), b->view(), (u64)seq_first, count, ra->bits_as<u32>());
-  }
-  else if(g_tune.walk_emit == 1)
-  {
-    LAUNCH("lf_walk_noemit", k_lf_walk<1>, blocks, BLOCK_THREADS, a->view(), b->view(), (u64)seq_first, count, ra->bits_as<u32>());
+    if(g_tune.walk_emit == 0)      { LAUNCH("lf_walk", k_lf_walk_quad<0>, blocks, BLOCK_THREADS, a->view(), b->view(), (u64)seq_first, count, target); }
+    else if(g_tune.walk_emit == 1) { LAUNCH("lf_walk_noemit", k_lf_walk_quad<1>, blocks, BLOCK_THREADS, a->view(), b->view(), (u64)seq_first, count, target); }
+    else                           { LAUNCH("lf_walk_store", k_lf_walk_quad<2>, blocks, BLOCK_THREADS, a->view(), b->view(), (u64)seq_first, count, target); }
   }
   else
   {
-    DevBuf scratch; TRY(scratch.alloc(b->n * sizeof(u64) + 64));
-    LAUNCH("lf_walk_store", k_lf_walk<2>, blocks, BLOCK_THREADS, a->view(), b->view(), (u64)seq_first, count, scratch.as<u32>());
+    if(g_tune.walk_emit == 0)      { LAUNCH("lf_walk_lane", k_lf_walk<0>, blocks, BLOCK_THREADS, a->view(), b->view(), (u64)seq_first, count, target); }
+    else if(g_tune.walk_emit == 1) { LAUNCH("lf_walk_lane_noemit", k_lf_walk<1>, blocks, BLOCK_THREADS, a->view(), b->view(), (u64)seq_first, count, target); }
+    else                           { LAUNCH("lf_walk_lane_store", k_lf_walk<2>, blocks, BLOCK_THREADS, a->view(), b->view(), (u64)seq_first, count, target); }
   }
   return BWTM_OK;
 }

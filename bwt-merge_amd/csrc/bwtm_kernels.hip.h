@@ -482,6 +482,96 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_lf_walk(IndexView A, IndexVie
 }
 
 //------------------------------------------------------------------------------
+// K1, product form: FOUR lanes per chain.  A 64-byte record is four 16-byte chunks
+// {plane0, plane1, plane2, header word} of 32 positions each, so lane q of a quad loads chunk q
+// with ONE dwordx4: the quad's four loads fall into one 64-byte line and cost a single request in
+// the vector memory pipeline (measured: 95 G records/s against 23 G records/s when one lane issues
+// four loads, tools/microbench_gather.hip).  Every lane counts in its own 32 positions, extracts
+// its slice of the 25-bit header field, contributes the super-table entry it loaded, and a
+// quad-wide DPP butterfly adds the pieces, so all four lanes hold the next (i, r).
+
+__device__ inline u32 dpp_quad(u32 v, int ctrl_xor1)
+{
+  // ctrl_xor1 != 0: lanes [1,0,3,2]; else lanes [2,3,0,1]
+  return (ctrl_xor1 ? (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false)
+                    : (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));
+}
+
+__device__ inline u64 quad_sum_u64(u64 v)
+{
+  u64 t = ((u64)dpp_quad((u32)(v >> 32), 1) << 32) | dpp_quad((u32)v, 1);
+  v += t;
+  t = ((u64)dpp_quad((u32)(v >> 32), 0) << 32) | dpp_quad((u32)v, 0);
+  return v + t;
+}
+
+__device__ inline u32 quad_or_u32(u32 v)
+{
+  v |= dpp_quad(v, 1);
+  return v | dpp_quad(v, 0);
+}
+
+// This lane's share of rank(c) within a record: matches below position j in its 32 positions
+// plus its slice of the header field of c.  `ch` = {plane0, plane1, plane2, header word} of chunk q.
+__device__ inline u32 quad_rank_part(uint4 ch, u32 q, u32 c, u32 j)
+{
+  u32 part = (u32)__builtin_popcount(plane_match(ch.x, ch.y, ch.z, c) & below_mask(j, q));
+  int s = (int)(FIELD_BITS * (c - 1));            // field occupies header bits [s, s + 25)
+  int lo = s - 32 * (int)q;                        // field start relative to this lane's word
+  u32 piece;
+  if(lo >= 32 || lo + (int)FIELD_BITS <= 0) { piece = 0; }
+  else if(lo >= 0) { piece = (ch.w >> lo) & FIELD_MASK; }                 // low part of the field
+  else { piece = (ch.w << (-lo)) & FIELD_MASK; }                          // high part of the field
+  return part + piece;
+}
+
+template<int EMIT>
+__global__ void __launch_bounds__(BLOCK_THREADS) k_lf_walk_quad(IndexView A, IndexView B, u64 seq_first, u64 seq_count, u32* bits)
+{
+  __shared__ u64 sC[16];
+  if(threadIdx.x == 0)
+  {
+#pragma unroll
+    for(int k = 0; k < 8; k++) { sC[k] = A.C[k]; sC[8 + k] = B.C[k]; }
+  }
+  __syncthreads();
+
+  const u32 q = threadIdx.x & 3;
+  const u64 stride = ((u64)gridDim.x * BLOCK_THREADS) >> 2;
+  u64 next = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 2;
+  u64 i = 0, r = 0;
+  bool walking = false;
+  while(true)
+  {
+    if(!walking)
+    {
+      if(next >= seq_count) { break; }
+      i = seq_first + next; r = A.m;                          // fmi.cpp:286: trie root "$"
+      next += stride; walking = true;
+      if(q == 0) { walk_emit<EMIT>(bits, i, r); }
+    }
+    const uint4 cb = B.recs[4 * (i >> REC_SHIFT) + q];
+    const uint4 ca = A.recs[4 * (r >> REC_SHIFT) + q];
+    const u64* sb = B.sup + (i >> SUPER_SHIFT) * SUP_STRIDE;
+    const u64* sa = A.sup + (r >> SUPER_SHIFT) * SUP_STRIDE;
+    const u64 sb_q = sb[1 + q], sb_5 = sb[5];
+    const u64 sa_q = sa[1 + q], sa_5 = sa[5];
+
+    const u32 jb = (u32)(i & (REC_POS - 1)), ja = (u32)(r & (REC_POS - 1));
+    // BWT_B[i]: held by the lane whose 32 positions contain jb.
+    const u32 t = jb & 31;
+    u32 mine = ((cb.x >> t) & 1u) | (((cb.y >> t) & 1u) << 1) | (((cb.z >> t) & 1u) << 2);
+    const u32 c = quad_or_u32((jb >> 5) == q ? mine : 0u);
+    if(c == 0) { walking = false; continue; }                 // fmi.cpp:299: start of the sequence (quad-uniform)
+    u64 pb = (u64)quad_rank_part(cb, q, c, jb) + (c == q + 1 ? sb_q : 0) + ((q == 0 && c == 5) ? sb_5 : 0);
+    u64 pa = (u64)quad_rank_part(ca, q, c, ja) + (c == q + 1 ? sa_q : 0) + ((q == 0 && c == 5) ? sa_5 : 0);
+    i = sC[8 + c] + quad_sum_u64(pb);                         // LF_B(i), utils.h:335-341
+    r = sC[c] + quad_sum_u64(pa);                             // LF_A(r, c), utils.h:343-348
+    if(q == 0) { walk_emit<EMIT>(bits, i, r); }
+  }
+}
+
+//------------------------------------------------------------------------------
 // K2: rank-array finalize.  A chunk is 64 output records = 8192 bits = 128 words; one wave
 // per chunk counts the set bits.  (An exclusive scan of the counts follows.)
 

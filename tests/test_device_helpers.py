@@ -1,0 +1,102 @@
+"""The pure helpers shared by all kernels (bwtm_device.h), compiled for the host and checked
+against the reference's known-answer vectors and the oracle's codec."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def shim():
+    out = os.path.join(HERE, "_build")
+    os.makedirs(out, exist_ok=True)
+    lib = os.path.join(out, "libshim.so")
+    src = os.path.join(HERE, "host_shim.cpp")
+    hdr = os.path.join(HERE, "..", "bwt-merge_amd", "csrc", "bwtm_device.h")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", lib, src])
+    L = C.CDLL(lib)
+    u64, u32 = C.c_uint64, C.c_uint32
+    L.shim_long_run_bytes.restype = u64; L.shim_long_run_bytes.argtypes = [u64, u64]
+    L.shim_long_run_write.restype = u64; L.shim_long_run_write.argtypes = [C.c_void_p, u64, u32, u64]
+    L.shim_pack_header.argtypes = [C.c_void_p, C.c_void_p]
+    L.shim_rec_header.restype = u32; L.shim_rec_header.argtypes = [C.c_void_p, u32]
+    L.shim_rec_count.restype = u32; L.shim_rec_count.argtypes = [C.c_void_p, u32, u32]
+    L.shim_rec_symbol.restype = u32; L.shim_rec_symbol.argtypes = [C.c_void_p, u32]
+    L.shim_range_mask128.argtypes = [u32, u32, C.c_void_p, C.c_void_p]
+    L.shim_run_decode.restype = u64; L.shim_run_decode.argtypes = [C.c_void_p, u64, C.c_void_p, C.c_void_p]
+    return L
+
+
+def test_long_run_encoder_matches_reference_vectors(shim, golden, oracle):
+    g = golden["run_write"]
+    for row in g["rows"]:
+        for off in (0, 61, 62, 63):
+            expect = bytes.fromhex(row["off%d" % off].replace(" ", ""))
+            buf = np.zeros(256, dtype=np.uint8)
+            n = shim.shim_long_run_write(buf.ctypes.data, 64 * 2 + off, g["comp"], row["len"])
+            assert bytes(buf[128 + off: 128 + off + n]) == expect
+            assert shim.shim_long_run_bytes(off, row["len"]) == len(expect)
+
+
+def test_long_run_encoder_matches_oracle_everywhere(shim, oracle):
+    rng = np.random.default_rng(0)
+    lengths = [1, 2, 40, 41, 42, 43, 44, 127, 128, 168, 169, 170, 171, 300, 16424, 16425, 16426, 16427, 2 ** 21, 2 ** 21 + 41,
+               2 ** 28 + 5, 2 ** 35 + 9, 2 ** 40 + 1] + [int(x) for x in rng.integers(42, 10 ** 7, 40)]
+    for length in lengths:
+        for off in range(64):
+            ref = oracle.run_write(5, length, prefill=off)
+            assert shim.shim_long_run_bytes(off, length) == len(ref), (length, off)
+            buf = np.zeros(128, dtype=np.uint8)
+            n = shim.shim_long_run_write(buf.ctypes.data, off, 5, length)
+            assert bytes(buf[off: off + n]) == ref, (length, off)
+
+
+def test_record_helpers(shim):
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        sym = rng.integers(0, 6, 128).astype(np.uint32)
+        rel = np.zeros(6, dtype=np.uint32); rel[1:] = rng.integers(0, 1 << 25, 5)
+        h = np.zeros(4, dtype=np.uint32)
+        shim.shim_pack_header(rel.ctypes.data, h.ctypes.data)
+        w = np.zeros(16, dtype=np.uint32)
+        for k in range(4):
+            for plane in range(3):
+                bits = (sym[32 * k: 32 * k + 32] >> plane) & 1
+                w[4 * k + plane] = int(sum(int(b) << t for t, b in enumerate(bits)))
+            w[4 * k + 3] = h[k]
+        for c in range(1, 6):
+            assert shim.shim_rec_header(w.ctypes.data, c) == rel[c]
+        for j in list(rng.integers(0, 129, 8)) + [0, 128, 31, 32, 33, 64, 96]:
+            j = int(j)
+            for c in range(6):
+                assert shim.shim_rec_count(w.ctypes.data, c, j) == int(np.sum(sym[:j] == c))
+            if j < 128:
+                assert shim.shim_rec_symbol(w.ctypes.data, j) == sym[j]
+
+
+def test_range_mask(shim):
+    for a in range(0, 128, 7):
+        for n in (1, 2, 31, 32, 33, 63, 64, 65, 128 - a):
+            if n <= 0 or a + n > 128:
+                continue
+            lo = C.c_uint64(0); hi = C.c_uint64(0)
+            shim.shim_range_mask128(a, n, C.byref(lo), C.byref(hi))
+            v = lo.value | (hi.value << 64)
+            assert v == ((1 << n) - 1) << a
+
+
+def test_run_decode_matches_oracle(shim, oracle):
+    data = b"".join(oracle.run_write(c, l, prefill=0) for c, l in [(1, 1), (5, 41), (0, 42), (3, 1000000), (2, 169)])
+    ref = oracle.run_decode(data)
+    buf = np.frombuffer(data, dtype=np.uint8).copy()
+    pos, got = 0, []
+    while pos < buf.size:
+        sym = C.c_uint32(0); ln = C.c_uint64(0)
+        pos = shim.shim_run_decode(buf.ctypes.data, pos, C.byref(sym), C.byref(ln))
+        got.append((sym.value, ln.value))
+    assert got == ref

@@ -33,10 +33,12 @@ def run(label, emit, blocks):
             print("%-34s %-16s %9.2f ms  %6.2f Gsteps/s" % (label, k, ms / n, B.bases / (ms / n) / 1e6), flush=True)
 
 mode = sys.argv[2] if len(sys.argv) > 2 else "sweep"
-if mode == "sweep":
-    for blocks in (512, 8192):
-        run("atomicOr, %d blocks" % blocks, 0, blocks)
-run("atomicOr, 2048 blocks", 0, 2048)
-run("no emit, 2048 blocks", 1, 2048)
-run("8-byte store emit, 2048 blocks", 2, 2048)
-pkg.tune("walk_emit", 0); pkg.tune("walk_blocks", 0)
+for kernel, kname in ((0, "quad"), (1, "lane")):
+    pkg.tune("walk_kernel", kernel)
+    if mode == "sweep" and kernel == 0:
+        for blocks in (1024, 4096, 8192):
+            run("%s atomicOr, %d blocks" % (kname, blocks), 0, blocks)
+    run("%s atomicOr, 2048 blocks" % kname, 0, 2048)
+    run("%s no emit, 2048 blocks" % kname, 1, 2048)
+    run("%s 8-byte store emit, 2048 blocks" % kname, 2, 2048)
+pkg.tune("walk_emit", 0); pkg.tune("walk_blocks", 0); pkg.tune("walk_kernel", 0)
