@@ -53,6 +53,8 @@ struct Tuning
   long long walk_emit = 0;       // 0 product path; 1 / 2 timing-only variants of the emit (see k_lf_walk)
   long long walk_blocks = 0;     // grid size override for k_lf_walk (0 = default)
   long long walk_kernel = 0;     // 0 = four lanes per chain (product), 1 = one lane per chain (first version, kept for A/B)
+  long long emit_path = 0;       // 0 = partitioned emit (product), 1 = atomicOr on the bitvector (first version, also the fallback)
+  long long round_emits = 1ll << 33;   // upper bound of emits partitioned per round (bounds the temporary regions)
 };
 Tuning g_tune;
 
@@ -100,6 +102,13 @@ void profile_collect()
 #define LAUNCH(name, kernel, grid, block, ...) do { \
   profile_begin(name); \
   hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, g_ctx.stream, __VA_ARGS__); \
+  profile_end(); \
+  hipError_t le_ = hipGetLastError(); \
+  if(le_ != hipSuccess) { return fail(BWTM_ENODEV, "launch of %s failed: %s", name, hipGetErrorString(le_)); } } while(0)
+
+#define LAUNCH_LDS(name, kernel, grid, block, lds, ...) do { \
+  profile_begin(name); \
+  hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3((unsigned)(block)), (unsigned)(lds), g_ctx.stream, __VA_ARGS__); \
   profile_end(); \
   hipError_t le_ = hipGetLastError(); \
   if(le_ != hipSuccess) { return fail(BWTM_ENODEV, "launch of %s failed: %s", name, hipGetErrorString(le_)); } } while(0)
@@ -317,6 +326,8 @@ extern "C" int bwtm_tune(const char* key, long long value)
   if(k == "walk_emit") { g_tune.walk_emit = value; }
   else if(k == "walk_blocks") { g_tune.walk_blocks = value; }
   else if(k == "walk_kernel") { g_tune.walk_kernel = value; }
+  else if(k == "emit_path") { g_tune.emit_path = value; }
+  else if(k == "round_emits") { g_tune.round_emits = (value > 0 ? value : 1); }
   else { return fail(BWTM_EINVAL, "bwtm_tune: unknown key %s", key); }
   return BWTM_OK;
 }
@@ -597,16 +608,13 @@ extern "C" void bwtm_ra_free(bwtm_ra* ra)
   delete ra;
 }
 
-extern "C" int bwtm_search(const bwtm_index* a, const bwtm_index* b, uint64_t seq_first, uint64_t seq_last, bwtm_ra* ra)
+namespace
 {
-  TRY(ensure_ready());
-  if(!a || !b || !ra) { return fail(BWTM_EINVAL, "bwtm_search: null argument"); }
-  if(ra->na != a->n || ra->nb != b->n) { return fail(BWTM_EINVAL, "bwtm_search: rank array was created for other inputs"); }
-  if(ra->finalized) { return fail(BWTM_EINVAL, "bwtm_search: rank array already finalized"); }
-  if(b->m == 0 || seq_first > seq_last) { return BWTM_OK; }       // empty range (utils.h:80-83)
-  if(seq_last >= b->m) { return fail(BWTM_EINVAL, "bwtm_search: sequence %llu out of range (%llu sequences)", (unsigned long long)seq_last, (unsigned long long)b->m); }
-  u64 count = seq_last - seq_first + 1;
-  // Enough resident waves to fill the chip, every lane taking sequences in a grid stride.
+
+// First version of the search (one atomicOr per emit); kept for A/B measurements and as the
+// fallback when the partition parameters do not fit (see search_partitioned).
+int search_atomic(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64 count, bwtm_ra* ra)
+{
   const u64 lanes_per_chain = (g_tune.walk_kernel == 0 ? 4 : 1);
   u64 blocks = div_up(count * lanes_per_chain, BLOCK_THREADS);
   const u64 max_blocks = (g_tune.walk_blocks > 0 ? (u64)g_tune.walk_blocks : 256 * 8);
@@ -616,17 +624,106 @@ extern "C" int bwtm_search(const bwtm_index* a, const bwtm_index* b, uint64_t se
   if(g_tune.walk_emit == 2) { TRY(scratch.alloc(b->n * sizeof(u64) + 64)); target = scratch.as<u32>(); }
   if(g_tune.walk_kernel == 0)
   {
-    if(g_tune.walk_emit == 0)      { LAUNCH("lf_walk", k_lf_walk_quad<0>, blocks, BLOCK_THREADS, a->view(), b->view(), (u64)seq_first, count, target); }
-    else if(g_tune.walk_emit == 1) { LAUNCH("lf_walk_noemit", k_lf_walk_quad<1>, blocks, BLOCK_THREADS, a->view(), b->view(), (u64)seq_first, count, target); }
-    else                           { LAUNCH("lf_walk_store", k_lf_walk_quad<2>, blocks, BLOCK_THREADS, a->view(), b->view(), (u64)seq_first, count, target); }
+    if(g_tune.walk_emit == 0)      { LAUNCH("lf_walk_atomic", k_lf_walk_quad<0>, blocks, BLOCK_THREADS, a->view(), b->view(), seq_first, count, target); }
+    else if(g_tune.walk_emit == 1) { LAUNCH("lf_walk_noemit", k_lf_walk_quad<1>, blocks, BLOCK_THREADS, a->view(), b->view(), seq_first, count, target); }
+    else                           { LAUNCH("lf_walk_store", k_lf_walk_quad<2>, blocks, BLOCK_THREADS, a->view(), b->view(), seq_first, count, target); }
   }
   else
   {
-    if(g_tune.walk_emit == 0)      { LAUNCH("lf_walk_lane", k_lf_walk<0>, blocks, BLOCK_THREADS, a->view(), b->view(), (u64)seq_first, count, target); }
-    else if(g_tune.walk_emit == 1) { LAUNCH("lf_walk_lane_noemit", k_lf_walk<1>, blocks, BLOCK_THREADS, a->view(), b->view(), (u64)seq_first, count, target); }
-    else                           { LAUNCH("lf_walk_lane_store", k_lf_walk<2>, blocks, BLOCK_THREADS, a->view(), b->view(), (u64)seq_first, count, target); }
+    if(g_tune.walk_emit == 0)      { LAUNCH("lf_walk_lane", k_lf_walk<0>, blocks, BLOCK_THREADS, a->view(), b->view(), seq_first, count, target); }
+    else if(g_tune.walk_emit == 1) { LAUNCH("lf_walk_lane_noemit", k_lf_walk<1>, blocks, BLOCK_THREADS, a->view(), b->view(), seq_first, count, target); }
+    else                           { LAUNCH("lf_walk_lane_store", k_lf_walk<2>, blocks, BLOCK_THREADS, a->view(), b->view(), seq_first, count, target); }
   }
   return BWTM_OK;
+}
+
+// Product path: walk with partitioned emit, level-2 counting sort, tile build (bwtm_kernels.hip.h).
+int search_partitioned(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64 count, bwtm_ra* ra)
+{
+  const u64 ntiles = div_up(ra->n_out + 1, 1ull << TILE_SHIFT);
+  const u64 nsub = div_up(ntiles, L1_BINS);
+  if(nsub > 8192) { return search_atomic(a, b, seq_first, count, ra); }       // LDS tables of level 2 would not fit
+  const u64 ntiles_pad = nsub * L1_BINS;
+  const u64 nwords = ra->nchunks * CHUNK_WORDS;
+
+  // Rounds bound the temporary regions: emits of a round <= round_emits (estimated from the
+  // average sequence length; the regions have slack and an exact fallback).
+  const u64 per_seq = b->n / (b->m > 0 ? b->m : 1) + 1;
+  u64 seqs_per_round = (u64)g_tune.round_emits / per_seq; if(seqs_per_round == 0) { seqs_per_round = 1; }
+  const u64 nrounds = div_up(count, seqs_per_round);
+  seqs_per_round = div_up(count, nrounds);
+
+  for(u64 round = 0; round < nrounds; round++)
+  {
+    const u64 r_first = seq_first + round * seqs_per_round;
+    u64 r_count = seqs_per_round; if(round * seqs_per_round + r_count > count) { r_count = count - round * seqs_per_round; }
+    u64 blocks = div_up(r_count, (u64)(WB_THREADS / 4) * WALK_ILP);
+    const u64 max_blocks = (g_tune.walk_blocks > 0 ? (u64)g_tune.walk_blocks : 512);
+    if(blocks > max_blocks) { blocks = max_blocks; }
+    const u64 est = r_count * per_seq;
+    u64 cap = est / L1_BINS + est / (4 * L1_BINS) + blocks * L1_CHUNK + (1ull << TILE_SHIFT);
+    cap = div_up(cap, L1_CHUNK) * L1_CHUNK;
+
+    DevBuf l1, gcount, overflow;
+    TRY(l1.alloc((u64)L1_BINS * cap * sizeof(u32)));
+    TRY(gcount.alloc(L1_BINS * sizeof(u64), true));
+    TRY(overflow.alloc(64, true));
+    EmitSink sink; sink.l1 = l1.as<u32>(); sink.cap = cap; sink.gcount = gcount.as<u64>(); sink.bits = ra->bits_as<u32>(); sink.overflow = overflow.as<u32>();
+    LAUNCH("lf_walk", k_lf_walk_binned, blocks, WB_THREADS, a->view(), b->view(), r_first, r_count, sink);
+
+    std::vector<u64> counts_host(L1_BINS);
+    HIP_TRY(hipMemcpyAsync(counts_host.data(), gcount.p, L1_BINS * sizeof(u64), hipMemcpyDeviceToHost, g_ctx.stream));
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+
+    // Slices of at most PART_SLICE entries, each inside one bin.
+    std::vector<u32> slice_bin, bin_slice0(L1_BINS + 1);
+    std::vector<u64> slice_begin;
+    u64 total_entries = 0;
+    for(u32 bin = 0; bin < (u32)L1_BINS; bin++)
+    {
+      bin_slice0[bin] = (u32)slice_bin.size();
+      u64 total = (counts_host[bin] > cap ? cap : counts_host[bin]);
+      total_entries += total;
+      for(u64 begin = 0; begin < total; begin += PART_SLICE) { slice_bin.push_back(bin); slice_begin.push_back(begin); }
+    }
+    bin_slice0[L1_BINS] = (u32)slice_bin.size();
+    const u64 nslices = slice_bin.size();
+    if(nslices == 0) { continue; }
+
+    DevBuf d_slice_bin, d_slice_begin, d_bin_slice0, counts, tile_start, lists;
+    TRY(d_slice_bin.alloc(nslices * sizeof(u32))); TRY(d_slice_begin.alloc(nslices * sizeof(u64))); TRY(d_bin_slice0.alloc((L1_BINS + 1) * sizeof(u32)));
+    HIP_TRY(hipMemcpyAsync(d_slice_bin.p, slice_bin.data(), nslices * sizeof(u32), hipMemcpyHostToDevice, g_ctx.stream));
+    HIP_TRY(hipMemcpyAsync(d_slice_begin.p, slice_begin.data(), nslices * sizeof(u64), hipMemcpyHostToDevice, g_ctx.stream));
+    HIP_TRY(hipMemcpyAsync(d_bin_slice0.p, bin_slice0.data(), (L1_BINS + 1) * sizeof(u32), hipMemcpyHostToDevice, g_ctx.stream));
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));         // the host vectors go out of scope at the end of the round
+    TRY(counts.alloc(nslices * nsub * sizeof(u32)));
+    TRY(tile_start.alloc((ntiles_pad + 1) * sizeof(u64), true));
+    TRY(lists.alloc(total_entries * sizeof(unsigned short) + 64));
+
+    LAUNCH_LDS("part_count", k_part_count, nslices, PART_THREADS, nsub * sizeof(u32), l1.as<const u32>(), cap, gcount.as<const u64>(),
+      d_slice_bin.as<const u32>(), d_slice_begin.as<const u64>(), (u32)nsub, counts.as<u32>());
+    LAUNCH("part_offsets", k_part_offsets, div_up(ntiles_pad, BLOCK_THREADS), BLOCK_THREADS, counts.as<u32>(), d_bin_slice0.as<const u32>(), (u32)nsub, tile_start.as<u64>());
+    TRY(device_scan<0>(tile_start.as<u64>(), tile_start.as<u64>(), ntiles_pad + 1));
+    LAUNCH_LDS("part_scatter", k_part_scatter, nslices, PART_THREADS, nsub * sizeof(u64), l1.as<const u32>(), cap, gcount.as<const u64>(),
+      d_slice_bin.as<const u32>(), d_slice_begin.as<const u64>(), (u32)nsub, counts.as<const u32>(), tile_start.as<const u64>(), lists.as<unsigned short>());
+    LAUNCH("tile_build", k_tile_build, ntiles_pad, BLOCK_THREADS, lists.as<const unsigned short>(), tile_start.as<const u64>(), ntiles_pad, ra->bits_as<u64>(), nwords);
+  }
+  return BWTM_OK;
+}
+
+} // namespace
+
+extern "C" int bwtm_search(const bwtm_index* a, const bwtm_index* b, uint64_t seq_first, uint64_t seq_last, bwtm_ra* ra)
+{
+  TRY(ensure_ready());
+  if(!a || !b || !ra) { return fail(BWTM_EINVAL, "bwtm_search: null argument"); }
+  if(ra->na != a->n || ra->nb != b->n) { return fail(BWTM_EINVAL, "bwtm_search: rank array was created for other inputs"); }
+  if(ra->finalized) { return fail(BWTM_EINVAL, "bwtm_search: rank array already finalized"); }
+  if(b->m == 0 || seq_first > seq_last) { return BWTM_OK; }       // empty range (utils.h:80-83)
+  if(seq_last >= b->m) { return fail(BWTM_EINVAL, "bwtm_search: sequence %llu out of range (%llu sequences)", (unsigned long long)seq_last, (unsigned long long)b->m); }
+  u64 count = seq_last - seq_first + 1;
+  if(g_tune.emit_path == 0 && g_tune.walk_emit == 0 && g_tune.walk_kernel == 0) { return search_partitioned(a, b, seq_first, count, ra); }
+  return search_atomic(a, b, seq_first, count, ra);
 }
 
 extern "C" int bwtm_ra_device_buffer(bwtm_ra* ra, void** device_ptr, uint64_t* nbytes)

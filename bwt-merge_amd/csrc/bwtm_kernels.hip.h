@@ -516,12 +516,12 @@ __device__ inline u32 quad_or_u32(u32 v)
 __device__ inline u32 quad_rank_part(uint4 ch, u32 q, u32 c, u32 j)
 {
   u32 part = (u32)__builtin_popcount(plane_match(ch.x, ch.y, ch.z, c) & below_mask(j, q));
-  int s = (int)(FIELD_BITS * (c - 1));            // field occupies header bits [s, s + 25)
-  int lo = s - 32 * (int)q;                        // field start relative to this lane's word
-  u32 piece;
-  if(lo >= 32 || lo + (int)FIELD_BITS <= 0) { piece = 0; }
-  else if(lo >= 0) { piece = (ch.w >> lo) & FIELD_MASK; }                 // low part of the field
-  else { piece = (ch.w << (-lo)) & FIELD_MASK; }                          // high part of the field
+  // field of c occupies header bits [s, s + 25); this lane holds header bits [32 q, 32 q + 32)
+  int lo = (int)(FIELD_BITS * (c - 1)) - 32 * (int)q;          // field start relative to this lane's word
+  u64 wide = (u64)ch.w << 32;                                   // word at bits [32, 64) of a 64-bit window
+  int sh = lo + 32;                                             // shift of the window (may be out of range)
+  u32 piece = (sh >= 0 && sh < 64 ? (u32)(wide >> sh) : 0u) & FIELD_MASK;
+  // lo >= 0: (w >> lo); lo < 0: (w << -lo); |lo| >= 32 or field below the word: 0 by the range test / mask
   return part + piece;
 }
 
@@ -568,6 +568,282 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_lf_walk_quad(IndexView A, Ind
     i = sC[8 + c] + quad_sum_u64(pb);                         // LF_B(i), utils.h:335-341
     r = sC[c] + quad_sum_u64(pa);                             // LF_A(r, c), utils.h:343-348
     if(q == 0) { walk_emit<EMIT>(bits, i, r); }
+  }
+}
+
+//------------------------------------------------------------------------------
+// K1 + K2, product form: search with a PARTITIONED EMIT.
+//
+// Scattered memory-side atomics cap at ~24 G/s on MI355X and queue behind the next step's loads
+// (DESIGN.md 3.1), so the walk does not touch the bitvector.  Every emit p = i + r becomes a 32-bit
+// entry that is radix-partitioned in two levels (this is the "radix sort" of the north star,
+// reduced to what the interleave needs: which output positions come from B):
+//
+//   tile  = p >> 16                       (65 536 bits = 8 KiB of the bitvector: an LDS tile)
+//   level 1 (inside the walk): bin = tile & 511, staged in LDS rings, flushed as full 64-byte
+//            lines into per-workgroup chunks of the bin's region;  entry = (tile >> 9) << 16 | (p & 0xFFFF)
+//   level 2 (k_part_count / k_part_offsets / k_part_scatter): counting sort of every bin by
+//            sub = tile >> 9 into exact per-tile lists of 16-bit offsets
+//   tiles   (k_tile_build): one workgroup per tile sets the bits in LDS and ORs the 8 KiB into
+//            the bitvector with plain coalesced stores.
+//
+// Interleaving the tiles over the bins (bin = tile & 511) keeps the bins balanced whatever the
+// distribution of B among A.  Ring overflow (a > 32-deep burst into one bin within four
+// iterations) and region overflow fall back to an atomicOr on the bitvector, so the result is
+// exact in every case.
+
+constexpr int WB_THREADS   = 512;
+constexpr int TILE_SHIFT   = 16;
+constexpr u32 TILE_MASK    = (1u << TILE_SHIFT) - 1;
+constexpr int L1_BITS      = 9;
+constexpr int L1_BINS      = 1 << L1_BITS;
+constexpr int L1_RING      = 32;
+constexpr int L1_CHUNK     = 256;          // entries per chunk reservation (1 KiB)
+constexpr int L1_FLUSH_EVERY = 4;
+constexpr u32 L1_SENTINEL  = 0xFFFFFFFFu;
+constexpr int WALK_ILP     = 4;            // chains per quad
+
+struct EmitSink
+{
+  u32* l1;            // L1_BINS regions of `cap` entries
+  u64  cap;           // entries per region (multiple of L1_CHUNK)
+  u64* gcount;        // entries reserved per region
+  u32* bits;          // the bitvector (fallback path)
+  u32* overflow;      // set when a region overflowed (diagnostic; the fallback keeps the result exact)
+};
+
+__device__ inline void sink_fallback(u32* bits, u64 p) { atomicOr(bits + (p >> 5), 1u << (p & 31)); }
+
+__device__ inline void sink_append(u32* bits, u32* ring, u32* tail, const u32* head, u64 p)
+{
+  u64 tile = p >> TILE_SHIFT;
+  u32 b = (u32)tile & (L1_BINS - 1);
+  u32 entry = ((u32)(tile >> L1_BITS) << TILE_SHIFT) | ((u32)p & TILE_MASK);
+  u32 slot = atomicAdd(&tail[b], 1u);
+  if(slot - head[b] < (u32)L1_RING) { ring[b * L1_RING + (slot & (L1_RING - 1))] = entry; }
+  else { sink_fallback(bits, p); }
+}
+
+// Flushes full 16-entry blocks of bin b (one thread per bin, between barriers).
+__device__ __attribute__((noinline)) void sink_flush_bin(const EmitSink sink, u32* ring, u32* tail, u32* head, u64* chunk_pos, u32* chunk_left, u32 b, bool final)
+{
+  u32 h = head[b];
+  u32 real = tail[b] - h; if(real > (u32)L1_RING) { real = L1_RING; }     // slots past the ring took the fallback
+  while(real >= 16 || (final && real > 0))
+  {
+    u32 n = (real >= 16 ? 16u : real);
+    uint4* src = (uint4*)(ring + b * L1_RING + (h & (L1_RING - 1)));
+    uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+    if(n < 16)
+    {
+      u32 e[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+      for(u32 k = 0; k < 16; k++) { if(k >= n) { e[k] = L1_SENTINEL; } }
+      v0 = make_uint4(e[0], e[1], e[2], e[3]); v1 = make_uint4(e[4], e[5], e[6], e[7]);
+      v2 = make_uint4(e[8], e[9], e[10], e[11]); v3 = make_uint4(e[12], e[13], e[14], e[15]);
+    }
+    if(chunk_left[b] == 0)
+    {
+      u64 base = atomicAdd((unsigned long long*)&sink.gcount[b], (unsigned long long)L1_CHUNK);
+      if(base + L1_CHUNK <= sink.cap) { chunk_pos[b] = (u64)b * sink.cap + base; chunk_left[b] = L1_CHUNK; }
+      else { atomicOr(sink.overflow, 1u); }
+    }
+    if(chunk_left[b] != 0)
+    {
+      uint4* dst = (uint4*)(sink.l1 + chunk_pos[b]);
+      dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
+      chunk_pos[b] += 16; chunk_left[b] -= 16;
+    }
+    else
+    {
+      // region full: apply the block directly
+      u32 e[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+      for(u32 k = 0; k < 16; k++)
+      {
+        if(e[k] != L1_SENTINEL) { sink_fallback(sink.bits, ((((u64)(e[k] >> TILE_SHIFT) << L1_BITS) | b) << TILE_SHIFT) | (e[k] & TILE_MASK)); }
+      }
+    }
+    h += 16; real -= n;
+  }
+  if(final)
+  {
+    // pad the open chunk so that every reserved entry is either valid or a sentinel
+    uint4 sv = make_uint4(L1_SENTINEL, L1_SENTINEL, L1_SENTINEL, L1_SENTINEL);
+    uint4* dst = (uint4*)(sink.l1 + chunk_pos[b]);
+    for(u32 k = 0; k < chunk_left[b] / 4; k++) { dst[k] = sv; }
+    chunk_left[b] = 0;
+    head[b] = 0; tail[b] = 0;
+  }
+  else { head[b] = h; tail[b] = h + real; }
+}
+
+__global__ void __launch_bounds__(WB_THREADS, 4) k_lf_walk_binned(IndexView A, IndexView B, u64 seq_first, u64 seq_count, EmitSink sink)
+{
+  __shared__ u64 sC[16];
+  __shared__ u32 ring[L1_BINS * L1_RING];
+  __shared__ u32 tail[L1_BINS], head[L1_BINS], chunk_left[L1_BINS];
+  __shared__ u64 chunk_pos[L1_BINS];
+  if(threadIdx.x < L1_BINS) { tail[threadIdx.x] = 0; head[threadIdx.x] = 0; chunk_left[threadIdx.x] = 0; chunk_pos[threadIdx.x] = 0; }
+  if(threadIdx.x == 0)
+  {
+#pragma unroll
+    for(int k = 0; k < 8; k++) { sC[k] = A.C[k]; sC[8 + k] = B.C[k]; }
+  }
+  __syncthreads();
+
+  const u32 q = threadIdx.x & 3;
+  const u64 stride = ((u64)gridDim.x * WB_THREADS) >> 2;
+  u64 next = ((u64)blockIdx.x * WB_THREADS + threadIdx.x) >> 2;
+  u64 i[WALK_ILP], r[WALK_ILP];
+  bool walking[WALK_ILP];
+#pragma unroll
+  for(int s = 0; s < WALK_ILP; s++) { i[s] = 0; r[s] = 0; walking[s] = false; }
+
+  for(u32 it = 0; ; it++)
+  {
+    uint4 cb[WALK_ILP], ca[WALK_ILP];
+    u64 sbq[WALK_ILP], saq[WALK_ILP];
+#pragma unroll
+    for(int s = 0; s < WALK_ILP; s++)
+    {
+      if(!walking[s] && next < seq_count)
+      {
+        i[s] = seq_first + next; r[s] = A.m;                    // fmi.cpp:286: trie root "$"
+        next += stride; walking[s] = true;
+        if(q == 0) { sink_append(sink.bits, ring, tail, head, i[s] + r[s]); }
+      }
+      if(walking[s])
+      {
+        cb[s] = B.recs[4 * (i[s] >> REC_SHIFT) + q];
+        ca[s] = A.recs[4 * (r[s] >> REC_SHIFT) + q];
+        sbq[s] = B.sup[(i[s] >> SUPER_SHIFT) * SUP_STRIDE + 1 + q];
+        saq[s] = A.sup[(r[s] >> SUPER_SHIFT) * SUP_STRIDE + 1 + q];
+      }
+    }
+#pragma unroll
+    for(int s = 0; s < WALK_ILP; s++)
+    {
+      if(walking[s])
+      {
+        const u32 jb = (u32)(i[s] & (REC_POS - 1)), ja = (u32)(r[s] & (REC_POS - 1));
+        const u32 t = jb & 31;
+        u32 mine = ((cb[s].x >> t) & 1u) | (((cb[s].y >> t) & 1u) << 1) | (((cb[s].z >> t) & 1u) << 2);
+        const u32 c = quad_or_u32((jb >> 5) == q ? mine : 0u);      // BWT_B[i]
+        if(c == 0) { walking[s] = false; }                          // fmi.cpp:299: start of the sequence
+        else
+        {
+          u64 pb = (u64)quad_rank_part(cb[s], q, c, jb) + (c == q + 1 ? sbq[s] : 0);
+          u64 pa = (u64)quad_rank_part(ca[s], q, c, ja) + (c == q + 1 ? saq[s] : 0);
+          if(c == 5 && q == 0)            // 'N' is rare: its super entries are fetched on demand
+          {
+            pb += B.sup[(i[s] >> SUPER_SHIFT) * SUP_STRIDE + 5];
+            pa += A.sup[(r[s] >> SUPER_SHIFT) * SUP_STRIDE + 5];
+          }
+          i[s] = sC[8 + c] + quad_sum_u64(pb);                      // LF_B(i), utils.h:335-341
+          r[s] = sC[c] + quad_sum_u64(pa);                          // LF_A(r, c), utils.h:343-348
+          if(q == 0) { sink_append(sink.bits, ring, tail, head, i[s] + r[s]); }
+        }
+      }
+    }
+    if((it & (L1_FLUSH_EVERY - 1)) == L1_FLUSH_EVERY - 1)
+    {
+      bool busy = (next < seq_count);
+#pragma unroll
+      for(int s = 0; s < WALK_ILP; s++) { busy = busy || walking[s]; }
+      int any = __syncthreads_or(busy ? 1 : 0);
+      if(threadIdx.x < L1_BINS) { sink_flush_bin(sink, ring, tail, head, chunk_pos, chunk_left, threadIdx.x, !any); }
+      __syncthreads();
+      if(!any) { break; }
+    }
+  }
+}
+
+// Level 2, pass a: histogram of sub-bins for one slice of one bin.  slice_bin / slice_begin
+// describe the slices (host-built); counts is [nslices][nsub].
+constexpr int PART_THREADS = 1024;
+constexpr u64 PART_SLICE = 1ull << 20;      // entries per slice
+
+__global__ void __launch_bounds__(PART_THREADS) k_part_count(const u32* l1, u64 cap, const u64* gcount, const u32* slice_bin,
+  const u64* slice_begin, u32 nsub, u32* counts)
+{
+  extern __shared__ u32 hist[];
+  for(u32 k = threadIdx.x; k < nsub; k += PART_THREADS) { hist[k] = 0; }
+  __syncthreads();
+  u32 b = slice_bin[blockIdx.x];
+  u64 begin = slice_begin[blockIdx.x];
+  u64 end = begin + PART_SLICE; u64 total = gcount[b]; if(total > cap) { total = cap; } if(end > total) { end = total; }
+  const u32* src = l1 + (u64)b * cap;
+  for(u64 k = begin + threadIdx.x; k < end; k += PART_THREADS)
+  {
+    u32 e = src[k];
+    if(e != L1_SENTINEL) { atomicAdd(&hist[e >> TILE_SHIFT], 1u); }
+  }
+  __syncthreads();
+  for(u32 k = threadIdx.x; k < nsub; k += PART_THREADS) { counts[(u64)blockIdx.x * nsub + k] = hist[k]; }
+}
+
+// Level 2, pass b: per (bin, sub) = tile: exclusive prefix of the slice counts (in place) and the
+// tile total.  One thread per tile; slices of a bin are consecutive: [bin_slice0[b], bin_slice0[b + 1]).
+__global__ void __launch_bounds__(BLOCK_THREADS) k_part_offsets(u32* counts, const u32* bin_slice0, u32 nsub, u64* tile_total)
+{
+  u64 id = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(id >= (u64)nsub * L1_BINS) { return; }
+  u32 b = (u32)(id / nsub), sub = (u32)(id % nsub);
+  u64 acc = 0;
+  for(u32 sl = bin_slice0[b]; sl < bin_slice0[b + 1]; sl++)
+  {
+    u64 idx = (u64)sl * nsub + sub;
+    u32 c = counts[idx]; counts[idx] = (u32)acc; acc += c;
+  }
+  tile_total[(u64)sub * L1_BINS + b] = acc;
+}
+
+// Level 2, pass c: scatter the 16-bit offsets of one slice to their tiles' lists.
+__global__ void __launch_bounds__(PART_THREADS) k_part_scatter(const u32* l1, u64 cap, const u64* gcount, const u32* slice_bin,
+  const u64* slice_begin, u32 nsub, const u32* counts, const u64* tile_start, unsigned short* out)
+{
+  extern __shared__ u64 cursor[];
+  u32 b = slice_bin[blockIdx.x];
+  for(u32 k = threadIdx.x; k < nsub; k += PART_THREADS)
+  {
+    cursor[k] = tile_start[(u64)k * L1_BINS + b] + counts[(u64)blockIdx.x * nsub + k];
+  }
+  __syncthreads();
+  u64 begin = slice_begin[blockIdx.x];
+  u64 end = begin + PART_SLICE; u64 total = gcount[b]; if(total > cap) { total = cap; } if(end > total) { end = total; }
+  const u32* src = l1 + (u64)b * cap;
+  for(u64 k = begin + threadIdx.x; k < end; k += PART_THREADS)
+  {
+    u32 e = src[k];
+    if(e != L1_SENTINEL)
+    {
+      u64 pos = atomicAdd((unsigned long long*)&cursor[e >> TILE_SHIFT], 1ull);
+      out[pos] = (unsigned short)(e & TILE_MASK);
+    }
+  }
+}
+
+// Tiles: set the bits of one 65 536-bit tile in LDS, then OR the 8 KiB into the bitvector.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_tile_build(const unsigned short* lists, const u64* tile_start, u64 ntiles, u64* bits, u64 nwords)
+{
+  __shared__ u32 tile[1 << (TILE_SHIFT - 5)];           // 2048 x u32 = 8 KiB
+  u64 t = blockIdx.x;
+  if(t >= ntiles) { return; }
+  u64 begin = tile_start[t], end = tile_start[t + 1];
+  if(begin == end) { return; }
+  for(u32 k = threadIdx.x; k < (1u << (TILE_SHIFT - 5)); k += BLOCK_THREADS) { tile[k] = 0; }
+  __syncthreads();
+  for(u64 k = begin + threadIdx.x; k < end; k += BLOCK_THREADS)
+  {
+    u32 off = lists[k];
+    atomicOr(&tile[off >> 5], 1u << (off & 31));
+  }
+  __syncthreads();
+  u64 w0 = t << (TILE_SHIFT - 6);
+  for(u32 k = threadIdx.x; k < (1u << (TILE_SHIFT - 6)); k += BLOCK_THREADS)
+  {
+    u64 w = w0 + k;
+    if(w < nwords) { bits[w] |= (u64)tile[2 * k] | ((u64)tile[2 * k + 1] << 32); }
   }
 }
 

@@ -33,6 +33,22 @@ def run(label, emit, blocks):
             print("%-34s %-16s %9.2f ms  %6.2f Gsteps/s" % (label, k, ms / n, B.bases / (ms / n) / 1e6), flush=True)
 
 mode = sys.argv[2] if len(sys.argv) > 2 else "sweep"
+def run_product(label):
+    pkg.tune("walk_emit", 0); pkg.tune("walk_blocks", 0); pkg.tune("walk_kernel", 0); pkg.tune("emit_path", 0); pkg.tune("emit_path", 0)
+    pkg.profile_reset()
+    for _ in range(2):
+        ra = pkg.RankArray(A, B)
+        ra.search(A, B, 0, B.sequences - 1)
+        pkg.synchronize()
+        ra.free()
+    prof = pkg.profile_read()
+    tot = 0
+    for k, (ms, n) in prof.items():
+        print("%-34s %-16s %9.2f ms per search" % (label, k, ms / 2), flush=True); tot += ms / 2
+    print("%-34s %-16s %9.2f ms  %6.2f Gsteps/s" % (label, "TOTAL", tot, B.bases / tot / 1e6), flush=True)
+
+run_product("partitioned emit (product)")
+pkg.tune("emit_path", 1)
 for kernel, kname in ((0, "quad"), (1, "lane")):
     pkg.tune("walk_kernel", kernel)
     if mode == "sweep" and kernel == 0:
@@ -41,4 +57,4 @@ for kernel, kname in ((0, "quad"), (1, "lane")):
     run("%s atomicOr, 2048 blocks" % kname, 0, 2048)
     run("%s no emit, 2048 blocks" % kname, 1, 2048)
     run("%s 8-byte store emit, 2048 blocks" % kname, 2, 2048)
-pkg.tune("walk_emit", 0); pkg.tune("walk_blocks", 0); pkg.tune("walk_kernel", 0)
+pkg.tune("walk_emit", 0); pkg.tune("walk_blocks", 0); pkg.tune("walk_kernel", 0); pkg.tune("emit_path", 0)
