@@ -53,6 +53,7 @@ struct Tuning
   long long walk_emit = 0;       // 0 product path; 1 / 2 timing-only variants of the emit (see k_lf_walk)
   long long walk_blocks = 0;     // grid size override for k_lf_walk (0 = default)
   long long walk_kernel = 0;     // 0 = four lanes per chain (product), 1 = one lane per chain (first version, kept for A/B)
+  long long walk_ablate = 0;     // timing-only ablations of the no-emit quad kernel (tools/walk_experiments.py)
   long long emit_path = 0;       // 0 = partitioned emit (product), 1 = atomicOr on the bitvector (first version, also the fallback)
   long long round_emits = 1ll << 33;   // upper bound of emits partitioned per round (bounds the temporary regions)
 };
@@ -327,6 +328,7 @@ extern "C" int bwtm_tune(const char* key, long long value)
   else if(k == "walk_blocks") { g_tune.walk_blocks = value; }
   else if(k == "walk_kernel") { g_tune.walk_kernel = value; }
   else if(k == "emit_path") { g_tune.emit_path = value; }
+  else if(k == "walk_ablate") { g_tune.walk_ablate = value; }
   else if(k == "round_emits") { g_tune.round_emits = (value > 0 ? value : 1); }
   else { return fail(BWTM_EINVAL, "bwtm_tune: unknown key %s", key); }
   return BWTM_OK;
@@ -625,7 +627,18 @@ int search_atomic(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64 c
   if(g_tune.walk_kernel == 0)
   {
     if(g_tune.walk_emit == 0)      { LAUNCH("lf_walk_atomic", k_lf_walk_quad<0>, blocks, BLOCK_THREADS, a->view(), b->view(), seq_first, count, target); }
-    else if(g_tune.walk_emit == 1) { LAUNCH("lf_walk_noemit", k_lf_walk_quad<1>, blocks, BLOCK_THREADS, a->view(), b->view(), seq_first, count, target); }
+    else if(g_tune.walk_emit == 1)
+    {
+      switch(g_tune.walk_ablate)
+      {
+        case 1: LAUNCH("lf_walk_noemit_nosup", (k_lf_walk_quad<1, 1>), blocks, BLOCK_THREADS, a->view(), b->view(), seq_first, count, target); break;
+        case 2: LAUNCH("lf_walk_noemit_noA", (k_lf_walk_quad<1, 2>), blocks, BLOCK_THREADS, a->view(), b->view(), seq_first, count, target); break;
+        case 3: LAUNCH("lf_walk_noemit_nosup_noA", (k_lf_walk_quad<1, 3>), blocks, BLOCK_THREADS, a->view(), b->view(), seq_first, count, target); break;
+        case 7: LAUNCH("lf_walk_noemit_noloads", (k_lf_walk_quad<1, 7>), blocks, BLOCK_THREADS, a->view(), b->view(), seq_first, count, target); break;
+        case 8: LAUNCH("lf_walk_noemit_synthetic", (k_lf_walk_quad<1, 8>), blocks, BLOCK_THREADS, a->view(), b->view(), seq_first, count, target); break;
+        default: LAUNCH("lf_walk_noemit", (k_lf_walk_quad<1, 0>), blocks, BLOCK_THREADS, a->view(), b->view(), seq_first, count, target); break;
+      }
+    }
     else                           { LAUNCH("lf_walk_store", k_lf_walk_quad<2>, blocks, BLOCK_THREADS, a->view(), b->view(), seq_first, count, target); }
   }
   else
@@ -669,7 +682,15 @@ int search_partitioned(const bwtm_index* a, const bwtm_index* b, u64 seq_first, 
     TRY(gcount.alloc(L1_BINS * sizeof(u64), true));
     TRY(overflow.alloc(64, true));
     EmitSink sink; sink.l1 = l1.as<u32>(); sink.cap = cap; sink.gcount = gcount.as<u64>(); sink.bits = ra->bits_as<u32>(); sink.overflow = overflow.as<u32>();
-    LAUNCH("lf_walk", k_lf_walk_binned, blocks, WB_THREADS, a->view(), b->view(), r_first, r_count, sink);
+    const u64 sup_bytes = 5 * (a->nsup + b->nsup) * sizeof(u64);
+    if(sup_bytes <= 40 * 1024)
+    {
+      LAUNCH_LDS("lf_walk", k_lf_walk_binned<true>, blocks, WB_THREADS, sup_bytes, a->view(), b->view(), r_first, r_count, sink, (u32)a->nsup, (u32)b->nsup);
+    }
+    else
+    {
+      LAUNCH_LDS("lf_walk", k_lf_walk_binned<false>, blocks, WB_THREADS, 0, a->view(), b->view(), r_first, r_count, sink, (u32)a->nsup, (u32)b->nsup);
+    }
 
     std::vector<u64> counts_host(L1_BINS);
     HIP_TRY(hipMemcpyAsync(counts_host.data(), gcount.p, L1_BINS * sizeof(u64), hipMemcpyDeviceToHost, g_ctx.stream));

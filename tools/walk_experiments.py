@@ -48,6 +48,13 @@ def run_product(label):
     print("%-34s %-16s %9.2f ms  %6.2f Gsteps/s" % (label, "TOTAL", tot, B.bases / tot / 1e6), flush=True)
 
 run_product("partitioned emit (product)")
+if mode == "ablate":
+    pkg.tune("emit_path", 1); pkg.tune("walk_kernel", 0)
+    for abl, name in ((0, "full"), (8, "synthetic chain, all loads"), (1, "no sup loads"), (2, "no A record"), (3, "no sup, no A record"), (7, "no loads at all")):
+        pkg.tune("walk_ablate", abl)
+        run("quad no-emit ablation: %s" % name, 1, 2048)
+    pkg.tune("walk_ablate", 0); pkg.tune("emit_path", 0)
+    sys.exit(0)
 pkg.tune("emit_path", 1)
 for kernel, kname in ((0, "quad"), (1, "lane")):
     pkg.tune("walk_kernel", kernel)
