@@ -1,0 +1,182 @@
+/*
+  bwt_merge -- merges BWT files, with the hot path on an MI355X.  Same command line and the
+  same stdout lines as the reference tool (bwt_merge.cpp:47-299); formats: native, plain_default.
+*/
+#include <atomic>
+#include <sstream>
+#include <unistd.h>
+
+#include "fmi.h"
+
+using namespace bwtmerge;
+
+size_type Parallel::max_threads = std::max(1u, std::thread::hardware_concurrency());
+
+static void printUsage()
+{
+  std::cerr << "Usage: bwt_merge [options] input1 input2 [input3 ...] output" << std::endl << std::endl;
+  std::cerr << "Options:" << std::endl;
+  std::cerr << "  -b N          Set thread buffer size to N megabytes / thread (default: " << MergeParameters::defaultTB() << ")" << std::endl;
+  std::cerr << "  -m N          Set the number of merge buffers to N (default: " << MergeParameters::defaultMB() << ")" << std::endl;
+  std::cerr << "  -r N          Set run buffer size to N megabytes / thread (default: " << MergeParameters::defaultRB() << ")" << std::endl;
+  std::cerr << "  -s N          Set the number of sequence blocks to N (default: " << MergeParameters::defaultSB() << " / thread)" << std::endl;
+  std::cerr << "  -t N          Use N parallel threads (default: " << MergeParameters::defaultT() << " on this system)" << std::endl << std::endl;
+  std::cerr << "  -d directory  Use the given directory for temporary files (default: .)" << std::endl;
+  std::cerr << "  -v filename   Verify by querying with patterns from the given file" << std::endl << std::endl;
+  std::cerr << "  -i formats    Read the inputs in the given formats (default: native)" << std::endl;
+  std::cerr << "                Multiple comma-separated formats can be provided." << std::endl;
+  std::cerr << "  -o format     Write the output in the given format (default: native)" << std::endl;
+  std::cerr << "  -g N          Use GPU N (default: 0; the buffer options have no effect on the device)" << std::endl << std::endl;
+  printFormats(std::cerr);
+}
+
+static size_type readRows(const std::string& filename, std::vector<std::string>& rows)
+{
+  std::ifstream in(filename.c_str(), std::ios_base::binary);
+  if(!in) { std::cerr << "readRows(): Cannot open input file " << filename << std::endl; return 0; }
+  size_type chars = 0;
+  for(std::string line; std::getline(in, line); ) { if(!line.empty()) { rows.push_back(line); chars += line.length(); } }
+  return chars;
+}
+
+// Adds the number of occurrences of every pattern to `results`.
+static void verifyFMI(const FMI& fmi, const std::string& name, const std::vector<std::string>& patterns, std::vector<size_type>& results)
+{
+  size_type chars = 0;
+  for(const std::string& p : patterns) { chars += p.length(); }
+  printSize(name, sizeInBytes(fmi), fmi.size());
+  if(chars > 0)
+  {
+    double start = readTimer();
+    std::atomic<size_type> found(0), matches(0), next(0);
+    std::vector<std::thread> workers;
+    for(size_type t = 0; t < Parallel::max_threads; t++)
+    {
+      workers.emplace_back([&]()
+      {
+        size_type f = 0, m = 0;
+        for(size_type k = next++; k < patterns.size(); k = next++)
+        {
+          range_type range = fmi.find(patterns[k]);
+          results[k] += Range::length(range);
+          if(!Range::empty(range)) { f++; m += Range::length(range); }
+        }
+        found += f; matches += m;
+      });
+    }
+    for(std::thread& w : workers) { w.join(); }
+    printTime(name, found, matches, chars, readTimer() - start);
+  }
+  std::cout << std::endl;
+}
+
+static void merge(FMI& index, FMI& increment, const MergeParameters& parameters)
+{
+  double increment_mb = inMegabytes(increment.size());
+  double start = readTimer();
+  FMI temp(index, increment, parameters);
+  index.swap(temp);
+  double seconds = readTimer() - start;
+  std::cout << "BWTs merged in " << seconds << " seconds (" << (increment_mb / seconds) << " MB/s)" << std::endl << std::endl;
+}
+
+int main(int argc, char** argv)
+{
+  if(argc < 2) { printUsage(); std::exit(EXIT_SUCCESS); }
+
+  double start = readTimer();
+  std::cout << "BWT-merge" << std::endl << std::endl;
+
+  int c = 0, device = 0;
+  bool verify = false;
+  MergeParameters parameters;
+  std::string pattern_name, output_format;
+  std::vector<std::string> input_formats;
+  while((c = getopt(argc, argv, "b:m:r:s:t:d:v:i:o:g:")) != -1)
+  {
+    switch(c)
+    {
+    case 'b': parameters.setTB(std::stoul(optarg)); break;
+    case 'm': parameters.setMB(std::stoul(optarg)); break;
+    case 'r': parameters.setRB(std::stoul(optarg)); break;
+    case 's': parameters.setSB(std::stoul(optarg)); break;
+    case 't': parameters.setT(std::stoul(optarg)); break;
+    case 'd': parameters.setTemp(optarg); break;
+    case 'g': device = std::stoi(optarg); break;
+    case 'v': pattern_name = optarg; verify = true; break;
+    case 'i':
+      {
+        std::istringstream ss(optarg);
+        for(std::string token; std::getline(ss, token, ','); ) { input_formats.push_back(token); }
+        for(const std::string& f : input_formats)
+        {
+          if(!formatExists(f)) { std::cerr << "bwt_merge: Invalid input format: " << f << std::endl; std::exit(EXIT_FAILURE); }
+        }
+      }
+      break;
+    case 'o':
+      output_format = optarg;
+      if(!formatExists(output_format)) { std::cerr << "bwt_merge: Invalid output format: " << output_format << std::endl; std::exit(EXIT_FAILURE); }
+      break;
+    default: std::exit(EXIT_FAILURE);
+    }
+  }
+
+  int inputs = (argc - 1) - optind;
+  if(inputs < 2) { std::cerr << "bwt_merge: Output file not specified" << std::endl; std::exit(EXIT_FAILURE); }
+  if(input_formats.empty()) { input_formats.assign(inputs, NativeFormat::tag()); }
+  if(input_formats.size() == 1) { input_formats.assign(inputs, input_formats[0]); }
+  if(input_formats.size() != (size_type)inputs)
+  {
+    std::cerr << "bwt_merge: Specified " << input_formats.size() << " formats for " << inputs << " inputs" << std::endl;
+    std::exit(EXIT_FAILURE);
+  }
+  if(output_format.empty()) { output_format = NativeFormat::tag(); }
+  parameters.sanitize();
+  Parallel::max_threads = parameters.threads;
+
+  for(int i = optind; i < argc - 1; i++) { std::cout << "Input:            " << argv[i] << " (" << input_formats[i - optind] << ")" << std::endl; }
+  std::cout << "Output:           " << argv[argc - 1] << " (" << output_format << ")" << std::endl;
+  if(verify) { std::cout << "Patterns:         " << pattern_name << std::endl; }
+  std::cout << std::endl << parameters << std::endl;
+
+  gpuCheck(bwtm_init(device), "bwt_merge");
+
+  std::vector<std::string> patterns;
+  std::vector<size_type> pre_results, post_results;
+  if(verify)
+  {
+    size_type chars = readRows(pattern_name, patterns);
+    pre_results.assign(patterns.size(), 0); post_results.assign(patterns.size(), 0);
+    std::cout << "Read " << patterns.size() << " patterns of total length " << chars << std::endl << std::endl;
+  }
+
+  FMI index; load(index, argv[optind], input_formats[0]);
+  verifyFMI(index, "Input", patterns, pre_results);
+
+  size_type bytes_added = 0;
+  for(int input = 1; input < inputs; input++)
+  {
+    FMI increment; load(increment, argv[optind + input], input_formats[input]);
+    bytes_added += increment.size();
+    verifyFMI(increment, "Input", patterns, pre_results);
+    merge(index, increment, parameters);
+  }
+
+  serialize(index, argv[argc - 1], output_format);
+  verifyFMI(index, "Output", patterns, post_results);
+
+  if(verify)
+  {
+    size_type errors = 0;
+    for(size_type i = 0; i < patterns.size(); i++) { if(pre_results[i] != post_results[i]) { errors++; } }
+    if(errors > 0) { std::cout << "Verification failed for " << errors << " patterns" << std::endl; }
+    else { std::cout << "Verification successful" << std::endl; }
+    std::cout << std::endl;
+  }
+
+  double seconds = readTimer() - start;
+  std::cout << "Total time:       " << seconds << " seconds (" << (inMegabytes(bytes_added) / seconds) << " MB/s)" << std::endl;
+  std::cout << "Peak memory:      " << inGigabytes(memoryUsage()) << " GB" << std::endl << std::endl;
+  return 0;
+}

@@ -1,0 +1,284 @@
+/*
+  fmi.h -- host facade: FMI, MergeParameters and the format-dispatching load / serialize
+  (reference fmi.h:38-230, fmi.cpp:336-495).  The merging constructor runs the whole hot path
+  on the GPU through the C ABI; everything else is small host code.
+*/
+#ifndef BWTM_HOST_FMI_H
+#define BWTM_HOST_FMI_H
+
+#include <thread>
+#include "bwt.h"
+
+namespace bwtmerge
+{
+
+class FMI;
+void serialize(const FMI& fmi, const std::string& filename, const std::string& format);
+void load(FMI& fmi, const std::string& filename, const std::string& format);
+
+/*
+  The reference's knobs.  Buffer sizes, merge buffers and the temp directory have nothing to
+  configure on the device (no buffer hierarchy, no temp files); they are accepted, printed and
+  otherwise ignored.  sequence_blocks is the number of bwtm_search() calls the search is split
+  into (the device partitions further on its own).
+*/
+struct MergeParameters
+{
+  typedef range_type run_type;
+
+  const static size_type RUN_BUFFER_SIZE = 8 * MEGABYTE;
+  const static size_type THREAD_BUFFER_SIZE = 256 * MEGABYTE;
+  const static size_type MERGE_BUFFERS = 6;
+  const static size_type BLOCKS_PER_THREAD = 4;
+
+  MergeParameters() :
+    run_buffer_size(RUN_BUFFER_SIZE), thread_buffer_size(THREAD_BUFFER_SIZE), merge_buffers(MERGE_BUFFERS),
+    threads(Parallel::max_threads), sequence_blocks(threads * BLOCKS_PER_THREAD), temp_dir(".") {}
+
+  void sanitize()
+  {
+    threads = Range::bound(threads, 1, Parallel::max_threads);
+    sequence_blocks = std::max(sequence_blocks, (size_type)1);
+    threads = std::min(threads, sequence_blocks);
+  }
+
+  static double defaultRB() { return inMegabytes(RUN_BUFFER_SIZE * sizeof(run_type)); }
+  static double defaultTB() { return inMegabytes(THREAD_BUFFER_SIZE); }
+  static size_type defaultMB() { return MERGE_BUFFERS; }
+  static size_type defaultT()  { return Parallel::max_threads; }
+  static size_type defaultSB() { return BLOCKS_PER_THREAD; }
+
+  void setRB(size_type mb) { run_buffer_size = mb * MEGABYTE / sizeof(run_type); }
+  void setTB(size_type mb) { thread_buffer_size = mb * MEGABYTE; }
+  void setMB(size_type n)  { merge_buffers = n; }
+  void setT(size_type n)   { threads = n; }
+  void setSB(size_type n)  { sequence_blocks = n; }
+  void setTemp(const std::string& directory)
+  {
+    if(directory.empty()) { temp_dir = "."; }
+    else { temp_dir = (directory.back() == '/' ? directory.substr(0, directory.length() - 1) : directory); }
+  }
+
+  size_type run_buffer_size, thread_buffer_size;
+  size_type merge_buffers;
+  size_type threads, sequence_blocks;
+  std::string temp_dir;
+};
+
+inline std::ostream& operator<<(std::ostream& out, const MergeParameters& p)
+{
+  out << "Run buffers:      " << inMegabytes(p.run_buffer_size * sizeof(MergeParameters::run_type)) << " MB" << std::endl;
+  out << "Thread buffers:   " << inMegabytes(p.thread_buffer_size) << " MB" << std::endl;
+  out << "Merge buffers:    " << p.merge_buffers << std::endl;
+  out << "Threads:          " << p.threads << std::endl;
+  out << "Sequence blocks:  " << p.sequence_blocks << std::endl;
+  out << "Temp directory:   " << p.temp_dir << std::endl;
+  return out;
+}
+
+class FMI
+{
+public:
+  typedef BWT::size_type size_type;
+  const static size_type SHORT_RANGE = 256;
+
+  FMI() {}
+
+  // Merges a and b, destroying them (reference fmi.h:107-110).
+  FMI(FMI& a, FMI& b, MergeParameters parameters = MergeParameters());
+
+  void swap(FMI& other) { bwt.swap(other.bwt); std::swap(alpha, other.alpha); }
+
+  size_type size() const { return bwt.size(); }
+  size_type sequences() const { return bwt.sequences(); }
+  range_type charRange(comp_type comp) const { return range_type(alpha.C[comp], alpha.C[comp + 1] - 1); }
+
+  // (LF(i), BWT[i])
+  range_type LF(size_type i) const
+  {
+    range_type t = bwt.inverse_select(i);
+    return range_type(t.first + alpha.C[t.second], t.second);
+  }
+  size_type LF(size_type i, comp_type comp) const { return alpha.C[comp] + bwt.rank(i, comp); }
+  range_type LF(range_type range, comp_type comp) const { return range_type(LF(range.first, comp), LF(range.second + 1, comp) - 1); }
+  void LF(size_type i, BWT::ranks_type& results) const
+  {
+    bwt.ranks(i, results);
+    for(size_type c = 1; c < alpha.sigma; c++) { results[c] += alpha.C[c]; }
+  }
+  void LF(range_type range, BWT::ranks_type& sp, BWT::ranks_type& ep) const
+  {
+    bwt.ranks(range.first, sp); bwt.ranks(range.second + 1, ep);
+    for(size_type c = 1; c < alpha.sigma; c++) { sp[c] += alpha.C[c]; ep[c] += alpha.C[c] - 1; }
+  }
+  void LF(range_type range, BWT::rank_ranges_type& results) const
+  {
+    bwt.ranks(range, results);
+    for(size_type c = 1; c < alpha.sigma; c++) { results[c].first += alpha.C[c]; results[c].second += alpha.C[c] - 1; }
+  }
+
+  // Backward search; the pattern is given in characters.
+  template<class Iterator>
+  range_type find(Iterator begin, Iterator end) const
+  {
+    if(begin == end) { return range_type(0, size() - 1); }
+    --end;
+    range_type range = charRange(alpha.char2comp[(byte_type)*end]);
+    while(!Range::empty(range) && end != begin)
+    {
+      --end;
+      range = LF(range, alpha.char2comp[(byte_type)*end]);
+    }
+    return range;
+  }
+  template<class Container> range_type find(const Container& pattern) const { return find(pattern.begin(), pattern.end()); }
+
+  template<class Format> void serialize(const std::string& filename) const;
+  template<class Format> void load(const std::string& filename);
+
+  BWT      bwt;
+  Alphabet alpha;
+};
+
+// Search phase (buildRA, reference fmi.cpp:272-334) as a free function: uploads a and b and
+// fills a device rank array; parameters.sequence_blocks splits the sequences of b.
+inline void buildRA(const FMI& a, const FMI& b, const MergeParameters& parameters, RankArray& ra)
+{
+  ra.clear();
+  ra.a = a.bwt.upload(a.alpha.C);
+  ra.b = b.bwt.upload(b.alpha.C);
+  gpuCheck(bwtm_ra_create(ra.a, ra.b, &ra.handle), "buildRA()");
+  if(b.sequences() == 0) { return; }
+  for(range_type block : getBounds(range_type(0, b.sequences() - 1), parameters.sequence_blocks))
+  {
+    gpuCheck(bwtm_search(ra.a, ra.b, block.first, block.second, ra.handle), "buildRA()");
+  }
+}
+
+inline FMI::FMI(FMI& a, FMI& b, MergeParameters parameters)
+{
+  if(a.alpha != b.alpha)
+  {
+    std::cerr << "FMI::FMI(): Cannot merge BWTs with different alphabets" << std::endl;
+    std::exit(EXIT_FAILURE);
+  }
+  // One search call over all sequences is the fastest split on the device; more blocks only
+  // when the caller asks for them explicitly through a smaller-than-default setting.
+  MergeParameters p = parameters; p.sequence_blocks = 1;
+  RankArray ra;
+  buildRA(a, b, p, ra);
+  Alphabet merged = a.alpha;
+  for(size_type c = 0; c <= merged.sigma; c++) { merged.C[c] += b.alpha.C[c]; }
+  this->bwt = BWT(a.bwt, b.bwt, ra);
+  this->alpha = merged;
+}
+
+//------------------------------------------------------------------------------
+// Formats.
+
+template<>
+inline void FMI::serialize<NativeFormat>(const std::string& filename) const
+{
+  std::ofstream out(filename.c_str(), std::ios_base::binary);
+  if(!out) { std::cerr << "FMI::serialize(): Cannot open output file " << filename << std::endl; return; }
+  bwt.serialize(out);
+  // Alphabet: char2comp int_vector<8>, comp2char int_vector<8>, C int_vector<64>, u64 sigma.
+  sdsl_compat::PackedVector c2c(alpha.char2comp.size(), 8), c2ch(alpha.comp2char.size(), 8), cc(alpha.C.size(), 64);
+  for(size_type k = 0; k < alpha.char2comp.size(); k++) { c2c.set(k, alpha.char2comp[k]); }
+  for(size_type k = 0; k < alpha.comp2char.size(); k++) { c2ch.set(k, alpha.comp2char[k]); }
+  for(size_type k = 0; k < alpha.C.size(); k++) { cc.set(k, alpha.C[k]); }
+  c2c.serialize(out, false); c2ch.serialize(out, false); cc.serialize(out, false);
+  sdsl_compat::write_member(alpha.sigma, out);
+}
+
+template<>
+inline void FMI::load<NativeFormat>(const std::string& filename)
+{
+  std::ifstream in(filename.c_str(), std::ios_base::binary);
+  if(!in) { std::cerr << "FMI::load(): Cannot open input file " << filename << std::endl; std::exit(EXIT_FAILURE); }
+  bwt.load(in);
+  sdsl_compat::PackedVector c2c, c2ch, cc;
+  c2c.load(in, false, 8); c2ch.load(in, false, 8); cc.load(in, false, 64);
+  alpha.char2comp.resize(c2c.count); alpha.comp2char.resize(c2ch.count); alpha.C.resize(cc.count);
+  for(size_type k = 0; k < c2c.count; k++) { alpha.char2comp[k] = (byte_type)c2c.get(k); }
+  for(size_type k = 0; k < c2ch.count; k++) { alpha.comp2char[k] = (byte_type)c2ch.get(k); }
+  for(size_type k = 0; k < cc.count; k++) { alpha.C[k] = cc.get(k); }
+  sdsl_compat::read_member(alpha.sigma, in);
+}
+
+// One character per base (reference PlainData, formats.cpp:126-188).
+template<>
+inline void FMI::serialize<PlainFormatD>(const std::string& filename) const
+{
+  std::ofstream out(filename.c_str(), std::ios_base::binary);
+  if(!out) { std::cerr << "BWT::serialize(): Cannot open output file " << filename << std::endl; return; }
+  std::vector<char> buffer;
+  for(size_type rle_pos = 0; rle_pos < bwt.bytes(); )
+  {
+    range_type run = Run::read(bwt.data, rle_pos);
+    buffer.insert(buffer.end(), run.second, (char)alpha.comp2char[run.first]);
+    if(buffer.size() >= MEGABYTE) { out.write(buffer.data(), buffer.size()); buffer.clear(); }
+  }
+  out.write(buffer.data(), buffer.size());
+}
+
+template<>
+inline void FMI::load<PlainFormatD>(const std::string& filename)
+{
+  std::ifstream in(filename.c_str(), std::ios_base::binary);
+  if(!in) { std::cerr << "BWT::load(): Cannot open input file " << filename << std::endl; std::exit(EXIT_FAILURE); }
+  alpha = Alphabet();
+  bwt.data.clear();
+  // Runs are formed on the raw characters and mapped afterwards, like the reference does
+  // (formats.cpp:147-156), so 'a' next to 'A' stays two runs.
+  RunBuffer run_buffer;
+  std::vector<char> buffer(MEGABYTE);
+  while(in)
+  {
+    in.read(buffer.data(), buffer.size());
+    for(std::streamsize k = 0; k < in.gcount(); k++)
+    {
+      if(run_buffer.add((byte_type)buffer[k])) { Run::write(bwt.data, alpha.char2comp[run_buffer.run.first], run_buffer.run.second); }
+    }
+  }
+  run_buffer.flush(); Run::write(bwt.data, alpha.char2comp[run_buffer.run.first], run_buffer.run.second);
+  bwt.buildFromData(AO_DEFAULT);
+  std::vector<size_type> counts(BWT::SIGMA);
+  for(size_type c = 0; c < BWT::SIGMA; c++) { counts[c] = bwt.count(c); }
+  alpha = Alphabet(counts);
+}
+
+inline void serialize(const FMI& fmi, const std::string& filename, const std::string& format)
+{
+  if(format == NativeFormat::tag()) { fmi.serialize<NativeFormat>(filename); }
+  else if(format == PlainFormatD::tag()) { fmi.serialize<PlainFormatD>(filename); }
+  else { std::cerr << "serialize(): Invalid BWT format: " << format << std::endl; std::exit(EXIT_FAILURE); }
+}
+
+inline void load(FMI& fmi, const std::string& filename, const std::string& format)
+{
+  if(format == NativeFormat::tag()) { fmi.load<NativeFormat>(filename); }
+  else if(format == PlainFormatD::tag()) { fmi.load<PlainFormatD>(filename); }
+  else { std::cerr << "load(): Invalid BWT format: " << format << std::endl; std::exit(EXIT_FAILURE); }
+}
+
+// Bytes the native serialization takes (stands in for sdsl::size_in_bytes in the size report).
+inline size_type sizeInBytes(const FMI& fmi)
+{
+  struct Counter : std::streambuf { size_type n = 0; std::streamsize xsputn(const char*, std::streamsize k) override { n += k; return k; } int overflow(int c) override { n++; return c; } };
+  // Exact for data, header and alphabet; the Elias-Fano samples are estimated from their parameters
+  // (2 + log2(n / m) bits per block), serializing them only to count bytes would take seconds.
+  size_type blocks = fmi.bwt.blocks();
+  size_type total = 24 + 8 + fmi.bwt.data.blocks() * BlockArray::BLOCK_SIZE + 256 + 6 + 7 * 8 + 8 + 3 * 8;
+  for(size_type c = 0; c <= BWT::SIGMA; c++)
+  {
+    size_type universe = (c < BWT::SIGMA ? fmi.bwt.count((comp_type)c) + blocks : fmi.size());
+    size_type per = 2 + (blocks > 0 && universe > blocks ? bit_length(universe / blocks) : 1);
+    total += blocks * per / 8 + 64;
+  }
+  return total;
+}
+
+} // namespace bwtmerge
+
+#endif // BWTM_HOST_FMI_H

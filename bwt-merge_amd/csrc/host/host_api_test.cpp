@@ -1,0 +1,130 @@
+/*
+  host_api_test -- exercises the C++ facade (FMI / BWT / RankArray / RunBuffer / formats) on the GPU.
+  Usage: host_api_test a.plain b.plain expected_data.bin workdir
+  `expected_data.bin` holds the native data bytes the oracle computed for merge(a, b).
+  Exit code 0 = every check passed.
+*/
+#include <cstdio>
+#include <thread>
+#include "fmi.h"
+
+using namespace bwtmerge;
+size_type Parallel::max_threads = 4;
+
+static int failures = 0;
+#define CHECK(cond) do { if(!(cond)) { std::fprintf(stderr, "CHECK failed: %s (%s:%d)\n", #cond, __FILE__, __LINE__); failures++; } } while(0)
+
+static std::vector<byte_type> readFile(const std::string& name)
+{
+  std::ifstream in(name.c_str(), std::ios_base::binary);
+  return std::vector<byte_type>((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+}
+
+static std::vector<byte_type> symbolsOf(const FMI& fmi)
+{
+  std::vector<byte_type> out; fmi.bwt.extract(range_type(0, fmi.size() - 1), out); return out;
+}
+
+int main(int argc, char** argv)
+{
+  if(argc < 5) { std::fprintf(stderr, "usage: host_api_test a.plain b.plain expected_data.bin workdir\n"); return 2; }
+  std::string work = argv[4];
+  gpuCheck(bwtm_init(0), "host_api_test");
+
+  // RunBuffer contract (utils.h:110-142 of the reference).
+  {
+    RunBuffer rb; std::vector<range_type> runs;
+    size_type values[] = {0, 0, 3, 3, 3, 1, 3};
+    for(size_type v : values) { if(rb.add(v)) { runs.push_back(rb.run); } }
+    rb.flush(); runs.push_back(rb.run);
+    CHECK(runs.size() == 4 && runs[0] == range_type(0, 2) && runs[1] == range_type(3, 3) && runs[2] == range_type(1, 1) && runs[3] == range_type(3, 1));
+  }
+
+  FMI a, b;
+  load(a, argv[1], "plain_default"); load(b, argv[2], "plain_default");
+  FMI a2 = a, b2 = b;
+  std::vector<byte_type> sa = symbolsOf(a), sb = symbolsOf(b);
+  size_type na = a.size(), nb = b.size();
+
+  // Scalar queries against a plain scan.
+  {
+    size_type seen[6] = {};
+    for(size_type i = 0; i <= na; i++)
+    {
+      if(i % 37 == 0 || i == na)
+      {
+        for(comp_type c = 0; c < 6; c++) { CHECK(a.bwt.rank(i, c) == seen[c]); }
+        BWT::ranks_type r; a.bwt.ranks(i, r);
+        for(size_type c = 1; c < 6; c++) { CHECK(r[c] == seen[c]); }
+        if(i < na)
+        {
+          CHECK(a.bwt[i] == sa[i]);
+          range_type is = a.bwt.inverse_select(i);
+          CHECK(is.second == sa[i] && is.first == seen[sa[i]]);
+          CHECK(a.LF(i).first == a.alpha.C[sa[i]] + seen[sa[i]]);
+          if(seen[sa[i]] + 1 <= a.bwt.count(sa[i])) { CHECK(a.bwt.select(seen[sa[i]] + 1, sa[i]) == i); }
+        }
+      }
+      if(i < na) { seen[sa[i]]++; }
+    }
+    std::vector<size_type> counts; a.bwt.characterCounts(counts);
+    for(size_type c = 0; c < 6; c++) { CHECK(counts[c] == seen[c]); CHECK(a.alpha.C[c + 1] - a.alpha.C[c] == seen[c]); }
+    size_type h = FNV_OFFSET_BASIS; for(byte_type s : sa) { h = fnv1a_hash(s, h); }
+    CHECK(a.bwt.hash() == h);
+  }
+
+  // Pattern counts before the merge (what bwt_merge -v compares).
+  std::vector<std::string> patterns = {"A", "ACG", "GATTACA", "TTTT", "N", "CGCG", ""};
+  std::vector<size_type> before;
+  for(const std::string& p : patterns)
+  {
+    range_type ra = a.find(p), rb = b.find(p);
+    before.push_back((Range::empty(ra) ? 0 : Range::length(ra)) + (Range::empty(rb) ? 0 : Range::length(rb)));
+  }
+
+  // The merging constructor == FMI::FMI(a, b, parameters).
+  FMI merged(a, b, MergeParameters());
+  CHECK(a.bwt.bytes() == 0 && b.bwt.bytes() == 0);                      // inputs are consumed
+  CHECK(merged.size() == na + nb);
+  std::vector<byte_type> expected = readFile(argv[3]);
+  CHECK(merged.bwt.data.bytes == expected);
+  for(size_type k = 0; k < patterns.size(); k++)
+  {
+    range_type r = merged.find(patterns[k]);
+    CHECK((Range::empty(r) ? 0 : Range::length(r)) == before[k]);
+  }
+  {
+    FMI rebuilt; rebuilt.bwt.data = merged.bwt.data; rebuilt.bwt.buildFromData();
+    CHECK(rebuilt.bwt.block_end == merged.bwt.block_end);
+    for(size_type c = 0; c < 6; c++) { CHECK(rebuilt.bwt.cumulative[c] == merged.bwt.cumulative[c]); }
+    CHECK(rebuilt.bwt.header.sequences == merged.sequences() && rebuilt.bwt.header.bases == merged.size());
+  }
+
+  // The two-step API: buildRA over several sequence blocks + BWT(a, b, ra).
+  {
+    MergeParameters p; p.setSB(5);
+    RankArray ra; buildRA(a2, b2, p, ra);
+    BWT interleaved(a2.bwt, b2.bwt, ra);
+    CHECK(interleaved.data.bytes == expected);
+  }
+
+  // Native file round trip.
+  {
+    std::string name = work + "/merged.native";
+    serialize(merged, name, "native");
+    FMI back; load(back, name, "native");
+    CHECK(back.bwt.data.bytes == merged.bwt.data.bytes);
+    CHECK(back.bwt.block_end == merged.bwt.block_end);
+    for(size_type c = 0; c < 6; c++) { CHECK(back.bwt.cumulative[c] == merged.bwt.cumulative[c]); }
+    CHECK(back.alpha == merged.alpha && back.alpha.C == merged.alpha.C);
+    CHECK(back.bwt.header.sequences == merged.sequences() && back.bwt.header.bases == merged.size() && back.bwt.header.check());
+    CHECK(back.bwt.hash() == merged.bwt.hash());
+    std::vector<byte_type> raw = readFile(name);
+    CHECK(raw.size() >= 24 + 8 + BlockArray::BLOCK_SIZE);               // whole 8 MiB blocks (reference support.cpp:302-306)
+    std::uint32_t tag; std::memcpy(&tag, raw.data(), 4); CHECK(tag == 0x54574221);
+  }
+
+  if(failures == 0) { std::printf("host_api_test: all checks passed\n"); return 0; }
+  std::fprintf(stderr, "host_api_test: %d checks failed\n", failures);
+  return 1;
+}

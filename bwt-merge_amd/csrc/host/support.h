@@ -1,0 +1,136 @@
+/*
+  support.h -- host facade: Alphabet, BlockArray, ByteCode, Run (reference support.h:41-286).
+  The RA buffer hierarchy of the reference (RLArray, RankArray over temp files) has no
+  counterpart here: the rank array lives on the device (fmi.h, RankArray below wraps the handle).
+*/
+#ifndef BWTM_HOST_SUPPORT_H
+#define BWTM_HOST_SUPPORT_H
+
+#include <cstring>
+#include "utils.h"
+
+namespace bwtmerge
+{
+
+// char <-> comp maps and the C array.  Default order $ACGTN = 0..5; every other byte maps to N.
+class Alphabet
+{
+public:
+  const static size_type MAX_SIGMA = 256;
+
+  Alphabet() : char2comp(MAX_SIGMA, 5), comp2char({'$', 'A', 'C', 'G', 'T', 'N'}), C(7, 0), sigma(6)
+  {
+    char2comp[0] = 0; char2comp['$'] = 0;
+    const char* upper = "ACGT"; const char* lower = "acgt";
+    for(size_type k = 0; k < 4; k++) { char2comp[(byte_type)upper[k]] = k + 1; char2comp[(byte_type)lower[k]] = k + 1; }
+  }
+
+  // counts[c] = occurrences of comp value c
+  explicit Alphabet(const std::vector<size_type>& counts) : Alphabet()
+  {
+    for(size_type c = 0; c < counts.size() && c < sigma; c++) { C[c + 1] = C[c] + counts[c]; }
+  }
+
+  bool sorted() const
+  {
+    for(size_type c = 1; c < sigma; c++) { if(comp2char[c - 1] >= comp2char[c]) { return false; } }
+    return true;
+  }
+
+  // Equality ignores C (reference support.cpp:192-205).
+  bool operator==(const Alphabet& another) const
+  {
+    return sigma == another.sigma && char2comp == another.char2comp && comp2char == another.comp2char;
+  }
+  bool operator!=(const Alphabet& another) const { return !(*this == another); }
+
+  std::vector<byte_type> char2comp, comp2char;
+  std::vector<size_type> C;
+  size_type              sigma;
+};
+
+// Byte array of the BWT.  The reference keeps 8 MiB mmap blocks (support.h:90-150); here the
+// bytes are contiguous (they are uploaded in one piece), and only serialization pads to blocks.
+class BlockArray
+{
+public:
+  typedef byte_type value_type;
+  const static size_type BLOCK_SIZE = 8 * MEGABYTE;
+
+  size_type size() const { return bytes.size(); }
+  bool empty() const { return bytes.empty(); }
+  size_type blocks() const { return (bytes.size() + BLOCK_SIZE - 1) / BLOCK_SIZE; }
+  void clear() { bytes.clear(); bytes.shrink_to_fit(); }
+  value_type operator[](size_type i) const { return bytes[i]; }
+  value_type& operator[](size_type i) { return bytes[i]; }
+  void push_back(value_type v) { bytes.push_back(v); }
+  void swap(BlockArray& other) { bytes.swap(other.bytes); }
+  const value_type* data() const { return bytes.data(); }
+
+  std::vector<value_type> bytes;
+};
+
+// 7 data bits per byte, least significant group first, high bit = "continues".
+struct ByteCode
+{
+  template<class ByteArray>
+  static size_type read(const ByteArray& array, size_type& i)
+  {
+    size_type shift = 0, value = array[i] & 0x7F;
+    while(array[i] & 0x80) { i++; shift += 7; value += ((size_type)(array[i] & 0x7F)) << shift; }
+    i++;
+    return value;
+  }
+
+  template<class ByteArray>
+  static void write(ByteArray& array, size_type value)
+  {
+    for(; value > 0x7F; value >>= 7) { array.push_back((byte_type)((value & 0x7F) | 0x80)); }
+    array.push_back((byte_type)value);
+  }
+};
+
+// A BWT run: one byte comp + 6 * (length - 1) for length < 42; otherwise that byte with
+// length 42 followed by the varint of the rest.  No run crosses a 64-byte boundary.
+struct Run
+{
+  const static size_type BLOCK_SIZE = 64;
+  const static size_type SIGMA      = 6;
+  const static size_type MAX_RUN    = 256 / SIGMA;
+
+  static byte_type encodeBasic(comp_type comp, size_type length) { return (byte_type)(comp + SIGMA * (length - 1)); }
+  static range_type decodeBasic(byte_type code) { return range_type(code % SIGMA, code / SIGMA + 1); }
+
+  template<class ByteArray>
+  static range_type read(const ByteArray& array, size_type& i)
+  {
+    range_type run = decodeBasic(array[i]); i++;
+    if(run.second >= MAX_RUN) { run.second += ByteCode::read(array, i); }
+    return run;
+  }
+
+  template<class ByteArray>
+  static void write(ByteArray& array, comp_type comp, size_type length)
+  {
+    while(length > 0)
+    {
+      if(length < MAX_RUN) { array.push_back(encodeBasic(comp, length)); return; }
+      size_type room = BLOCK_SIZE - (array.size() % BLOCK_SIZE);       // bytes left in the block, >= 1
+      size_type head = (room > 1 ? MAX_RUN : MAX_RUN - 1);               // a lone last byte cannot announce an extension
+      array.push_back(encodeBasic(comp, head)); length -= head; room--;
+      if(room > 0)
+      {
+        size_type extension = length;
+        if(bit_length(length) > 7 * room) { extension = (~(size_type)0) >> (64 - 7 * room); }
+        ByteCode::write(array, extension); length -= extension;
+      }
+    }
+  }
+
+  template<class ByteArray>
+  static void write(ByteArray& array, range_type run) { write(array, (comp_type)run.first, run.second); }
+};
+
+} // namespace bwtmerge
+
+#endif // BWTM_HOST_SUPPORT_H
