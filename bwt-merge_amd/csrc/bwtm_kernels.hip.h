@@ -855,6 +855,76 @@ __global__ void __launch_bounds__(PART_THREADS) k_part_scatter(const u32* l1, u6
   }
 }
 
+// Level 2, pass c, product form: LDS counting sort of 16 384-entry chunks, so that entries of
+// the same tile leave the workgroup as contiguous runs (a wave store touches ~3 lines instead
+// of 64).  Dynamic LDS: sorted[SORT_CHUNK] u32, hist[nsub] u32, offs[nsub] u32, cursor[nsub] u64.
+constexpr int SORT_CHUNK = 16384;
+constexpr int SORT_PER_THREAD = SORT_CHUNK / PART_THREADS;      // 16
+
+__global__ void __launch_bounds__(PART_THREADS) k_part_scatter_sorted(const u32* l1, u64 cap, const u64* gcount, const u32* slice_bin,
+  const u64* slice_begin, u32 nsub, const u32* counts, const u64* tile_start, unsigned short* out)
+{
+  extern __shared__ u64 lds_raw[];
+  u64* cursor = lds_raw;                                   // [nsub]
+  u32* sorted = (u32*)(cursor + nsub);                     // [SORT_CHUNK]
+  u32* hist = sorted + SORT_CHUNK;                         // [nsub]
+  u32* offs = hist + nsub;                                 // [nsub + 1]
+  __shared__ u32 wave_total[PART_THREADS / WAVE];
+
+  const u32 b = slice_bin[blockIdx.x];
+  for(u32 k = threadIdx.x; k < nsub; k += PART_THREADS)
+  {
+    cursor[k] = tile_start[(u64)k * L1_BINS + b] + counts[(u64)blockIdx.x * nsub + k];
+  }
+  u64 begin = slice_begin[blockIdx.x];
+  u64 end = begin + PART_SLICE; u64 total = gcount[b]; if(total > cap) { total = cap; } if(end > total) { end = total; }
+  const u32* src = l1 + (u64)b * cap;
+
+  for(u64 chunk = begin; chunk < end; chunk += SORT_CHUNK)
+  {
+    for(u32 k = threadIdx.x; k < nsub; k += PART_THREADS) { hist[k] = 0; }
+    __syncthreads();
+    u32 e[SORT_PER_THREAD], rank[SORT_PER_THREAD];
+#pragma unroll
+    for(int k = 0; k < SORT_PER_THREAD; k++)
+    {
+      u64 idx = chunk + (u64)k * PART_THREADS + threadIdx.x;
+      e[k] = (idx < end ? src[idx] : L1_SENTINEL);
+      rank[k] = (e[k] != L1_SENTINEL ? atomicAdd(&hist[e[k] >> TILE_SHIFT], 1u) : 0u);
+    }
+    __syncthreads();
+    // exclusive scan of hist -> offs (each thread owns a contiguous strip of sub-bins)
+    const u32 strip = (nsub + PART_THREADS - 1) / PART_THREADS;
+    u32 s0 = threadIdx.x * strip, s1 = s0 + strip; if(s1 > nsub) { s1 = nsub; } if(s0 > nsub) { s0 = nsub; }
+    u32 mine = 0;
+    for(u32 k = s0; k < s1; k++) { mine += hist[k]; }
+    u64 incl = wave_incl_sum(mine);
+    if(lane_id() == WAVE - 1) { wave_total[threadIdx.x >> 6] = (u32)incl; }
+    __syncthreads();
+    u32 base = 0;
+    for(u32 w = 0; w < (threadIdx.x >> 6); w++) { base += wave_total[w]; }
+    u32 run = base + (u32)incl - mine;
+    for(u32 k = s0; k < s1; k++) { offs[k] = run; run += hist[k]; }
+    if(threadIdx.x == PART_THREADS - 1) { offs[nsub] = run; }
+    __syncthreads();
+#pragma unroll
+    for(int k = 0; k < SORT_PER_THREAD; k++)
+    {
+      if(e[k] != L1_SENTINEL) { sorted[offs[e[k] >> TILE_SHIFT] + rank[k]] = e[k]; }
+    }
+    __syncthreads();
+    const u32 valid = offs[nsub];
+    for(u32 p = threadIdx.x; p < valid; p += PART_THREADS)
+    {
+      u32 v = sorted[p]; u32 sub = v >> TILE_SHIFT;
+      out[cursor[sub] + (p - offs[sub])] = (unsigned short)(v & TILE_MASK);
+    }
+    __syncthreads();
+    for(u32 k = threadIdx.x; k < nsub; k += PART_THREADS) { cursor[k] += hist[k]; }
+    __syncthreads();
+  }
+}
+
 // Tiles: set the bits of one 65 536-bit tile in LDS, then OR the 8 KiB into the bitvector.
 __global__ void __launch_bounds__(BLOCK_THREADS) k_tile_build(const unsigned short* lists, const u64* tile_start, u64 ntiles, u64* bits, u64 nwords)
 {
