@@ -270,7 +270,7 @@ int transcode(bwtm_index* x)
   LAUNCH("build_sup", k_build_sup, div_up(x->nsup, BLOCK_THREADS), BLOCK_THREADS,
     x->data.as<const u8>(), x->nbytes, x->block_start.as<const u64>(), x->cum.as<const u64>(), stride, x->nblocks, x->n,
     x->sup.as<u64>(), x->nsup);
-  LAUNCH("build_recs", k_build_recs, div_up(x->nrecs, BLOCK_THREADS), BLOCK_THREADS,
+  LAUNCH("build_recs", k_build_recs, div_up(x->nrecs, BLOCK_THREADS), BLOCK_THREADS,   // one wave per 64 records
     x->data.as<const u8>(), x->nbytes, x->block_start.as<const u64>(), x->cum.as<const u64>(), stride, x->nblocks, x->n,
     x->sup.as<const u64>(), x->recs.as<uint4>(), x->nrecs);
   return BWTM_OK;

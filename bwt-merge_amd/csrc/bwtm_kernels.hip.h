@@ -196,19 +196,53 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_scan_apply(const u64* in, u64
 // K0a / K5: per native 64-byte block, the number of occurrences of every symbol
 // (BWT::build, bwt.cpp:487-502).  One lane per block.  cnt is SoA: cnt[c * stride + b].
 
+// Each wave stages its 64 blocks (4 KiB) in LDS with coalesced 16-byte loads, then every lane
+// decodes its own block from LDS (row stride 17 words: conflict-free for 32-bit reads).
+constexpr int STAGE_WORDS = 17;
+
 __global__ void __launch_bounds__(BLOCK_THREADS) k_block_stats(const u8* data, u64 nbytes, u64 nblocks, u64* cnt, u64 stride)
 {
-  u64 b = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
-  if(b >= nblocks) { return; }
-  u64 pos = b * RLE_BLOCK;
-  u64 end = pos + RLE_BLOCK; if(end > nbytes) { end = nbytes; }
-  u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
-  while(pos < end)
+  __shared__ u32 stage[(BLOCK_THREADS / WAVE) * 64 * STAGE_WORDS];
+  const u32 lane = lane_id(), wave = threadIdx.x >> 6;
+  u32* rows = stage + wave * 64 * STAGE_WORDS;
+  const u64 first = ((u64)blockIdx.x * BLOCK_THREADS + (u64)wave * WAVE);      // first block of this wave
+  if(first >= nblocks) { return; }
+  // 64 blocks = 256 chunks of 16 bytes; lane handles chunks lane, lane + 64, ...
+  const uint4* src = (const uint4*)(data + first * RLE_BLOCK);
+  const u64 chunks_avail = (nbytes + 15 - first * RLE_BLOCK) / 16;              // the buffer is padded by 16 zero bytes
+#pragma unroll
+  for(int k = 0; k < 4; k++)
   {
-    u32 sym; u64 len;
-    run_decode(data, pos, sym, len);
-    c0 += (sym == 0 ? len : 0); c1 += (sym == 1 ? len : 0); c2 += (sym == 2 ? len : 0);
-    c3 += (sym == 3 ? len : 0); c4 += (sym == 4 ? len : 0); c5 += (sym == 5 ? len : 0);
+    u32 g = (u32)k * 64 + lane;
+    uint4 v = (g < chunks_avail ? src[g] : make_uint4(0, 0, 0, 0));
+    u32* dst = rows + (g >> 2) * STAGE_WORDS + (g & 3) * 4;
+    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const u64 b = first + lane;
+  if(b >= nblocks) { return; }
+  u64 begin = b * RLE_BLOCK;
+  u32 valid = (nbytes - begin >= RLE_BLOCK ? (u32)RLE_BLOCK : (u32)(nbytes - begin));
+  const u32* row = rows + lane * STAGE_WORDS;
+  u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+  u32 sym = 0, shift = 0; u64 len = 0; bool cont = false;
+#pragma unroll 1
+  for(int w = 0; w < 16; w++)
+  {
+    u32 word = row[w];
+#pragma unroll
+    for(int k = 0; k < 4; k++)
+    {
+      u32 byte = (word >> (8 * k)) & 0xFF;
+      bool active = ((u32)(4 * w + k) < valid);
+      bool done;
+      if(!cont) { sym = byte % 6; len = byte / 6 + 1; shift = 0; cont = (len >= MAX_RUN); done = !cont; }
+      else { len += (u64)(byte & 0x7F) << shift; shift += 7; cont = (byte & 0x80) != 0; done = !cont; }
+      if(!active) { done = false; cont = false; }
+      u64 add = (done ? len : 0);
+      c0 += (sym == 0 ? add : 0); c1 += (sym == 1 ? add : 0); c2 += (sym == 2 ? add : 0);
+      c3 += (sym == 3 ? add : 0); c4 += (sym == 4 ? add : 0); c5 += (sym == 5 ? add : 0);
+    }
   }
   cnt[0 * stride + b] = c0; cnt[1 * stride + b] = c1; cnt[2 * stride + b] = c2;
   cnt[3 * stride + b] = c3; cnt[4 * stride + b] = c4; cnt[5 * stride + b] = c5;
@@ -284,32 +318,65 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_build_sup(const u8* data, u64
   for(int c = 0; c < SUP_STRIDE; c++) { sup[s * SUP_STRIDE + c] = (c >= 1 && c < 6 ? abs[c] : 0); }
 }
 
-// K0c: records from the native stream.  One lane per record.
+// K0c: records from the native stream.  One wave per 64 consecutive records (8192 positions):
+// one binary search per wave finds the first block, the <= 132 blocks that can cover the span
+// (a full block holds >= 64 positions) and their start positions are staged in LDS with
+// coalesced loads, and every lane decodes its record from LDS.
+constexpr int BR_BLOCKS = 132;
+
 __global__ void __launch_bounds__(BLOCK_THREADS) k_build_recs(const u8* data, u64 nbytes, const u64* block_start,
   const u64* cum, u64 stride, u64 nblocks, u64 n, const u64* sup, uint4* recs, u64 nrecs)
 {
-  u64 q = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  __shared__ uint4 staged[BLOCK_THREADS / WAVE][BR_BLOCKS * 4];
+  __shared__ u64 starts[BLOCK_THREADS / WAVE][BR_BLOCKS + 1];
+  const u32 lane = lane_id(), wave = threadIdx.x >> 6;
+  const u64 q0 = ((u64)blockIdx.x * (BLOCK_THREADS / WAVE) + wave) * WAVE;
+  if(q0 >= nrecs) { return; }
+  const u64 p0 = q0 << REC_SHIFT;
+  const u64 b0 = (p0 >= n ? nblocks : find_block(block_start, nblocks, p0));      // wave-uniform
+  u32 nb = (nblocks - b0 > (u64)BR_BLOCKS ? (u32)BR_BLOCKS : (u32)(nblocks - b0));
+  const uint4* src = (const uint4*)(data + b0 * RLE_BLOCK);
+  const u64 chunks_avail = (b0 * RLE_BLOCK <= nbytes ? (nbytes + 15 - b0 * RLE_BLOCK) / 16 : 0);
+  for(u32 g = lane; g < nb * 4; g += WAVE) { staged[wave][g] = (g < chunks_avail ? src[g] : make_uint4(0, 0, 0, 0)); }
+  for(u32 k = lane; k <= nb; k += WAVE) { starts[wave][k] = block_start[b0 + k]; }
+  __builtin_amdgcn_wave_barrier();
+
+  const u64 q = q0 + lane;
   if(q >= nrecs) { return; }
-  u64 p = q << REC_SHIFT;
+  const u64 p = q << REC_SHIFT;
   u64 abs[6] = {0, 0, 0, 0, 0, 0};
   u64 lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0, lo2 = 0, hi2 = 0;
   if(p >= n) { for(int c = 1; c < 6; c++) { abs[c] = cum[c * stride + nblocks]; } }
   else
   {
-    RunCursor cur;
-    seek_native(data, nbytes, block_start, cum, stride, nblocks, p, cur, abs);
+    const u64* st = starts[wave];
+    u32 lo = 0, hi = nb;                          // st[lo] <= p < st[hi]
+    while(hi - lo > 1) { u32 mid = (lo + hi) >> 1; if(st[mid] <= p) { lo = mid; } else { hi = mid; } }
+    for(int c = 1; c < 6; c++) { abs[c] = cum[c * stride + b0 + lo]; }
+    const u8* bytes = (const u8*)staged[wave];
+    u64 rle = (u64)lo * RLE_BLOCK, pos = st[lo];
+    u32 sym = 0; u64 left = 0;
+    while(true)                                   // skip to p inside the block
+    {
+      u64 len; run_decode(bytes, rle, sym, len);
+      u64 take = (pos + len > p ? p - pos : len);
+      abs[1] += (sym == 1 ? take : 0); abs[2] += (sym == 2 ? take : 0); abs[3] += (sym == 3 ? take : 0);
+      abs[4] += (sym == 4 ? take : 0); abs[5] += (sym == 5 ? take : 0);
+      if(pos + len > p) { left = len - take; break; }
+      pos += len;
+    }
     u32 t = 0;
-    u64 avail = n - p;                      // positions that exist from p on
+    u64 avail = n - p;
     u32 limit = (avail >= REC_POS ? (u32)REC_POS : (u32)avail);
     while(t < limit)
     {
-      if(cur.left == 0) { run_decode(cur.data, cur.rle, cur.sym, cur.left); }
-      u32 take = (cur.left > (u64)(limit - t) ? limit - t : (u32)cur.left);
+      if(left == 0) { run_decode(bytes, rle, sym, left); }
+      u32 take = (left > (u64)(limit - t) ? limit - t : (u32)left);
       u64 ml, mh; range_mask128(t, take, ml, mh);
-      if(cur.sym & 1) { lo0 |= ml; hi0 |= mh; }
-      if(cur.sym & 2) { lo1 |= ml; hi1 |= mh; }
-      if(cur.sym & 4) { lo2 |= ml; hi2 |= mh; }
-      t += take; cur.left -= take;
+      if(sym & 1) { lo0 |= ml; hi0 |= mh; }
+      if(sym & 2) { lo1 |= ml; hi1 |= mh; }
+      if(sym & 4) { lo2 |= ml; hi2 |= mh; }
+      t += take; left -= take;
     }
   }
   const u64* s = sup + (p >> SUPER_SHIFT) * SUP_STRIDE;
@@ -1278,6 +1345,7 @@ __global__ void __launch_bounds__(WAVE) k_fold_seg(const u32* table, u64 nseg, c
 __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 nseg,
   const u64* prevhead, const u64* seg_base, u8* out)
 {
+  __shared__ __attribute__((aligned(16))) u8 stage[BLOCK_THREADS / WAVE][4096 + 32];
   u64 seg = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
   if(seg >= nseg) { return; }
   u64 first = seg * SEG_TILES;
@@ -1304,8 +1372,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
     bool slow = (__ballot(nlong > 0) != 0);
     if(!slow)
     {
-      // Every event is a run shorter than 42: one byte each, in position order.
-      u8* dst = out + off + (ev_incl - nev);
+      // Every event is a run shorter than 42: one byte each, in position order.  The bytes are
+      // staged in LDS at the same 16-byte phase as their destination and leave as 16-byte stores.
+      u8* lds = stage[threadIdx.x >> 6];
+      const u32 a = (u32)(off & 15);
+      u32 idx = a + (u32)(ev_incl - nev);
       u64 h = ti.H, cur = before, tb = T << 6;
       while(h)
       {
@@ -1314,10 +1385,24 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
         if(pos > 0)
         {
           u64 len = pos + 1 - cur;
-          *dst++ = (u8)(event_symbol(ti, b) + 6 * (len - 1));     // Run::encodeBasic, support.h:231-234
+          lds[idx++] = (u8)(event_symbol(ti, b) + 6 * (len - 1));     // Run::encodeBasic, support.h:231-234
         }
         cur = pos + 1;
       }
+      __builtin_amdgcn_wave_barrier();
+      const u32 total = a + (u32)chunk_events;
+      u8* base = out + (off - a);                                      // 16-byte aligned
+      for(u32 j = lane_id(); j * 16 < total; j += WAVE)
+      {
+        u32 lo = 16 * j, hi = lo + 16;
+        if(lo >= a && hi <= total) { *(uint4*)(base + lo) = *(const uint4*)(lds + lo); }
+        else
+        {
+          u32 from = (lo > a ? lo : a), to = (hi < total ? hi : total);
+          for(u32 t = from; t < to; t++) { base[t] = lds[t]; }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
       off += chunk_events;
     }
     else
