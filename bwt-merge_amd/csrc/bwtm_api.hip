@@ -54,6 +54,7 @@ struct Tuning
   long long walk_blocks = 0;     // grid size override for k_lf_walk (0 = default)
   long long walk_kernel = 0;     // 0 = four lanes per chain (product), 1 = one lane per chain (first version, kept for A/B)
   long long walk_ablate = 0;     // timing-only ablations of the no-emit quad kernel (tools/walk_experiments.py)
+  long long walk_variant = 0;    // 0 = four lanes per chain, four pipelined chains per quad (product); 1 = LDS-transposed one chain per lane
   long long scatter_kernel = 0;  // 0 = LDS counting sort (product), 1 = direct scattered stores (first version)
   long long emit_path = 0;       // 0 = partitioned emit (product), 1 = atomicOr on the bitvector (first version, also the fallback)
   long long round_emits = 1ll << 33;   // upper bound of emits partitioned per round (bounds the temporary regions)
@@ -319,6 +320,8 @@ extern "C" int bwtm_init(int device)
   // Kernels that take more than the default 64 KiB of dynamic LDS.
   HIP_TRY(hipFuncSetAttribute((const void*)k_part_scatter_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void*)k_lf_walk_binned<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_lf_walk_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 122 * 1024));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_lf_walk_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 82 * 1024));
   return BWTM_OK;
 }
 
@@ -334,6 +337,7 @@ extern "C" int bwtm_tune(const char* key, long long value)
   else if(k == "emit_path") { g_tune.emit_path = value; }
   else if(k == "walk_ablate") { g_tune.walk_ablate = value; }
   else if(k == "scatter_kernel") { g_tune.scatter_kernel = value; }
+  else if(k == "walk_variant") { g_tune.walk_variant = value; }
   else if(k == "round_emits") { g_tune.round_emits = (value > 0 ? value : 1); }
   else { return fail(BWTM_EINVAL, "bwtm_tune: unknown key %s", key); }
   return BWTM_OK;
@@ -688,7 +692,22 @@ int search_partitioned(const bwtm_index* a, const bwtm_index* b, u64 seq_first, 
     TRY(overflow.alloc(64, true));
     EmitSink sink; sink.l1 = l1.as<u32>(); sink.cap = cap; sink.gcount = gcount.as<u64>(); sink.bits = ra->bits_as<u32>(); sink.overflow = overflow.as<u32>();
     const u64 sup_bytes = 5 * (a->nsup + b->nsup) * sizeof(u64);
-    if(sup_bytes <= 40 * 1024)
+    const u64 stage_bytes = (u64)(WL_THREADS / WAVE) * 64 * WL_ROW * sizeof(u32);
+    if(g_tune.walk_variant == 1 && a->nrecs < (1ull << 32) && b->nrecs < (1ull << 32))
+    {
+      // variant: coalesced loads + one chain per lane through an LDS transpose (measured slower, kept for A/B)
+      u64 wl_blocks = div_up(r_count, WL_THREADS); if(wl_blocks > 256) { wl_blocks = 256; }
+      if(g_tune.walk_blocks > 0 && wl_blocks > (u64)g_tune.walk_blocks) { wl_blocks = g_tune.walk_blocks; }
+      if(sup_bytes <= 40 * 1024)
+      {
+        LAUNCH_LDS("lf_walk_ldsT", k_lf_walk_lds<true>, wl_blocks, WL_THREADS, stage_bytes + sup_bytes, a->view(), b->view(), r_first, r_count, sink, (u32)a->nsup, (u32)b->nsup);
+      }
+      else
+      {
+        LAUNCH_LDS("lf_walk_ldsT", k_lf_walk_lds<false>, wl_blocks, WL_THREADS, stage_bytes, a->view(), b->view(), r_first, r_count, sink, (u32)a->nsup, (u32)b->nsup);
+      }
+    }
+    else if(sup_bytes <= 40 * 1024)
     {
       LAUNCH_LDS("lf_walk", k_lf_walk_binned<true>, blocks, WB_THREADS, sup_bytes, a->view(), b->view(), r_first, r_count, sink, (u32)a->nsup, (u32)b->nsup);
     }

@@ -669,11 +669,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_lf_walk_quad(IndexView A, Ind
 constexpr int WB_THREADS   = 512;
 constexpr int TILE_SHIFT   = 16;
 constexpr u32 TILE_MASK    = (1u << TILE_SHIFT) - 1;
-constexpr int L1_BITS      = 8;
+constexpr int L1_BITS      = 7;
 constexpr int L1_BINS      = 1 << L1_BITS;
-constexpr int L1_RING      = 32;
+constexpr int L1_RING      = 64;
 constexpr int L1_CHUNK     = 256;          // entries per chunk reservation (1 KiB)
-constexpr int L1_FLUSH_EVERY = 2;
+constexpr int L1_FLUSH_EVERY = 8;
 constexpr u32 L1_SENTINEL  = 0xFFFFFFFFu;
 constexpr int WALK_ILP     = 4;            // chains per quad
 
@@ -690,23 +690,25 @@ __device__ inline void sink_fallback(u32* bits, u64 p) { atomicOr(bits + (p >> 5
 
 __device__ inline void sink_append(u32* bits, u32* ring, u32* tail, const u32* head, u64 p)
 {
+  (void)head;                                   // the ring always starts at slot 0 (see sink_flush_bin)
   u64 tile = p >> TILE_SHIFT;
   u32 b = (u32)tile & (L1_BINS - 1);
   u32 entry = ((u32)(tile >> L1_BITS) << TILE_SHIFT) | ((u32)p & TILE_MASK);
   u32 slot = atomicAdd(&tail[b], 1u);
-  if(slot - head[b] < (u32)L1_RING) { ring[b * L1_RING + (slot & (L1_RING - 1))] = entry; }
+  if(slot < (u32)L1_RING) { ring[b * L1_RING + slot] = entry; }
   else { sink_fallback(bits, p); }
 }
 
 // Flushes full 16-entry blocks of bin b (one thread per bin, between barriers).
 __device__ __attribute__((noinline)) void sink_flush_bin(const EmitSink sink, u32* ring, u32* tail, u32* head, u64* chunk_pos, u32* chunk_left, u32 b, bool final)
 {
-  u32 h = head[b];
-  u32 real = tail[b] - h; if(real > (u32)L1_RING) { real = L1_RING; }     // slots past the ring took the fallback
+  (void)head;
+  u32 h = 0;
+  u32 real = tail[b]; if(real > (u32)L1_RING) { real = L1_RING; }     // slots past the ring took the fallback
   while(real >= 16 || (final && real > 0))
   {
     u32 n = (real >= 16 ? 16u : real);
-    uint4* src = (uint4*)(ring + b * L1_RING + (h & (L1_RING - 1)));
+    uint4* src = (uint4*)(ring + b * L1_RING + h);
     uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
     if(n < 16)
     {
@@ -746,9 +748,14 @@ __device__ __attribute__((noinline)) void sink_flush_bin(const EmitSink sink, u3
     uint4* dst = (uint4*)(sink.l1 + chunk_pos[b]);
     for(u32 k = 0; k < chunk_left[b] / 4; k++) { dst[k] = sv; }
     chunk_left[b] = 0;
-    head[b] = 0; tail[b] = 0;
+    tail[b] = 0;
   }
-  else { head[b] = h; tail[b] = h + real; }
+  else
+  {
+    // keep the < 16 left-over entries at the front of the ring
+    if(h != 0) { for(u32 k = 0; k < real; k++) { ring[b * L1_RING + k] = ring[b * L1_RING + h + k]; } }
+    tail[b] = real;
+  }
 }
 
 // LDS_SUP: both super tables are staged in dynamic LDS (5 u64 per super block: symbols 1..5),
@@ -756,23 +763,23 @@ __device__ __attribute__((noinline)) void sink_flush_bin(const EmitSink sink, u3
 template<bool LDS_SUP>
 __global__ void __launch_bounds__(WB_THREADS, 4) k_lf_walk_binned(IndexView A, IndexView B, u64 seq_first, u64 seq_count, EmitSink sink, u32 nsup_a, u32 nsup_b)
 {
-  extern __shared__ u64 sup_lds[];            // [5 * nsup_a] for A, then [5 * nsup_b] for B
-  if(LDS_SUP)
-  {
-    for(u32 k = threadIdx.x; k < 5 * nsup_a; k += WB_THREADS) { sup_lds[k] = A.sup[(k / 5) * SUP_STRIDE + 1 + (k % 5)]; }
-    for(u32 k = threadIdx.x; k < 5 * nsup_b; k += WB_THREADS) { sup_lds[5 * nsup_a + k] = B.sup[(k / 5) * SUP_STRIDE + 1 + (k % 5)]; }
-  }
-  const u64* lds_a = sup_lds; const u64* lds_b = sup_lds + 5 * nsup_a;
+  extern __shared__ u64 sup_lds[];            // LDS_SUP: [5 * nsup_a] for A, then [5 * nsup_b] for B, C already added
   __shared__ u64 sC[16];
   __shared__ u32 ring[L1_BINS * L1_RING];
-  __shared__ u32 tail[L1_BINS], head[L1_BINS], chunk_left[L1_BINS];
+  __shared__ u32 tail[L1_BINS], chunk_left[L1_BINS];
   __shared__ u64 chunk_pos[L1_BINS];
-  if(threadIdx.x < L1_BINS) { tail[threadIdx.x] = 0; head[threadIdx.x] = 0; chunk_left[threadIdx.x] = 0; chunk_pos[threadIdx.x] = 0; }
+  if(threadIdx.x < L1_BINS) { tail[threadIdx.x] = 0; chunk_left[threadIdx.x] = 0; chunk_pos[threadIdx.x] = 0; }
   if(threadIdx.x == 0)
   {
 #pragma unroll
     for(int k = 0; k < 8; k++) { sC[k] = A.C[k]; sC[8 + k] = B.C[k]; }
   }
+  if(LDS_SUP)
+  {
+    for(u32 k = threadIdx.x; k < 5 * nsup_a; k += WB_THREADS) { sup_lds[k] = A.sup[(k / 5) * SUP_STRIDE + 1 + (k % 5)] + A.C[1 + (k % 5)]; }
+    for(u32 k = threadIdx.x; k < 5 * nsup_b; k += WB_THREADS) { sup_lds[5 * nsup_a + k] = B.sup[(k / 5) * SUP_STRIDE + 1 + (k % 5)] + B.C[1 + (k % 5)]; }
+  }
+  const u64* lds_a = sup_lds; const u64* lds_b = sup_lds + 5 * nsup_a;
   __syncthreads();
 
   const u32 q = threadIdx.x & 3;
@@ -780,36 +787,21 @@ __global__ void __launch_bounds__(WB_THREADS, 4) k_lf_walk_binned(IndexView A, I
   u64 next = ((u64)blockIdx.x * WB_THREADS + threadIdx.x) >> 2;
   u64 i[WALK_ILP], r[WALK_ILP];
   bool walking[WALK_ILP];
+  uint4 cb[WALK_ILP], ca[WALK_ILP];
+  u64 sbq[WALK_ILP], saq[WALK_ILP];
 #pragma unroll
-  for(int s = 0; s < WALK_ILP; s++) { i[s] = 0; r[s] = 0; walking[s] = false; }
+  for(int s = 0; s < WALK_ILP; s++) { i[s] = 0; r[s] = 0; walking[s] = false; cb[s] = make_uint4(0, 0, 0, 0); ca[s] = cb[s]; sbq[s] = 0; saq[s] = 0; }
 
+  // The four chains of a quad are software-pipelined: a chain's next records are requested right
+  // after its step has been computed and are consumed one loop iteration later, i.e. behind the
+  // steps of the other three chains.
   for(u32 it = 0; ; it++)
   {
-    uint4 cb[WALK_ILP], ca[WALK_ILP];
-    u64 sbq[WALK_ILP], saq[WALK_ILP];
+    u64 pend = 0; bool have = false;          // lane q carries the emit of chain q
 #pragma unroll
     for(int s = 0; s < WALK_ILP; s++)
     {
-      if(!walking[s] && next < seq_count)
-      {
-        i[s] = seq_first + next; r[s] = A.m;                    // fmi.cpp:286: trie root "$"
-        next += stride; walking[s] = true;
-        if(q == 0) { sink_append(sink.bits, ring, tail, head, i[s] + r[s]); }
-      }
-      if(walking[s])
-      {
-        cb[s] = B.recs[4 * (i[s] >> REC_SHIFT) + q];
-        ca[s] = A.recs[4 * (r[s] >> REC_SHIFT) + q];
-        if(!LDS_SUP)
-        {
-          sbq[s] = B.sup[(i[s] >> SUPER_SHIFT) * SUP_STRIDE + 1 + q];
-          saq[s] = A.sup[(r[s] >> SUPER_SHIFT) * SUP_STRIDE + 1 + q];
-        }
-      }
-    }
-#pragma unroll
-    for(int s = 0; s < WALK_ILP; s++)
-    {
+      u64 emit = 0; bool emitted = false;
       if(walking[s])
       {
         const u32 jb = (u32)(i[s] & (REC_POS - 1)), ja = (u32)(r[s] & (REC_POS - 1));
@@ -825,31 +817,161 @@ __global__ void __launch_bounds__(WB_THREADS, 4) k_lf_walk_binned(IndexView A, I
           {
             if(q == 0)
             {
-              pb += lds_b[5 * (u32)(i[s] >> SUPER_SHIFT) + (c - 1)];
-              pa += lds_a[5 * (u32)(r[s] >> SUPER_SHIFT) + (c - 1)];
+              pb += lds_b[5 * (u32)(i[s] >> SUPER_SHIFT) + (c - 1)];   // includes C_B[c]
+              pa += lds_a[5 * (u32)(r[s] >> SUPER_SHIFT) + (c - 1)];   // includes C_A[c]
             }
           }
           else
           {
             pb += (c == q + 1 ? sbq[s] : 0); pa += (c == q + 1 ? saq[s] : 0);
-            if(c == 5 && q == 0)            // 'N' is rare: its super entries are fetched on demand
+            if(q == 0)
             {
-              pb += B.sup[(i[s] >> SUPER_SHIFT) * SUP_STRIDE + 5];
-              pa += A.sup[(r[s] >> SUPER_SHIFT) * SUP_STRIDE + 5];
+              pb += sC[8 + c]; pa += sC[c];
+              if(c == 5) { pb += B.sup[(i[s] >> SUPER_SHIFT) * SUP_STRIDE + 5]; pa += A.sup[(r[s] >> SUPER_SHIFT) * SUP_STRIDE + 5]; }
             }
           }
-          i[s] = sC[8 + c] + quad_sum_u64(pb);                      // LF_B(i), utils.h:335-341
-          r[s] = sC[c] + quad_sum_u64(pa);                          // LF_A(r, c), utils.h:343-348
-          if(q == 0) { sink_append(sink.bits, ring, tail, head, i[s] + r[s]); }
+          i[s] = quad_sum_u64(pb);                                  // LF_B(i), utils.h:335-341
+          r[s] = quad_sum_u64(pa);                                  // LF_A(r, c), utils.h:343-348
+          emit = i[s] + r[s]; emitted = true;
         }
       }
+      if(!walking[s] && next < seq_count)
+      {
+        i[s] = seq_first + next; r[s] = A.m;                        // fmi.cpp:286: trie root "$"
+        next += stride; walking[s] = true;
+        emit = i[s] + r[s]; emitted = true;
+      }
+      if(walking[s])
+      {
+        cb[s] = B.recs[4 * (i[s] >> REC_SHIFT) + q];
+        ca[s] = A.recs[4 * (r[s] >> REC_SHIFT) + q];
+        if(!LDS_SUP)
+        {
+          sbq[s] = B.sup[(i[s] >> SUPER_SHIFT) * SUP_STRIDE + 1 + q];
+          saq[s] = A.sup[(r[s] >> SUPER_SHIFT) * SUP_STRIDE + 1 + q];
+        }
+      }
+      if((u32)s == q) { pend = emit; have = emitted; }
     }
+    if(have) { sink_append(sink.bits, ring, tail, nullptr, pend); }
     if((it & (L1_FLUSH_EVERY - 1)) == L1_FLUSH_EVERY - 1)
     {
       bool busy = (next < seq_count);
 #pragma unroll
       for(int s = 0; s < WALK_ILP; s++) { busy = busy || walking[s]; }
       int any = __syncthreads_or(busy ? 1 : 0);
+      if(threadIdx.x < L1_BINS) { sink_flush_bin(sink, ring, tail, nullptr, chunk_pos, chunk_left, threadIdx.x, !any); }
+      __syncthreads();
+      if(!any) { break; }
+    }
+  }
+}
+
+// K1, product form 3: COALESCED LOADS, ONE CHAIN PER LANE.
+// The quad kernel above makes every lane of a quad repeat the chain arithmetic (9.6 wave
+// instructions per LF step against 2.8 for one lane per chain), and the ablation shows ~106 ms of
+// pure issue time at config 2.  Here a lane owns one chain again, but the records still arrive
+// with quad-shaped loads: for j = 0..3 lane l fetches chunk (l & 3) of the record of chain
+// (l >> 2) + 16 j (record index taken from that lane with a wave shuffle), the 64 records are
+// written to a per-wave LDS tile (rows of 20 words: conflict-free 128-bit reads) and every lane
+// reads its own row back.  Same number of distinct-line requests as the quad kernel, a third of
+// the vector instructions.
+constexpr int WL_THREADS = 1024;
+constexpr int WL_ROW = 20;                 // words per staged record (16 + 4 padding)
+
+template<bool LDS_SUP>
+__global__ void __launch_bounds__(WL_THREADS, 4) k_lf_walk_lds(IndexView A, IndexView B, u64 seq_first, u64 seq_count, EmitSink sink, u32 nsup_a, u32 nsup_b)
+{
+  extern __shared__ u64 dyn_lds[];           // stage tiles, then the super tables
+  __shared__ u64 sC[16];
+  __shared__ u32 ring[L1_BINS * L1_RING];
+  __shared__ u32 tail[L1_BINS], head[L1_BINS], chunk_left[L1_BINS];
+  __shared__ u64 chunk_pos[L1_BINS];
+  u32* stage_all = (u32*)dyn_lds;                                              // [waves][64][WL_ROW]
+  u64* sup_lds = dyn_lds + (WL_THREADS / WAVE) * 64 * WL_ROW / 2;             // [5 nsup_a][5 nsup_b]
+  if(threadIdx.x < L1_BINS) { tail[threadIdx.x] = 0; head[threadIdx.x] = 0; chunk_left[threadIdx.x] = 0; chunk_pos[threadIdx.x] = 0; }
+  if(threadIdx.x == 0)
+  {
+#pragma unroll
+    for(int k = 0; k < 8; k++) { sC[k] = A.C[k]; sC[8 + k] = B.C[k]; }
+  }
+  if(LDS_SUP)
+  {
+    for(u32 k = threadIdx.x; k < 5 * nsup_a; k += WL_THREADS) { sup_lds[k] = A.sup[(k / 5) * SUP_STRIDE + 1 + (k % 5)]; }
+    for(u32 k = threadIdx.x; k < 5 * nsup_b; k += WL_THREADS) { sup_lds[5 * nsup_a + k] = B.sup[(k / 5) * SUP_STRIDE + 1 + (k % 5)]; }
+  }
+  const u64* lds_a = sup_lds; const u64* lds_b = sup_lds + 5 * nsup_a;
+  __syncthreads();
+
+  const u32 lane = lane_id();
+  u32* tile = stage_all + (threadIdx.x >> 6) * 64 * WL_ROW;
+  const u32 src_lane = lane >> 2, part = lane & 3;
+  const u64 stride = (u64)gridDim.x * WL_THREADS;
+  u64 next = (u64)blockIdx.x * WL_THREADS + threadIdx.x;
+  u64 i = 0, r = 0;
+  bool walking = false;
+
+  for(u32 it = 0; ; it++)
+  {
+    if(!walking && next < seq_count)
+    {
+      i = seq_first + next; r = A.m;                              // fmi.cpp:286: trie root "$"
+      next += stride; walking = true;
+      sink_append(sink.bits, ring, tail, head, i + r);
+    }
+    // Record indexes (0 for idle lanes: any valid record).
+    const u32 qb = (walking ? (u32)(i >> REC_SHIFT) : 0u), qa = (walking ? (u32)(r >> REC_SHIFT) : 0u);
+    uint4 vb[4], va[4];
+#pragma unroll
+    for(int j = 0; j < 4; j++)
+    {
+      u32 ib = (u32)__shfl((int)qb, (int)src_lane + 16 * j, WAVE);
+      u32 ia = (u32)__shfl((int)qa, (int)src_lane + 16 * j, WAVE);
+      vb[j] = B.recs[4 * (u64)ib + part];
+      va[j] = A.recs[4 * (u64)ia + part];
+    }
+    u32 wb[16], wa[16];
+    // B records through the tile
+#pragma unroll
+    for(int j = 0; j < 4; j++) { *(uint4*)(tile + (src_lane + 16 * j) * WL_ROW + 4 * part) = vb[j]; }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for(int k = 0; k < 4; k++) { uint4 t = *(const uint4*)(tile + lane * WL_ROW + 4 * k); wb[4 * k] = t.x; wb[4 * k + 1] = t.y; wb[4 * k + 2] = t.z; wb[4 * k + 3] = t.w; }
+    __builtin_amdgcn_wave_barrier();
+    // A records through the same tile
+#pragma unroll
+    for(int j = 0; j < 4; j++) { *(uint4*)(tile + (src_lane + 16 * j) * WL_ROW + 4 * part) = va[j]; }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for(int k = 0; k < 4; k++) { uint4 t = *(const uint4*)(tile + lane * WL_ROW + 4 * k); wa[4 * k] = t.x; wa[4 * k + 1] = t.y; wa[4 * k + 2] = t.z; wa[4 * k + 3] = t.w; }
+    __builtin_amdgcn_wave_barrier();
+
+    if(walking)
+    {
+      const u32 jb = (u32)(i & (REC_POS - 1)), ja = (u32)(r & (REC_POS - 1));
+      const u32 c = rec_symbol(wb, jb);                             // BWT_B[i]
+      if(c == 0) { walking = false; }                               // fmi.cpp:299: start of the sequence
+      else
+      {
+        u64 supb, supa;
+        if(LDS_SUP)
+        {
+          supb = lds_b[5 * (u32)(i >> SUPER_SHIFT) + (c - 1)];
+          supa = lds_a[5 * (u32)(r >> SUPER_SHIFT) + (c - 1)];
+        }
+        else
+        {
+          supb = B.sup[(i >> SUPER_SHIFT) * SUP_STRIDE + c];
+          supa = A.sup[(r >> SUPER_SHIFT) * SUP_STRIDE + c];
+        }
+        i = sC[8 + c] + supb + rec_header(wb, c) + rec_count(wb, c, jb);   // LF_B(i), utils.h:335-341
+        r = sC[c] + supa + rec_header(wa, c) + rec_count(wa, c, ja);       // LF_A(r, c), utils.h:343-348
+        sink_append(sink.bits, ring, tail, head, i + r);
+      }
+    }
+    if((it & (L1_FLUSH_EVERY - 1)) == L1_FLUSH_EVERY - 1)
+    {
+      int any = __syncthreads_or((walking || next < seq_count) ? 1 : 0);
       if(threadIdx.x < L1_BINS) { sink_flush_bin(sink, ring, tail, head, chunk_pos, chunk_left, threadIdx.x, !any); }
       __syncthreads();
       if(!any) { break; }

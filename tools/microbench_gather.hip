@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include <cstdlib>
 typedef uint64_t u64; typedef uint32_t u32;
 
 __device__ inline u64 mix(u64 z) { z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); }
@@ -123,7 +124,7 @@ int main()
     u32* bits; (void)hipMalloc(&bits, sbytes); (void)hipMemset(bits, 0, sbytes);
     const uint4* ta = table; const uint4* tb = table + (bytes / 32);
     u64 nunits = bytes / 2 / 64;
-    int blocks = 2048; u64 it3 = 1024; double n = (double)blocks * 256 / 4 * it3;
+    int blocks = 2048; u64 it3 = (getenv("MB_ITERS") ? strtoull(getenv("MB_ITERS"), 0, 10) : 1024); double n = (double)blocks * 256 / 4 * it3;
     const char* wn[] = {"walk-like quad gather x2, no emit", "walk-like quad gather x2 + atomicOr", "walk-like quad gather x2 + 8-byte store"};
     for(int mode = 0; mode < 3; mode++)
     {
