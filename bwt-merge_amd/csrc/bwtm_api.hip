@@ -54,6 +54,7 @@ struct Tuning
   long long walk_blocks = 0;     // grid size override for k_lf_walk (0 = default)
   long long walk_kernel = 0;     // 0 = four lanes per chain (product), 1 = one lane per chain (first version, kept for A/B)
   long long walk_ablate = 0;     // timing-only ablations of the no-emit quad kernel (tools/walk_experiments.py)
+  long long l1_cap = 0;          // tests only: entries per level-1 region (0 = sized from the input)
   long long walk_variant = 0;    // 0 = four lanes per chain, four pipelined chains per quad (product); 1 = LDS-transposed one chain per lane
   long long scatter_kernel = 0;  // 0 = LDS counting sort (product), 1 = direct scattered stores (first version)
   long long emit_path = 0;       // 0 = partitioned emit (product), 1 = atomicOr on the bitvector (first version, also the fallback)
@@ -338,6 +339,7 @@ extern "C" int bwtm_tune(const char* key, long long value)
   else if(k == "walk_ablate") { g_tune.walk_ablate = value; }
   else if(k == "scatter_kernel") { g_tune.scatter_kernel = value; }
   else if(k == "walk_variant") { g_tune.walk_variant = value; }
+  else if(k == "l1_cap") { g_tune.l1_cap = value; }
   else if(k == "round_emits") { g_tune.round_emits = (value > 0 ? value : 1); }
   else { return fail(BWTM_EINVAL, "bwtm_tune: unknown key %s", key); }
   return BWTM_OK;
@@ -685,6 +687,7 @@ int search_partitioned(const bwtm_index* a, const bwtm_index* b, u64 seq_first, 
     const u64 est = r_count * per_seq;
     u64 cap = est / L1_BINS + est / (4 * L1_BINS) + blocks * L1_CHUNK + (1ull << TILE_SHIFT);
     cap = div_up(cap, L1_CHUNK) * L1_CHUNK;
+    if(g_tune.l1_cap > 0) { cap = div_up((u64)g_tune.l1_cap, L1_CHUNK) * L1_CHUNK; }      // tests: force region overflow
 
     DevBuf l1, gcount, overflow;
     TRY(l1.alloc((u64)L1_BINS * cap * sizeof(u32)));

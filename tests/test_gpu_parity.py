@@ -199,3 +199,39 @@ def test_config1_shape_merge(gpu, oracle):
     assert np.array_equal(M.data(), m.data)
     be, cum = M.samples(); obe, ocum = m.samples
     assert np.array_equal(be, obe) and np.array_equal(cum, ocum)
+
+
+def test_partitioned_emit_rounds_fallbacks_and_variants(gpu, oracle):
+    """The search's partition machinery under stress: many rounds, tiny regions (overflow ->
+    exact fallback), skewed insert positions, and every kernel variant give the same rank array."""
+    # B's suffixes all sort into two narrow places of A: emits concentrate in a few tiles
+    rng = np.random.default_rng(21)
+    a_reads = np.concatenate([np.concatenate([rng.choice([1, 2], 60), [0]]) for _ in range(1500)]).astype(np.uint8)
+    b_reads = np.concatenate([np.concatenate([rng.choice([3, 4], 60), [0]]) for _ in range(1200)]).astype(np.uint8)
+    cases = [(oracle.FMI.from_text(a_reads), oracle.FMI.from_text(b_reads))]
+    ta = oracle.generate_reads(31, 3000, 100); tb = oracle.generate_reads(32, 2500, 100)
+    cases.append((oracle.FMI.from_text(ta), oracle.FMI.from_text(tb)))
+    try:
+        for a, b in cases:
+            ranks, counts, _ = oracle.search(a, b, threads=2)
+            ora = oracle.ra_from_runs(ranks, counts)
+            A = gpu.Index.upload(a.data, a.sequences, a.bases)
+            B = gpu.Index.upload(b.data, b.sequences, b.bases)
+            settings = [dict(), dict(round_emits=20000), dict(round_emits=3000, walk_blocks=1), dict(walk_variant=1),
+                        dict(emit_path=1), dict(emit_path=1, walk_kernel=1), dict(scatter_kernel=1),
+                        dict(l1_cap=256), dict(l1_cap=1024, walk_variant=1)]
+            for st in settings:
+                for k in ("round_emits", "walk_blocks", "walk_variant", "emit_path", "walk_kernel", "scatter_kernel", "l1_cap"):
+                    gpu.tune(k, {"round_emits": 1 << 33}.get(k, 0))
+                for k, v in st.items():
+                    gpu.tune(k, v)
+                ra = gpu.RankArray(A, B)
+                ra.search(A, B, 0, b.sequences - 1)
+                ra.finalize()
+                assert ra.values == b.bases, st
+                assert np.array_equal(ra.download(), ora), st
+                ra.free()
+    finally:
+        for k in ("walk_blocks", "walk_variant", "emit_path", "walk_kernel", "scatter_kernel", "l1_cap"):
+            gpu.tune(k, 0)
+        gpu.tune("round_emits", 1 << 33)

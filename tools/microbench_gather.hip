@@ -20,11 +20,11 @@ __global__ void __launch_bounds__(256) k_gather(const uint4* table, u64 nunits, 
   u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
   u64 key = (MODE == 3 ? gid >> 2 : gid);
   u32 acc = 0;
-  u64 state = key * 0x9E3779B97F4A7C15ULL + 12345;
+  u64 state = mix(key * 0x9E3779B97F4A7C15ULL + 12345);   // independent stream per chain
   for(u64 it = 0; it < iters; it++)
   {
     u64 u = mix(state + acc) % nunits;      // dependent on the previous load (a chain)
-    state += 0x9E3779B97F4A7C15ULL;
+    state = state * 6364136223846793005ULL + 1442695040888963407ULL;
     if(MODE == 0) { const uint4* p = table + 4 * u; uint4 a = p[0], b = p[1], c = p[2], d = p[3]; acc += a.x ^ b.y ^ c.z ^ d.w; }
     else if(MODE == 1) { const uint4* p = table + 8 * u; uint4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5], g = p[6], h = p[7]; acc += a.x ^ b.y ^ c.z ^ d.w ^ e.x ^ f.y ^ g.z ^ h.w; }
     else if(MODE == 2) { const uint4* p = table + 4 * u; uint4 a = p[0]; acc += a.x; }
@@ -39,10 +39,10 @@ template<int MODE>
 __global__ void __launch_bounds__(256) k_scatter(u32* table, u64 nwords, u64 iters)
 {
   u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
-  u64 state = gid * 0x9E3779B97F4A7C15ULL + 777;
+  u64 state = mix(gid * 0x9E3779B97F4A7C15ULL + 777);
   for(u64 it = 0; it < iters; it++)
   {
-    u64 z = mix(state); state += 0x9E3779B97F4A7C15ULL;
+    u64 z = mix(state); state = state * 6364136223846793005ULL + 1442695040888963407ULL;
     u64 w = z % nwords;
     if(MODE == 0) { atomicOr(table + w, 1u << (z >> 59)); }
     else if(MODE == 1) { ((u64*)table)[w >> 1] = z; }
@@ -58,10 +58,10 @@ __global__ void __launch_bounds__(256) k_walklike(const uint4* ta, const uint4* 
   u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
   u64 key = gid >> 2; u32 q = threadIdx.x & 3;
   u32 acc = 0;
-  u64 state = key * 0x9E3779B97F4A7C15ULL + 12345;
+  u64 state = mix(key * 0x9E3779B97F4A7C15ULL + 12345);   // independent stream per chain
   for(u64 it = 0; it < iters; it++)
   {
-    u64 z = mix(state + acc); state += 0x9E3779B97F4A7C15ULL;
+    u64 z = mix(state + acc); state = state * 6364136223846793005ULL + 1442695040888963407ULL;
     u64 ua = z % nunits, ub = (z >> 20) % nunits;
     uint4 a = ta[4 * ua + q], b = tb[4 * ub + q];
     u32 v = a.x ^ a.y ^ b.z ^ b.w; v ^= __shfl_xor((int)v, 1); v ^= __shfl_xor((int)v, 2); acc += v;
