@@ -54,6 +54,7 @@ struct Tuning
   long long walk_blocks = 0;     // grid size override for k_lf_walk (0 = default)
   long long walk_kernel = 0;     // 0 = four lanes per chain (product), 1 = one lane per chain (first version, kept for A/B)
   long long walk_ablate = 0;     // timing-only ablations of the no-emit quad kernel (tools/walk_experiments.py)
+  long long search_algo = 0;     // 0 = level-synchronous frontier search (product), 1 = per-chain walk with partitioned emit
   long long l1_cap = 0;          // tests only: entries per level-1 region (0 = sized from the input)
   long long walk_variant = 0;    // 0 = four lanes per chain, four pipelined chains per quad (product); 1 = LDS-transposed one chain per lane
   long long scatter_kernel = 0;  // 0 = LDS counting sort (product), 1 = direct scattered stores (first version)
@@ -340,6 +341,7 @@ extern "C" int bwtm_tune(const char* key, long long value)
   else if(k == "scatter_kernel") { g_tune.scatter_kernel = value; }
   else if(k == "walk_variant") { g_tune.walk_variant = value; }
   else if(k == "l1_cap") { g_tune.l1_cap = value; }
+  else if(k == "search_algo") { g_tune.search_algo = value; }
   else if(k == "round_emits") { g_tune.round_emits = (value > 0 ? value : 1); }
   else { return fail(BWTM_EINVAL, "bwtm_tune: unknown key %s", key); }
   return BWTM_OK;
@@ -661,6 +663,67 @@ int search_atomic(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64 c
   return BWTM_OK;
 }
 
+// Level 2 of the emit partition + tile build (shared by the walk and the frontier search):
+// per-bin slices -> counts -> offsets -> LDS counting sort -> tiles ORed into the bitvector.
+int partition_level2(DevBuf& l1, DevBuf& gcount, u64 cap, u64 nsub, u32 subs, bwtm_ra* ra)
+{
+  const u32 nregions = (u32)L1_BINS * subs;
+  const u64 ntiles_pad = nsub * L1_BINS;
+  const u64 nwords = ra->nchunks * CHUNK_WORDS;
+  {
+    std::vector<u64> counts_host(nregions);
+    HIP_TRY(hipMemcpyAsync(counts_host.data(), gcount.p, nregions * sizeof(u64), hipMemcpyDeviceToHost, g_ctx.stream));
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+
+    // Slices of at most PART_SLICE entries, each inside one region; the slices of a bin are consecutive.
+    std::vector<u32> slice_bin, bin_slice0(L1_BINS + 1);
+    std::vector<u64> slice_begin;
+    u64 total_entries = 0;
+    for(u32 bin = 0; bin < (u32)L1_BINS; bin++)
+    {
+      bin_slice0[bin] = (u32)slice_bin.size();
+      for(u32 sub = 0; sub < subs; sub++)
+      {
+        u32 region = bin * subs + sub;
+        u64 total = (counts_host[region] > cap ? cap : counts_host[region]);
+        total_entries += total;
+        for(u64 begin = 0; begin < total; begin += PART_SLICE) { slice_bin.push_back(region); slice_begin.push_back(begin); }
+      }
+    }
+    bin_slice0[L1_BINS] = (u32)slice_bin.size();
+    const u64 nslices = slice_bin.size();
+    if(nslices == 0) { return BWTM_OK; }
+
+    DevBuf d_slice_bin, d_slice_begin, d_bin_slice0, counts, tile_start, lists;
+    TRY(d_slice_bin.alloc(nslices * sizeof(u32))); TRY(d_slice_begin.alloc(nslices * sizeof(u64))); TRY(d_bin_slice0.alloc((L1_BINS + 1) * sizeof(u32)));
+    HIP_TRY(hipMemcpyAsync(d_slice_bin.p, slice_bin.data(), nslices * sizeof(u32), hipMemcpyHostToDevice, g_ctx.stream));
+    HIP_TRY(hipMemcpyAsync(d_slice_begin.p, slice_begin.data(), nslices * sizeof(u64), hipMemcpyHostToDevice, g_ctx.stream));
+    HIP_TRY(hipMemcpyAsync(d_bin_slice0.p, bin_slice0.data(), (L1_BINS + 1) * sizeof(u32), hipMemcpyHostToDevice, g_ctx.stream));
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));         // the host vectors go out of scope at the end of the round
+    TRY(counts.alloc(nslices * nsub * sizeof(u32)));
+    TRY(tile_start.alloc((ntiles_pad + 1) * sizeof(u64), true));
+    TRY(lists.alloc(total_entries * sizeof(unsigned short) + 64));
+
+    LAUNCH_LDS("part_count", k_part_count, nslices, PART_THREADS, nsub * sizeof(u32), l1.as<const u32>(), cap, gcount.as<const u64>(),
+      d_slice_bin.as<const u32>(), d_slice_begin.as<const u64>(), (u32)nsub, counts.as<u32>());
+    LAUNCH("part_offsets", k_part_offsets, div_up(ntiles_pad, BLOCK_THREADS), BLOCK_THREADS, counts.as<u32>(), d_bin_slice0.as<const u32>(), (u32)nsub, tile_start.as<u64>());
+    TRY(device_scan<0>(tile_start.as<u64>(), tile_start.as<u64>(), ntiles_pad + 1));
+    const u64 sort_lds = nsub * sizeof(u64) + SORT_CHUNK * sizeof(u32) + (2 * nsub + 1) * sizeof(u32);
+    if(sort_lds <= 96 * 1024 && g_tune.scatter_kernel == 0)
+    {
+      LAUNCH_LDS("part_scatter", k_part_scatter_sorted, nslices, PART_THREADS, sort_lds, l1.as<const u32>(), cap, gcount.as<const u64>(),
+        d_slice_bin.as<const u32>(), subs, d_slice_begin.as<const u64>(), (u32)nsub, counts.as<const u32>(), tile_start.as<const u64>(), lists.as<unsigned short>());
+    }
+    else
+    {
+      LAUNCH_LDS("part_scatter_direct", k_part_scatter, nslices, PART_THREADS, nsub * sizeof(u64), l1.as<const u32>(), cap, gcount.as<const u64>(),
+        d_slice_bin.as<const u32>(), subs, d_slice_begin.as<const u64>(), (u32)nsub, counts.as<const u32>(), tile_start.as<const u64>(), lists.as<unsigned short>());
+    }
+    LAUNCH("tile_build", k_tile_build, ntiles_pad, BLOCK_THREADS, lists.as<const unsigned short>(), tile_start.as<const u64>(), ntiles_pad, ra->bits_as<u64>(), nwords);
+  }
+  return BWTM_OK;
+}
+
 // Product path: walk with partitioned emit, level-2 counting sort, tile build (bwtm_kernels.hip.h).
 int search_partitioned(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64 count, bwtm_ra* ra)
 {
@@ -693,7 +756,7 @@ int search_partitioned(const bwtm_index* a, const bwtm_index* b, u64 seq_first, 
     TRY(l1.alloc((u64)L1_BINS * cap * sizeof(u32)));
     TRY(gcount.alloc(L1_BINS * sizeof(u64), true));
     TRY(overflow.alloc(64, true));
-    EmitSink sink; sink.l1 = l1.as<u32>(); sink.cap = cap; sink.gcount = gcount.as<u64>(); sink.bits = ra->bits_as<u32>(); sink.overflow = overflow.as<u32>();
+    EmitSink sink; sink.l1 = l1.as<u32>(); sink.cap = cap; sink.subs = 1; sink.gcount = gcount.as<u64>(); sink.bits = ra->bits_as<u32>(); sink.overflow = overflow.as<u32>();
     const u64 sup_bytes = 5 * (a->nsup + b->nsup) * sizeof(u64);
     const u64 stage_bytes = (u64)(WL_THREADS / WAVE) * 64 * WL_ROW * sizeof(u32);
     if(g_tune.walk_variant == 1 && a->nrecs < (1ull << 32) && b->nrecs < (1ull << 32))
@@ -719,52 +782,86 @@ int search_partitioned(const bwtm_index* a, const bwtm_index* b, u64 seq_first, 
       LAUNCH_LDS("lf_walk", k_lf_walk_binned<false>, blocks, WB_THREADS, 0, a->view(), b->view(), r_first, r_count, sink, (u32)a->nsup, (u32)b->nsup);
     }
 
-    std::vector<u64> counts_host(L1_BINS);
-    HIP_TRY(hipMemcpyAsync(counts_host.data(), gcount.p, L1_BINS * sizeof(u64), hipMemcpyDeviceToHost, g_ctx.stream));
-    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-
-    // Slices of at most PART_SLICE entries, each inside one bin.
-    std::vector<u32> slice_bin, bin_slice0(L1_BINS + 1);
-    std::vector<u64> slice_begin;
-    u64 total_entries = 0;
-    for(u32 bin = 0; bin < (u32)L1_BINS; bin++)
-    {
-      bin_slice0[bin] = (u32)slice_bin.size();
-      u64 total = (counts_host[bin] > cap ? cap : counts_host[bin]);
-      total_entries += total;
-      for(u64 begin = 0; begin < total; begin += PART_SLICE) { slice_bin.push_back(bin); slice_begin.push_back(begin); }
-    }
-    bin_slice0[L1_BINS] = (u32)slice_bin.size();
-    const u64 nslices = slice_bin.size();
-    if(nslices == 0) { continue; }
-
-    DevBuf d_slice_bin, d_slice_begin, d_bin_slice0, counts, tile_start, lists;
-    TRY(d_slice_bin.alloc(nslices * sizeof(u32))); TRY(d_slice_begin.alloc(nslices * sizeof(u64))); TRY(d_bin_slice0.alloc((L1_BINS + 1) * sizeof(u32)));
-    HIP_TRY(hipMemcpyAsync(d_slice_bin.p, slice_bin.data(), nslices * sizeof(u32), hipMemcpyHostToDevice, g_ctx.stream));
-    HIP_TRY(hipMemcpyAsync(d_slice_begin.p, slice_begin.data(), nslices * sizeof(u64), hipMemcpyHostToDevice, g_ctx.stream));
-    HIP_TRY(hipMemcpyAsync(d_bin_slice0.p, bin_slice0.data(), (L1_BINS + 1) * sizeof(u32), hipMemcpyHostToDevice, g_ctx.stream));
-    HIP_TRY(hipStreamSynchronize(g_ctx.stream));         // the host vectors go out of scope at the end of the round
-    TRY(counts.alloc(nslices * nsub * sizeof(u32)));
-    TRY(tile_start.alloc((ntiles_pad + 1) * sizeof(u64), true));
-    TRY(lists.alloc(total_entries * sizeof(unsigned short) + 64));
-
-    LAUNCH_LDS("part_count", k_part_count, nslices, PART_THREADS, nsub * sizeof(u32), l1.as<const u32>(), cap, gcount.as<const u64>(),
-      d_slice_bin.as<const u32>(), d_slice_begin.as<const u64>(), (u32)nsub, counts.as<u32>());
-    LAUNCH("part_offsets", k_part_offsets, div_up(ntiles_pad, BLOCK_THREADS), BLOCK_THREADS, counts.as<u32>(), d_bin_slice0.as<const u32>(), (u32)nsub, tile_start.as<u64>());
-    TRY(device_scan<0>(tile_start.as<u64>(), tile_start.as<u64>(), ntiles_pad + 1));
-    const u64 sort_lds = nsub * sizeof(u64) + SORT_CHUNK * sizeof(u32) + (2 * nsub + 1) * sizeof(u32);
-    if(sort_lds <= 96 * 1024 && g_tune.scatter_kernel == 0)
-    {
-      LAUNCH_LDS("part_scatter", k_part_scatter_sorted, nslices, PART_THREADS, sort_lds, l1.as<const u32>(), cap, gcount.as<const u64>(),
-        d_slice_bin.as<const u32>(), d_slice_begin.as<const u64>(), (u32)nsub, counts.as<const u32>(), tile_start.as<const u64>(), lists.as<unsigned short>());
-    }
-    else
-    {
-      LAUNCH_LDS("part_scatter_direct", k_part_scatter, nslices, PART_THREADS, nsub * sizeof(u64), l1.as<const u32>(), cap, gcount.as<const u64>(),
-        d_slice_bin.as<const u32>(), d_slice_begin.as<const u64>(), (u32)nsub, counts.as<const u32>(), tile_start.as<const u64>(), lists.as<unsigned short>());
-    }
-    LAUNCH("tile_build", k_tile_build, ntiles_pad, BLOCK_THREADS, lists.as<const unsigned short>(), tile_start.as<const u64>(), ntiles_pad, ra->bits_as<u64>(), nwords);
+    TRY(partition_level2(l1, gcount, cap, nsub, 1, ra));
   }
+  return BWTM_OK;
+}
+
+// Level-synchronous search (k_frontier_*): one launch per LF step over the sorted frontier; the
+// emits of every step are written densely and turned into bitvector tiles at the end of an epoch.
+int frontier_flush(bwtm_ra* ra, DevBuf& emit16, u64 emit_cap, DevBuf& emit_base, DevBuf& bound, u64 ntiles, u64 nsteps)
+{
+  if(nsteps == 0) { return BWTM_OK; }
+  LAUNCH("bound_suffix_min", k_bound_suffix_min, nsteps, BLOCK_THREADS, bound.as<u32>(), ntiles, emit_base.as<const u64>(), nsteps);
+  LAUNCH("tile_build", k_tile_build_frontier, ntiles, BLOCK_THREADS, emit16.as<const unsigned short>(), emit_base.as<const u64>(), emit_cap, bound.as<const u32>(),
+    ntiles, nsteps, ra->bits_as<u64>(), ra->nchunks * CHUNK_WORDS);
+  return BWTM_OK;
+}
+
+int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64 count, bwtm_ra* ra)
+{
+  if(a->n >= (1ull << 40) || b->n >= (1ull << 40) || count >= (1ull << 32)) { return search_partitioned(a, b, seq_first, count, ra); }
+  const u64 ntiles = div_up(ra->n_out + 1, 1ull << TILE_SHIFT);
+  const u64 EPOCH = 512;                                  // steps whose emits are kept before tiles are built
+  const u64 nb_max = div_up(count, FR_BLOCK);
+  const u64 nseg = 5 * nb_max;
+  const u64 fcap = nb_max * FR_BLOCK;
+
+  DevBuf lo_i[2], hi_i[2], lo_r[2], hi_r[2], seg_len[2], seg_phys[2], seg_prefix, emit16, emit_base, bound;
+  for(int k = 0; k < 2; k++)
+  {
+    TRY(lo_i[k].alloc(fcap * 4)); TRY(hi_i[k].alloc(fcap)); TRY(lo_r[k].alloc(fcap * 4)); TRY(hi_r[k].alloc(fcap));
+    TRY(seg_len[k].alloc((nseg + 1) * sizeof(u64), true)); TRY(seg_phys[k].alloc((nseg + 1) * sizeof(u64), true));
+  }
+  TRY(seg_prefix.alloc((nseg + 1) * sizeof(u64)));
+  // An epoch emits at most one value per position of b; a shard of the sequences usually far less.
+  // Emits past the capacity take the exact atomicOr fallback.
+  const u64 per_seq = b->n / (b->m > 0 ? b->m : 1) + 1;
+  u64 emit_cap = 2 * count * per_seq + (1ull << 20);
+  if(emit_cap > b->n + 64) { emit_cap = b->n + 64; }
+  if(g_tune.l1_cap > 0) { emit_cap = (u64)g_tune.l1_cap; }       // tests: force the fallback
+  TRY(emit16.alloc(emit_cap * sizeof(unsigned short)));
+  TRY(emit_base.alloc((EPOCH + 1) * sizeof(u64), true));
+  TRY(bound.alloc(EPOCH * (ntiles + 1) * sizeof(u32)));
+  HIP_TRY(hipMemsetAsync(bound.p, 0xFF, EPOCH * (ntiles + 1) * sizeof(u32), g_ctx.stream));
+
+  u64 init_items = (fcap > nseg + 1 ? fcap : nseg + 1);
+  LAUNCH("frontier_init", k_frontier_init, div_up(init_items, BLOCK_THREADS), BLOCK_THREADS, lo_i[0].as<u32>(), hi_i[0].as<u8>(), lo_r[0].as<u32>(), hi_r[0].as<u8>(),
+    seg_len[0].as<u64>(), seg_phys[0].as<u64>(), nb_max, seq_first, count, a->m);
+  int cur = 0;
+  u64 in_epoch = 0;
+  for(u64 t = 0; t <= b->n; t++)
+  {
+    TRY(device_scan<0>(seg_len[cur].as<u64>(), seg_prefix.as<u64>(), nseg + 1));
+    if(t % 8 == 0)
+    {
+      u64 alive = 0;
+      HIP_TRY(hipMemcpyAsync(&alive, seg_prefix.as<u64>() + nseg, sizeof(u64), hipMemcpyDeviceToHost, g_ctx.stream));
+      HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+      if(alive == 0) { break; }
+    }
+    LAUNCH("frontier_prep", k_frontier_prep, 1, WAVE, seg_prefix.as<const u64>(), nseg, emit_base.as<u64>(), in_epoch);
+    FrontierView f;
+    f.I_lo = lo_i[cur].as<const u32>(); f.I_hi = hi_i[cur].as<const u8>(); f.R_lo = lo_r[cur].as<const u32>(); f.R_hi = hi_r[cur].as<const u8>();
+    f.In_lo = lo_i[1 - cur].as<u32>(); f.In_hi = hi_i[1 - cur].as<u8>(); f.Rn_lo = lo_r[1 - cur].as<u32>(); f.Rn_hi = hi_r[1 - cur].as<u8>();
+    f.seg_prefix = seg_prefix.as<const u64>(); f.seg_phys = seg_phys[cur].as<const u64>();
+    f.seg_len_next = seg_len[1 - cur].as<u64>(); f.seg_phys_next = seg_phys[1 - cur].as<u64>();
+    f.nb_max = nb_max;
+    f.emit16 = emit16.as<unsigned short>(); f.emit_base = emit_base.as<const u64>(); f.emit_cap = emit_cap; f.bits32 = ra->bits_as<u32>();
+    f.bound_row = bound.as<u32>() + in_epoch * (ntiles + 1); f.step = in_epoch;
+    if(g_tune.walk_emit == 1) { LAUNCH("frontier_step_noemit", k_frontier_step<1>, nb_max, FR_BLOCK, a->view(), b->view(), f); }
+    else { LAUNCH("frontier_step", k_frontier_step<0>, nb_max, FR_BLOCK, a->view(), b->view(), f); }
+    cur = 1 - cur;
+    in_epoch++;
+    if(in_epoch == EPOCH)
+    {
+      if(g_tune.walk_emit == 0) { TRY(frontier_flush(ra, emit16, emit_cap, emit_base, bound, ntiles, in_epoch)); }
+      HIP_TRY(hipMemsetAsync(bound.p, 0xFF, EPOCH * (ntiles + 1) * sizeof(u32), g_ctx.stream));
+      HIP_TRY(hipMemsetAsync(emit_base.p, 0, (EPOCH + 1) * sizeof(u64), g_ctx.stream));
+      in_epoch = 0;
+    }
+  }
+  if(g_tune.walk_emit == 0) { TRY(frontier_flush(ra, emit16, emit_cap, emit_base, bound, ntiles, in_epoch)); }
   return BWTM_OK;
 }
 
@@ -779,6 +876,7 @@ extern "C" int bwtm_search(const bwtm_index* a, const bwtm_index* b, uint64_t se
   if(b->m == 0 || seq_first > seq_last) { return BWTM_OK; }       // empty range (utils.h:80-83)
   if(seq_last >= b->m) { return fail(BWTM_EINVAL, "bwtm_search: sequence %llu out of range (%llu sequences)", (unsigned long long)seq_last, (unsigned long long)b->m); }
   u64 count = seq_last - seq_first + 1;
+  if(g_tune.search_algo == 0 && g_tune.emit_path == 0 && g_tune.walk_kernel == 0) { return search_frontier(a, b, seq_first, count, ra); }
   if(g_tune.emit_path == 0 && g_tune.walk_emit == 0 && g_tune.walk_kernel == 0) { return search_partitioned(a, b, seq_first, count, ra); }
   return search_atomic(a, b, seq_first, count, ra);
 }

@@ -679,8 +679,10 @@ constexpr int WALK_ILP     = 4;            // chains per quad
 
 struct EmitSink
 {
-  u32* l1;            // L1_BINS regions of `cap` entries
+  u32* l1;            // L1_BINS * subs regions of `cap` entries (region = bin * subs + sub)
   u64  cap;           // entries per region (multiple of L1_CHUNK)
+  u32  subs;          // sub-regions per bin (1 for the walk; the frontier search spreads its
+                      // reservations over 64 counters per bin: same-address atomics serialize)
   u64* gcount;        // entries reserved per region
   u32* bits;          // the bitvector (fallback path)
   u32* overflow;      // set when a region overflowed (diagnostic; the fallback keeps the result exact)
@@ -984,20 +986,32 @@ __global__ void __launch_bounds__(WL_THREADS, 4) k_lf_walk_lds(IndexView A, Inde
 constexpr int PART_THREADS = 1024;
 constexpr u64 PART_SLICE = 1ull << 20;      // entries per slice
 
-__global__ void __launch_bounds__(PART_THREADS) k_part_count(const u32* l1, u64 cap, const u64* gcount, const u32* slice_bin,
+__global__ void __launch_bounds__(PART_THREADS) k_part_count(const u32* l1, u64 cap, const u64* gcount, const u32* slice_region,
   const u64* slice_begin, u32 nsub, u32* counts)
 {
   extern __shared__ u32 hist[];
   for(u32 k = threadIdx.x; k < nsub; k += PART_THREADS) { hist[k] = 0; }
   __syncthreads();
-  u32 b = slice_bin[blockIdx.x];
+  u32 region = slice_region[blockIdx.x];
   u64 begin = slice_begin[blockIdx.x];
-  u64 end = begin + PART_SLICE; u64 total = gcount[b]; if(total > cap) { total = cap; } if(end > total) { end = total; }
-  const u32* src = l1 + (u64)b * cap;
-  for(u64 k = begin + threadIdx.x; k < end; k += PART_THREADS)
+  u64 end = begin + PART_SLICE; u64 total = gcount[region]; if(total > cap) { total = cap; } if(end > total) { end = total; }
+  const u32* src = l1 + (u64)region * cap;
+  for(u64 k0 = begin; k0 < end; k0 += PART_THREADS)
   {
-    u32 e = src[k];
-    if(e != L1_SENTINEL) { atomicAdd(&hist[e >> TILE_SHIFT], 1u); }
+    u64 k = k0 + threadIdx.x;
+    u32 e = (k < end ? src[k] : L1_SENTINEL);
+    bool valid = (e != L1_SENTINEL);
+    u32 key = e >> TILE_SHIFT;
+    // entries written by the frontier search arrive in long runs of one key: add them with one LDS atomic
+    u64 vm = __ballot(valid);
+    if(vm != 0)
+    {
+      u32 first = (u32)__builtin_ctzll(vm);
+      u32 key0 = (u32)__shfl((int)key, (int)first, WAVE);
+      u64 same = __ballot(valid && key == key0);
+      if(same == vm) { if(lane_id() == first) { atomicAdd(&hist[key0], (u32)__builtin_popcountll(vm)); } }
+      else if(valid) { atomicAdd(&hist[key], 1u); }
+    }
   }
   __syncthreads();
   for(u32 k = threadIdx.x; k < nsub; k += PART_THREADS) { counts[(u64)blockIdx.x * nsub + k] = hist[k]; }
@@ -1020,19 +1034,20 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_part_offsets(u32* counts, con
 }
 
 // Level 2, pass c: scatter the 16-bit offsets of one slice to their tiles' lists.
-__global__ void __launch_bounds__(PART_THREADS) k_part_scatter(const u32* l1, u64 cap, const u64* gcount, const u32* slice_bin,
+__global__ void __launch_bounds__(PART_THREADS) k_part_scatter(const u32* l1, u64 cap, const u64* gcount, const u32* slice_region, u32 subs,
   const u64* slice_begin, u32 nsub, const u32* counts, const u64* tile_start, unsigned short* out)
 {
   extern __shared__ u64 cursor[];
-  u32 b = slice_bin[blockIdx.x];
+  u32 region = slice_region[blockIdx.x];
+  u32 b = region / subs;
   for(u32 k = threadIdx.x; k < nsub; k += PART_THREADS)
   {
     cursor[k] = tile_start[(u64)k * L1_BINS + b] + counts[(u64)blockIdx.x * nsub + k];
   }
   __syncthreads();
   u64 begin = slice_begin[blockIdx.x];
-  u64 end = begin + PART_SLICE; u64 total = gcount[b]; if(total > cap) { total = cap; } if(end > total) { end = total; }
-  const u32* src = l1 + (u64)b * cap;
+  u64 end = begin + PART_SLICE; u64 total = gcount[region]; if(total > cap) { total = cap; } if(end > total) { end = total; }
+  const u32* src = l1 + (u64)region * cap;
   for(u64 k = begin + threadIdx.x; k < end; k += PART_THREADS)
   {
     u32 e = src[k];
@@ -1050,7 +1065,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_part_scatter(const u32* l1, u6
 constexpr int SORT_CHUNK = 16384;
 constexpr int SORT_PER_THREAD = SORT_CHUNK / PART_THREADS;      // 16
 
-__global__ void __launch_bounds__(PART_THREADS) k_part_scatter_sorted(const u32* l1, u64 cap, const u64* gcount, const u32* slice_bin,
+__global__ void __launch_bounds__(PART_THREADS) k_part_scatter_sorted(const u32* l1, u64 cap, const u64* gcount, const u32* slice_region, u32 subs,
   const u64* slice_begin, u32 nsub, const u32* counts, const u64* tile_start, unsigned short* out)
 {
   extern __shared__ u64 lds_raw[];
@@ -1060,14 +1075,15 @@ __global__ void __launch_bounds__(PART_THREADS) k_part_scatter_sorted(const u32*
   u32* offs = hist + nsub;                                 // [nsub + 1]
   __shared__ u32 wave_total[PART_THREADS / WAVE];
 
-  const u32 b = slice_bin[blockIdx.x];
+  const u32 region = slice_region[blockIdx.x];
+  const u32 b = region / subs;
   for(u32 k = threadIdx.x; k < nsub; k += PART_THREADS)
   {
     cursor[k] = tile_start[(u64)k * L1_BINS + b] + counts[(u64)blockIdx.x * nsub + k];
   }
   u64 begin = slice_begin[blockIdx.x];
-  u64 end = begin + PART_SLICE; u64 total = gcount[b]; if(total > cap) { total = cap; } if(end > total) { end = total; }
-  const u32* src = l1 + (u64)b * cap;
+  u64 end = begin + PART_SLICE; u64 total = gcount[region]; if(total > cap) { total = cap; } if(end > total) { end = total; }
+  const u32* src = l1 + (u64)region * cap;
 
   for(u64 chunk = begin; chunk < end; chunk += SORT_CHUNK)
   {
@@ -1135,6 +1151,308 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_tile_build(const unsigned sho
   {
     u64 w = w0 + k;
     if(w < nwords) { bits[w] |= (u64)tile[2 * k] | ((u64)tile[2 * k + 1] << 32); }
+  }
+}
+
+//------------------------------------------------------------------------------
+// K1, level-synchronous form ("frontier search").
+//
+// All chains advance together, one LF step per launch, and the frontier F_t (the chains that are
+// t steps from the end of their sequence) is kept SORTED BY SUFFIX.  Then both coordinates are
+// monotone along the frontier -- i (rank among B's suffixes) strictly increasing, r (rank among
+// A's suffixes) non-decreasing -- so the records of both indexes are read as sequential windows
+// instead of random gathers, and the emitted bit positions i + r are increasing as well.
+// One LF step keeps the order inside a symbol class (LF is monotone for a fixed symbol) and the
+// classes occupy disjoint, increasing ranges [C[c], C[c+1]), so F_{t+1} = stable 5-way split of
+// F_t by c = BWT_B[i]: the "radix sort + segmented scan" of the north star, one digit per step.
+//
+// No data is moved for the split: a block of FR_BLOCK elements writes its survivors grouped by
+// class into its own slot of the next buffer and records (length, physical start) per (class,
+// block) SEGMENT; the logical order of F_{t+1} is (class, block), and an exclusive scan of the
+// segment lengths (logical order) lets the next step map logical indexes to physical ones.
+// The reference explores the same trie level by level implicitly (fmi.cpp:286-323: ranges of B
+// with equal suffixes); here every sequence keeps its own element, which yields the same multiset
+// of ranks.
+
+constexpr int FR_BLOCK = 512;                  // elements (= threads) per block
+constexpr int FR_WINDOW = 64;                  // records per wave window
+
+struct FrontierView
+{
+  // Coordinates are 40-bit: low 32 bits and high byte in separate arrays (10 bytes per element).
+  const u32* I_lo; const u8* I_hi; const u32* R_lo; const u8* R_hi;      // current frontier (physical layout)
+  u32* In_lo; u8* In_hi; u32* Rn_lo; u8* Rn_hi;                          // next frontier
+  const u64* seg_prefix;                       // exclusive scan of seg_len (5 * nb_max + 1 entries); last = N_t
+  const u64* seg_phys;                         // physical start of every segment
+  u64* seg_len_next; u64* seg_phys_next;       // produced for the next step
+  u64 nb_max;                                  // blocks per class in the segment tables
+  // Dense emit of this step (EMIT == 0): the frontier is sorted, so are its bit positions p = i + r.
+  unsigned short* emit16;                      // in-tile offsets p & 0xFFFF at emit_base[step] + logical index
+  const u64* emit_base;                        // [steps + 1] running number of emits
+  u64 emit_cap;                                // capacity of emit16; emits beyond it fall back to atomicOr
+  u32* bits32;                                 // the bitvector (fallback path only)
+  u32* bound_row;                              // this step's row of tile boundaries: [ntiles + 1], pre-set to ~0
+  u64 step;
+};
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_init(u32* I_lo, u8* I_hi, u32* R_lo, u8* R_hi, u64* seg_len, u64* seg_phys, u64 nb_max,
+  u64 seq_first, u64 count, u64 m_a)
+{
+  u64 g = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(g < count)
+  {
+    u64 i = seq_first + g;                                                // fmi.cpp:286: trie root "$"
+    I_lo[g] = (u32)i; I_hi[g] = (u8)(i >> 32); R_lo[g] = (u32)m_a; R_hi[g] = (u8)(m_a >> 32);
+  }
+  if(g < 5 * nb_max)
+  {
+    u64 cls = g / nb_max, b = g % nb_max;
+    u64 begin = b * FR_BLOCK;
+    seg_len[g] = (cls == 0 && begin < count ? (count - begin < (u64)FR_BLOCK ? count - begin : (u64)FR_BLOCK) : 0);
+    seg_phys[g] = begin;
+  }
+  if(g == 5 * nb_max) { seg_len[g] = 0; }
+}
+
+// Loads the records of the wave's elements.  `rec` is this lane's record index (non-decreasing
+// along the wave; idle lanes repeat the last one).  If the wave's records fit a 64-record window,
+// exactly the spanned records are fetched with fully coalesced loads and read back from LDS.
+__device__ inline void frontier_fetch(const uint4* recs, u64 nrecs, u64 rec, uint4* window, u32 w[16])
+{
+  const u32 lane = lane_id();
+  u64 lo = shfl_u64(rec, 0), hi = shfl_u64(rec, WAVE - 1);
+  if(hi - lo < (u64)FR_WINDOW)
+  {
+    u32 chunks = 4 * (u32)(hi - lo + 1);                        // 16-byte chunks to fetch (<= 256)
+#pragma unroll
+    for(int k = 0; k < 4; k++)
+    {
+      u32 cidx = (u32)(64 * k) + lane;
+      if(cidx < chunks)
+      {
+        u64 chunk = 4 * lo + cidx;
+        window[cidx] = (chunk < 4 * nrecs ? recs[chunk] : make_uint4(0, 0, 0, 0));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    u32 off = (u32)(rec - lo);
+#pragma unroll
+    for(int k = 0; k < 4; k++)
+    {
+      uint4 t = window[4 * off + k];
+      w[4 * k] = t.x; w[4 * k + 1] = t.y; w[4 * k + 2] = t.z; w[4 * k + 3] = t.w;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  else
+  {
+    load_record(recs, (rec < nrecs ? rec : nrecs - 1), w);
+  }
+}
+
+template<int EMIT>
+__global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, IndexView B, FrontierView f)
+{
+  __shared__ uint4 window[FR_BLOCK / WAVE][4 * FR_WINDOW];
+  __shared__ u32 wave_cnt[FR_BLOCK / WAVE][6];
+  __shared__ u64 s_first_seg;
+  __shared__ u64 s_last_tile[FR_BLOCK / WAVE];
+  const u64 nseg = 5 * f.nb_max;
+  const u64 N = f.seg_prefix[nseg];
+  const u64 g0 = (u64)blockIdx.x * FR_BLOCK;
+  const u32 lane = lane_id(), wave = threadIdx.x >> 6;
+
+  // Blocks past the frontier only publish empty segments.
+  if(g0 >= N)
+  {
+    if(threadIdx.x < 5) { f.seg_len_next[(u64)threadIdx.x * f.nb_max + blockIdx.x] = 0; f.seg_phys_next[(u64)threadIdx.x * f.nb_max + blockIdx.x] = g0; }
+    if(blockIdx.x == 0 && threadIdx.x == 5) { f.seg_len_next[nseg] = 0; }
+    return;
+  }
+  if(threadIdx.x == 0)
+  {
+    u64 lo = 0, hi = nseg;                     // seg_prefix[lo] <= g0 < seg_prefix[hi]
+    while(hi - lo > 1) { u64 mid = (lo + hi) >> 1; if(f.seg_prefix[mid] <= g0) { lo = mid; } else { hi = mid; } }
+    s_first_seg = lo;
+  }
+  __syncthreads();
+
+  const u64 g = g0 + threadIdx.x;
+  const bool active = (g < N);
+  u64 i = 0, r = 0;
+  if(active)
+  {
+    u64 sgm = s_first_seg;
+    while(f.seg_prefix[sgm + 1] <= g) { sgm++; }               // skips empty segments
+    u64 phys = f.seg_phys[sgm] + (g - f.seg_prefix[sgm]);
+    i = (u64)f.I_lo[phys] | ((u64)f.I_hi[phys] << 32);
+    r = (u64)f.R_lo[phys] | ((u64)f.R_hi[phys] << 32);
+  }
+  const u64 any_active = __ballot(active);
+  u32 c = 0;
+  u64 ni = 0, nr = 0;
+  if(any_active != 0)
+  {
+    // idle lanes (a suffix of the wave) borrow the last active lane's coordinates
+    const u32 last_lane = 63 - (u32)__builtin_clzll(any_active);
+    const u64 li = shfl_u64(i, (int)last_lane), lr = shfl_u64(r, (int)last_lane);
+    if(EMIT == 0 && active)
+    {
+      u64 slot = f.emit_base[f.step] + g;
+      if(slot < f.emit_cap) { f.emit16[slot] = (unsigned short)((i + r) & TILE_MASK); }
+      else { sink_fallback(f.bits32, i + r); }                  // exact fallback; k_tile_build_frontier skips these slots
+    }
+    u32 wb[16], wa[16];
+    frontier_fetch(B.recs, B.nrecs, (active ? i : li) >> REC_SHIFT, window[wave], wb);
+    frontier_fetch(A.recs, A.nrecs, (active ? r : lr) >> REC_SHIFT, window[wave], wa);
+    if(active)
+    {
+      const u32 jb = (u32)(i & (REC_POS - 1)), ja = (u32)(r & (REC_POS - 1));
+      c = rec_symbol(wb, jb);                                   // BWT_B[i]; 0 ends the chain (fmi.cpp:299)
+      if(c != 0)
+      {
+        ni = B.sup[(i >> SUPER_SHIFT) * SUP_STRIDE + c] + rec_header(wb, c) + rec_count(wb, c, jb);
+        nr = A.sup[(r >> SUPER_SHIFT) * SUP_STRIDE + c] + rec_header(wa, c) + rec_count(wa, c, ja);
+        // C[c]: kernel arguments cannot be indexed dynamically without scratch, hence the selects
+        u64 cb = (c == 1 ? B.C[1] : (c == 2 ? B.C[2] : (c == 3 ? B.C[3] : (c == 4 ? B.C[4] : B.C[5]))));
+        u64 ca = (c == 1 ? A.C[1] : (c == 2 ? A.C[2] : (c == 3 ? A.C[3] : (c == 4 ? A.C[4] : A.C[5]))));
+        ni += cb; nr += ca;                                     // LF_B(i), LF_A(r, c): utils.h:335-348
+      }
+    }
+  }
+  // Stable split by class inside the block.
+  u32 my_rank = 0;
+  u32 cnt_w[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for(u32 k = 1; k < 6; k++)
+  {
+    u64 m = __ballot(active && c == k);
+    cnt_w[k] = (u32)__builtin_popcountll(m);
+    if(c == k) { my_rank = (u32)__builtin_popcountll(m & ((1ull << lane) - 1)); }
+  }
+  if(lane == 0) { for(u32 k = 1; k < 6; k++) { wave_cnt[wave][k] = cnt_w[k]; } }
+  if(EMIT == 0)
+  {
+    // last active lane of the wave publishes its tile for lane 0 of the next wave
+    u32 last = (any_active != 0 ? 63 - (u32)__builtin_clzll(any_active) : 0u);
+    if(lane == last) { s_last_tile[wave] = (any_active != 0 ? ((i + r) >> TILE_SHIFT) : ~0ull); }
+  }
+  // Raw barrier with an LDS-only wait: __syncthreads() would also drain vmcnt and expose the latency
+  // of the emit reservation / stores that are still in flight (measured: +35 ms per search).
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  u32 class_base = 0, before_waves = 0;
+#pragma unroll
+  for(u32 k = 1; k < 6; k++)
+  {
+    u32 tot = 0, bw = 0;
+    for(u32 w2 = 0; w2 < FR_BLOCK / WAVE; w2++) { u32 v = wave_cnt[w2][k]; if(w2 < wave) { bw += v; } tot += v; }
+    if(k < c) { class_base += tot; }
+    if(k == c) { before_waves = bw; }
+    if(threadIdx.x == k - 1)
+    {
+      u32 base_k = 0;
+      for(u32 k2 = 1; k2 < k; k2++) { for(u32 w2 = 0; w2 < FR_BLOCK / WAVE; w2++) { base_k += wave_cnt[w2][k2]; } }
+      f.seg_len_next[(u64)(k - 1) * f.nb_max + blockIdx.x] = tot;
+      f.seg_phys_next[(u64)(k - 1) * f.nb_max + blockIdx.x] = g0 + base_k;
+    }
+  }
+  if(blockIdx.x == 0 && threadIdx.x == 5) { f.seg_len_next[nseg] = 0; }
+  if(EMIT == 0)
+  {
+    // First element of every tile: bound_row[tile] = min(logical index).  A lane marks its tile when
+    // the previous element lies in another tile; the block's first element always marks (the true
+    // first element of the tile, possibly in an earlier block, marks too and wins the minimum).
+    // Tiles without elements are filled in by k_bound_suffix_min.
+    const u64 my_tile = (i + r) >> TILE_SHIFT;
+    u64 prev_tile = shfl_up_u64(my_tile, 1);
+    if(lane == 0) { prev_tile = (wave > 0 ? s_last_tile[wave - 1] : ~0ull); }
+    if(active && my_tile != prev_tile) { atomicMin(&f.bound_row[my_tile], (u32)g); }
+  }
+  if(active && c != 0)
+  {
+    u64 dst = g0 + class_base + before_waves + my_rank;
+    f.In_lo[dst] = (u32)ni; f.In_hi[dst] = (u8)(ni >> 32);
+    f.Rn_lo[dst] = (u32)nr; f.Rn_hi[dst] = (u8)(nr >> 32);
+  }
+}
+
+// Per-step bookkeeping of the dense emit: emit_base[t + 1] = emit_base[t] + N_t.
+__global__ void k_frontier_prep(const u64* seg_prefix, u64 nseg, u64* emit_base, u64 step)
+{
+  if(threadIdx.x == 0 && blockIdx.x == 0) { emit_base[step + 1] = emit_base[step] + seg_prefix[nseg]; }
+}
+
+// Row t of the boundary table: bound[T] = logical index of the first element of step t whose bit
+// position lies in tile >= T (suffix minimum over the markers; N_t past the last element).
+__global__ void __launch_bounds__(BLOCK_THREADS) k_bound_suffix_min(u32* bound, u64 ntiles, const u64* emit_base, u64 nsteps)
+{
+  __shared__ u32 lds[BLOCK_THREADS];
+  u64 t = blockIdx.x;
+  if(t >= nsteps) { return; }
+  u32* row = bound + t * (ntiles + 1);
+  u32 running = (u32)(emit_base[t + 1] - emit_base[t]);        // N_t
+  if(threadIdx.x == 0) { row[ntiles] = running; }
+  for(u64 hi = ntiles; hi > 0; )
+  {
+    u64 lo = (hi > (u64)BLOCK_THREADS ? hi - BLOCK_THREADS : 0);
+    u64 idx = lo + threadIdx.x;
+    u32 v = (idx < hi ? row[idx] : 0xFFFFFFFFu);
+    lds[threadIdx.x] = v;
+    __syncthreads();
+    // inclusive suffix min inside the chunk (Hillis-Steele over 256 entries)
+    for(int d = 1; d < BLOCK_THREADS; d <<= 1)
+    {
+      u32 o = ((int)threadIdx.x + d < BLOCK_THREADS ? lds[threadIdx.x + d] : 0xFFFFFFFFu);
+      __syncthreads();
+      if(o < lds[threadIdx.x]) { lds[threadIdx.x] = o; }
+      __syncthreads();
+    }
+    u32 m = lds[threadIdx.x]; if(running < m) { m = running; }
+    if(idx < hi) { row[idx] = m; }
+    u32 chunk_min = lds[0];
+    __syncthreads();
+    if(chunk_min < running) { running = chunk_min; }
+    hi = lo;
+  }
+}
+
+// Tiles from the dense per-step emits: tile T receives, from every step t, the contiguous run
+// [bound[t][T], bound[t][T + 1]) of 16-bit offsets.  One workgroup per tile.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_tile_build_frontier(const unsigned short* emit16, const u64* emit_base, u64 emit_cap, const u32* bound,
+  u64 ntiles, u64 nsteps, u64* bits, u64 nwords)
+{
+  __shared__ u32 tile[1 << (TILE_SHIFT - 5)];
+  __shared__ u32 any;
+  u64 T = blockIdx.x;
+  if(T >= ntiles) { return; }
+  for(u32 k = threadIdx.x; k < (1u << (TILE_SHIFT - 5)); k += BLOCK_THREADS) { tile[k] = 0; }
+  if(threadIdx.x == 0) { any = 0; }
+  __syncthreads();
+  for(u64 t = 0; t < nsteps; t++)
+  {
+    const u32* row = bound + t * (ntiles + 1);
+    u32 lo = row[T], hi = row[T + 1];
+    const u64 base = emit_base[t];
+    for(u32 k = lo + threadIdx.x; k < hi; k += BLOCK_THREADS)
+    {
+      if(base + k < emit_cap)
+      {
+        u32 off = emit16[base + k];
+        atomicOr(&tile[off >> 5], 1u << (off & 31));
+      }
+    }
+    if(threadIdx.x == 0 && hi > lo) { any = 1; }
+  }
+  __syncthreads();
+  if(any == 0) { return; }
+  u64 w0 = T << (TILE_SHIFT - 6);
+  for(u32 k = threadIdx.x; k < (1u << (TILE_SHIFT - 6)); k += BLOCK_THREADS)
+  {
+    u64 w = w0 + k;
+    u64 v = (u64)tile[2 * k] | ((u64)tile[2 * k + 1] << 32);
+    if(w < nwords && v != 0) { bits[w] |= v; }
   }
 }
 

@@ -33,9 +33,11 @@ def run(label, emit, blocks):
             print("%-34s %-16s %9.2f ms  %6.2f Gsteps/s" % (label, k, ms / n, B.bases / (ms / n) / 1e6), flush=True)
 
 mode = sys.argv[2] if len(sys.argv) > 2 else "sweep"
-def run_product(label):
-    pkg.tune("walk_emit", 0); pkg.tune("walk_blocks", 0); pkg.tune("walk_kernel", 0); pkg.tune("emit_path", 0); pkg.tune("emit_path", 0)
+def run_product(label, algo=1):
+    pkg.tune("walk_emit", 0); pkg.tune("walk_blocks", 0); pkg.tune("walk_kernel", 0); pkg.tune("emit_path", 0); pkg.tune("search_algo", algo)
+    import time as _t
     pkg.profile_reset()
+    pkg.synchronize(); _t0 = _t.perf_counter()
     for _ in range(2):
         ra = pkg.RankArray(A, B)
         ra.search(A, B, 0, B.sequences - 1)
@@ -45,9 +47,22 @@ def run_product(label):
     tot = 0
     for k, (ms, n) in prof.items():
         print("%-34s %-16s %9.2f ms per search" % (label, k, ms / 2), flush=True); tot += ms / 2
-    print("%-34s %-16s %9.2f ms  %6.2f Gsteps/s" % (label, "TOTAL", tot, B.bases / tot / 1e6), flush=True)
+    print("%-34s %-16s %9.2f ms  %6.2f Gsteps/s   (wall %.1f ms per search)" % (label, "TOTAL", tot, B.bases / tot / 1e6, (_t.perf_counter() - _t0) * 500), flush=True)
 
-run_product("partitioned emit (product)")
+run_product("per-chain walk + partitioned emit", 1)
+if mode == "frontier":
+    run_product("frontier search (product)", 0)
+    pkg.tune("search_algo", 0)
+    for mode_emit in (1,):
+        pkg.tune("walk_emit", mode_emit)
+        pkg.profile_reset()
+        for _ in range(2):
+            ra = pkg.RankArray(A, B); ra.search(A, B, 0, B.sequences - 1); pkg.synchronize(); ra.free()
+        for k, (ms, n) in pkg.profile_read().items():
+            if k.startswith("frontier_step"):
+                print("frontier timing-only variant       %-28s %9.2f ms per search" % (k, ms / 2), flush=True)
+    pkg.tune("walk_emit", 0)
+    sys.exit(0)
 if mode == "ablate":
     pkg.tune("emit_path", 1); pkg.tune("walk_kernel", 0)
     for abl, name in ((0, "full"), (8, "synthetic chain, all loads"), (1, "no sup loads"), (2, "no A record"), (3, "no sup, no A record"), (7, "no loads at all")):
@@ -55,7 +70,7 @@ if mode == "ablate":
         run("quad no-emit ablation: %s" % name, 1, 2048)
     pkg.tune("walk_ablate", 0); pkg.tune("emit_path", 0)
     sys.exit(0)
-pkg.tune("emit_path", 1)
+pkg.tune("emit_path", 1); pkg.tune("search_algo", 1)
 for kernel, kname in ((0, "quad"), (1, "lane")):
     pkg.tune("walk_kernel", kernel)
     if mode == "sweep" and kernel == 0:
