@@ -143,25 +143,30 @@ def main():
     value = (n_a + n_b) / 1e9 / sec_per_step
 
     # ---------------------------------------------------------------- roofline of the dominant kernel
-    walk_ms, walk_launches = prof.get("lf_walk", (0.0, 0))
-    walk_avg_s = (walk_ms / 1e3 / walk_launches) if walk_launches else float("nan")
-    units_per_launch = (seq_last - seq_first + 1) / max(1, B0.sequences) * n_b if seq_first <= seq_last else 0
-    achieved = SEARCH_BYTES_PER_BASE * units_per_launch / walk_avg_s / 1e9 if walk_launches else 0.0
-    # HBM bytes per launch from the PMC counters: cannot be collected inside this process; the last
-    # committed rocprofv3 --pmc measurement of the same kernel on the same configuration is quoted.
+    # The search kernel: k_frontier_step (one launch per LF step of the level-synchronous search) or,
+    # when the library falls back to it, k_lf_walk_binned (one launch per search).  SURVEY.md 8(d):
+    # 160 algorithmic bytes per LF step (one 64-byte block + 8 + 8 bytes on each side).
+    dom = "frontier_step" if "frontier_step" in prof else "lf_walk"
+    dom_ms, dom_launches = prof.get(dom, (0.0, 0))
+    searches = max(1, args.steps)
+    units_per_search = (seq_last - seq_first + 1) / max(1, B0.sequences) * n_b if seq_first <= seq_last else 0
+    launches_per_search = dom_launches / searches if dom_launches else 0
+    avg_launch_s = (dom_ms / 1e3 / dom_launches) if dom_launches else float("nan")
+    units_per_launch = units_per_search / launches_per_search if launches_per_search else 0
+    achieved = SEARCH_BYTES_PER_BASE * units_per_launch / avg_launch_s / 1e9 if dom_launches else 0.0
     traffic, traffic_source = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01d_lf_walk_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "search_kernel_traffic.json")) as f:
             t = json.load(f)
-        if t["config"]["reads_per_set"] == args.reads and t["config"]["read_length"] == args.readlen and world == 1:
+        if (t["kernel"] == dom and t["config"]["reads_per_set"] == args.reads and t["config"]["read_length"] == args.readlen and world == 1):
             traffic, traffic_source = t["hbm_bytes_per_launch"], t["source"]
     except (OSError, KeyError, ValueError):
         pass
-    roofline = {"bound": "hbm", "kernel": "k_lf_walk_binned", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                "random_access_ceiling": {"steps_per_s": 25.3e9, "source": "tools/microbench_gather.hip: two random 64-byte records per step, profiles/r01d_microbench_gather.log",
-                                          "frac": round((units_per_launch / walk_avg_s) / 25.3e9, 4) if walk_launches else None},
-                "kernel_ms": round(walk_avg_s * 1e3, 3), "algorithmic_bytes_per_launch": SEARCH_BYTES_PER_BASE * units_per_launch}
+    roofline = {"bound": "hbm", "kernel": "k_" + dom + ("_binned" if dom == "lf_walk" else ""), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "launches_per_step": round(launches_per_search, 2), "avg_launch_ms": round(avg_launch_s * 1e3, 4),
+                "kernel_ms_per_step": round(dom_ms / searches, 3),
+                "algorithmic_bytes_per_launch": SEARCH_BYTES_PER_BASE * units_per_launch}
     kernel_ms = {name: round(ms / max(1, args.steps), 3) for name, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0])}
     # whole-job algorithmic bytes W = 176 n_B + |A| + |B| + 2 |Out|
     out_bytes = last.nbytes if last is not None else 0

@@ -1176,6 +1176,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_tile_build(const unsigned sho
 
 constexpr int FR_BLOCK = 512;                  // elements (= threads) per block
 constexpr int FR_WINDOW = 64;                  // records per wave window
+constexpr int FR_SEGS = 31;                    // segment-table entries staged per block
 
 struct FrontierView
 {
@@ -1256,7 +1257,7 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
   __shared__ uint4 window[FR_BLOCK / WAVE][4 * FR_WINDOW];
   __shared__ u32 wave_cnt[FR_BLOCK / WAVE][6];
   __shared__ u64 s_first_seg;
-  __shared__ u64 s_last_tile[FR_BLOCK / WAVE];
+  __shared__ u64 s_prefix[FR_SEGS + 1], s_phys[FR_SEGS + 1];
   const u64 nseg = 5 * f.nb_max;
   const u64 N = f.seg_prefix[nseg];
   const u64 g0 = (u64)blockIdx.x * FR_BLOCK;
@@ -1276,15 +1277,31 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
     s_first_seg = lo;
   }
   __syncthreads();
+  // The block's elements live in a handful of segments: stage their table entries in LDS.
+  const u64 first_seg = s_first_seg;
+  if(threadIdx.x <= FR_SEGS)
+  {
+    u64 sidx = first_seg + threadIdx.x; if(sidx > nseg) { sidx = nseg; }
+    s_prefix[threadIdx.x] = f.seg_prefix[sidx];
+    s_phys[threadIdx.x] = f.seg_phys[sidx < nseg ? sidx : nseg - 1];
+  }
+  __syncthreads();
 
   const u64 g = g0 + threadIdx.x;
   const bool active = (g < N);
   u64 i = 0, r = 0;
   if(active)
   {
-    u64 sgm = s_first_seg;
-    while(f.seg_prefix[sgm + 1] <= g) { sgm++; }               // skips empty segments
-    u64 phys = f.seg_phys[sgm] + (g - f.seg_prefix[sgm]);
+    u64 phys;
+    u32 k = 0;
+    while(k < (u32)FR_SEGS && s_prefix[k + 1] <= g) { k++; }       // skips empty segments
+    if(k < (u32)FR_SEGS) { phys = s_phys[k] + (g - s_prefix[k]); }
+    else
+    {
+      u64 sgm = first_seg + FR_SEGS;                                 // rare: more segments than staged
+      while(f.seg_prefix[sgm + 1] <= g) { sgm++; }
+      phys = f.seg_phys[sgm] + (g - f.seg_prefix[sgm]);
+    }
     i = (u64)f.I_lo[phys] | ((u64)f.I_hi[phys] << 32);
     r = (u64)f.R_lo[phys] | ((u64)f.R_hi[phys] << 32);
   }
@@ -1296,11 +1313,22 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
     // idle lanes (a suffix of the wave) borrow the last active lane's coordinates
     const u32 last_lane = 63 - (u32)__builtin_clzll(any_active);
     const u64 li = shfl_u64(i, (int)last_lane), lr = shfl_u64(r, (int)last_lane);
-    if(EMIT == 0 && active)
+    if(EMIT == 0)
     {
-      u64 slot = f.emit_base[f.step] + g;
-      if(slot < f.emit_cap) { f.emit16[slot] = (unsigned short)((i + r) & TILE_MASK); }
-      else { sink_fallback(f.bits32, i + r); }                  // exact fallback; k_tile_build_frontier skips these slots
+      // Dense emit + tile markers: bound_row[tile] = min(logical index of an element in the tile).
+      // A lane marks when the previous lane lies in another tile; lane 0 of every wave always marks
+      // (the true first element of the tile marks too and wins the minimum).  Tiles without
+      // elements are filled in by k_bound_suffix_min.
+      const u64 p = i + r;
+      const u64 my_tile = p >> TILE_SHIFT;
+      const u64 prev_tile = shfl_up_u64(my_tile, 1);
+      if(active)
+      {
+        u64 slot = f.emit_base[f.step] + g;
+        if(slot < f.emit_cap) { f.emit16[slot] = (unsigned short)(p & TILE_MASK); }
+        else { sink_fallback(f.bits32, p); }                      // exact fallback; k_tile_build_frontier skips these slots
+        if(lane == 0 || my_tile != prev_tile) { atomicMin(&f.bound_row[my_tile], (u32)g); }
+      }
     }
     u32 wb[16], wa[16];
     frontier_fetch(B.recs, B.nrecs, (active ? i : li) >> REC_SHIFT, window[wave], wb);
@@ -1331,12 +1359,6 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
     if(c == k) { my_rank = (u32)__builtin_popcountll(m & ((1ull << lane) - 1)); }
   }
   if(lane == 0) { for(u32 k = 1; k < 6; k++) { wave_cnt[wave][k] = cnt_w[k]; } }
-  if(EMIT == 0)
-  {
-    // last active lane of the wave publishes its tile for lane 0 of the next wave
-    u32 last = (any_active != 0 ? 63 - (u32)__builtin_clzll(any_active) : 0u);
-    if(lane == last) { s_last_tile[wave] = (any_active != 0 ? ((i + r) >> TILE_SHIFT) : ~0ull); }
-  }
   // Raw barrier with an LDS-only wait: __syncthreads() would also drain vmcnt and expose the latency
   // of the emit reservation / stores that are still in flight (measured: +35 ms per search).
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1359,17 +1381,6 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
     }
   }
   if(blockIdx.x == 0 && threadIdx.x == 5) { f.seg_len_next[nseg] = 0; }
-  if(EMIT == 0)
-  {
-    // First element of every tile: bound_row[tile] = min(logical index).  A lane marks its tile when
-    // the previous element lies in another tile; the block's first element always marks (the true
-    // first element of the tile, possibly in an earlier block, marks too and wins the minimum).
-    // Tiles without elements are filled in by k_bound_suffix_min.
-    const u64 my_tile = (i + r) >> TILE_SHIFT;
-    u64 prev_tile = shfl_up_u64(my_tile, 1);
-    if(lane == 0) { prev_tile = (wave > 0 ? s_last_tile[wave - 1] : ~0ull); }
-    if(active && my_tile != prev_tile) { atomicMin(&f.bound_row[my_tile], (u32)g); }
-  }
   if(active && c != 0)
   {
     u64 dst = g0 + class_base + before_waves + my_rank;
