@@ -39,8 +39,9 @@ def main():
     print("| all bwtm kernels | | | %.3f | 100 %% |" % (total / steps / 1e6))
     print()
     print("timed region: %.3f ms wall per step between first and last kernel" % ((t_end - t_begin) / steps / 1e6))
-    r = next(r for r in sel if r[2].startswith("k_lf_walk"))[3]
-    print("k_lf_walk launch geometry: grid %s x workgroup %s, VGPR %s, SGPR %s, LDS %s B" %
+    top = max(agg.items(), key=lambda kv: sum(kv[1]))[0]
+    r = next(r for r in sel if r[2] == top)[3]
+    print(top + " launch geometry: grid %s x workgroup %s, VGPR %s, SGPR %s, LDS %s B" %
           (r.get("Grid_Size_X", r.get("Grid_Size")), r.get("Workgroup_Size_X", r.get("Workgroup_Size")), r.get("VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size")))
 
 

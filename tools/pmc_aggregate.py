@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Aggregates a rocprofv3 --pmc counter_collection.csv of `bench.py --steps 1 --warmup 1` per bwtm kernel and
+counter over the launches of the LAST merge step (the timed one): for every kernel the last `n` launches, where n
+is the number of launches of that kernel in one step.  Usage: pmc_aggregate.py counter_collection.csv"""
+import csv, sys, collections
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "bwtm::" in r["Kernel_Name"]]
+per = collections.defaultdict(list)
+for r in rows:
+    name = r["Kernel_Name"].split("bwtm::")[1].split("(")[0].split("<")[0]
+    per[(name, r["Counter_Name"])].append((int(r["Start_Timestamp"]), float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+# the last merge step starts at the last k_block_stats triple -> use the start of the third-from-last k_block_stats launch
+starts = sorted(set(t for (n, c), v in per.items() if n == "k_block_stats" for t, _, _ in v))
+t0 = starts[-3] if len(starts) >= 3 else 0
+for (name, counter), v in sorted(per.items()):
+    sel = [(val, dur) for t, val, dur in v if t >= t0]
+    if sel:
+        print("%-26s %-26s launches %4d  sum %.6g  kernel_ms %.3f" % (name, counter, len(sel), sum(x for x, _ in sel), sum(d for _, d in sel) / 1e6))
