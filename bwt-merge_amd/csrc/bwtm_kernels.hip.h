@@ -1217,26 +1217,46 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_init(u32* I_lo, u8* 
 
 // Loads the records of the wave's elements.  `rec` is this lane's record index (non-decreasing
 // along the wave; idle lanes repeat the last one).  If the wave's records fit a 64-record window,
-// exactly the spanned records are fetched with fully coalesced loads and read back from LDS.
-__device__ inline void frontier_fetch(const uint4* recs, u64 nrecs, u64 rec, uint4* window, u32 w[16])
+// exactly the spanned records are fetched with fully coalesced loads (frontier_issue: up to four
+// 16-byte chunks per lane, kept in registers so that the windows of both indexes are in flight
+// together) and read back through LDS (frontier_consume).
+struct FrontierFetch { uint4 v[4]; u64 lo; bool window; };
+
+__device__ inline FrontierFetch frontier_issue(const uint4* recs, u64 nrecs, u64 rec)
 {
   const u32 lane = lane_id();
-  u64 lo = shfl_u64(rec, 0), hi = shfl_u64(rec, WAVE - 1);
-  if(hi - lo < (u64)FR_WINDOW)
+  FrontierFetch ff;
+  ff.lo = shfl_u64(rec, 0);
+  u64 hi = shfl_u64(rec, WAVE - 1);
+  ff.window = (hi - ff.lo < (u64)FR_WINDOW);
+  if(ff.window)
   {
-    u32 chunks = 4 * (u32)(hi - lo + 1);                        // 16-byte chunks to fetch (<= 256)
+    u32 chunks = 4 * (u32)(hi - ff.lo + 1);                     // 16-byte chunks to fetch (<= 256)
 #pragma unroll
     for(int k = 0; k < 4; k++)
     {
       u32 cidx = (u32)(64 * k) + lane;
-      if(cidx < chunks)
-      {
-        u64 chunk = 4 * lo + cidx;
-        window[cidx] = (chunk < 4 * nrecs ? recs[chunk] : make_uint4(0, 0, 0, 0));
-      }
+      u64 chunk = 4 * ff.lo + cidx;
+      ff.v[k] = (cidx < chunks && chunk < 4 * nrecs ? recs[chunk] : make_uint4(0, 0, 0, 0));
     }
+  }
+  else
+  {
+    const uint4* p = recs + 4 * (rec < nrecs ? rec : nrecs - 1);
+    ff.v[0] = p[0]; ff.v[1] = p[1]; ff.v[2] = p[2]; ff.v[3] = p[3];
+  }
+  return ff;
+}
+
+__device__ inline void frontier_consume(const FrontierFetch& ff, u64 rec, uint4* window, u32 w[16])
+{
+  const u32 lane = lane_id();
+  if(ff.window)
+  {
+#pragma unroll
+    for(int k = 0; k < 4; k++) { window[64 * k + lane] = ff.v[k]; }
     __builtin_amdgcn_wave_barrier();
-    u32 off = (u32)(rec - lo);
+    u32 off = (u32)(rec - ff.lo);
 #pragma unroll
     for(int k = 0; k < 4; k++)
     {
@@ -1247,7 +1267,8 @@ __device__ inline void frontier_fetch(const uint4* recs, u64 nrecs, u64 rec, uin
   }
   else
   {
-    load_record(recs, (rec < nrecs ? rec : nrecs - 1), w);
+#pragma unroll
+    for(int k = 0; k < 4; k++) { w[4 * k] = ff.v[k].x; w[4 * k + 1] = ff.v[k].y; w[4 * k + 2] = ff.v[k].z; w[4 * k + 3] = ff.v[k].w; }
   }
 }
 
@@ -1330,17 +1351,28 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
         if(lane == 0 || my_tile != prev_tile) { atomicMin(&f.bound_row[my_tile], (u32)g); }
       }
     }
-    u32 wb[16], wa[16];
-    frontier_fetch(B.recs, B.nrecs, (active ? i : li) >> REC_SHIFT, window[wave], wb);
-    frontier_fetch(A.recs, A.nrecs, (active ? r : lr) >> REC_SHIFT, window[wave], wa);
+    u32 wb[16];
+    const u64 rec_b = (active ? i : li) >> REC_SHIFT, rec_a = (active ? r : lr) >> REC_SHIFT;
+    FrontierFetch fb = frontier_issue(B.recs, B.nrecs, rec_b);
+    FrontierFetch fa = frontier_issue(A.recs, A.nrecs, rec_a);     // in flight while B's window is consumed
+    frontier_consume(fb, rec_b, window[wave], wb);
+    if(active) { c = rec_symbol(wb, (u32)(i & (REC_POS - 1))); }   // BWT_B[i]; 0 ends the chain (fmi.cpp:299)
+    u64 supb = 0, supa = 0;
+    if(active && c != 0)
+    {
+      supb = B.sup[(i >> SUPER_SHIFT) * SUP_STRIDE + c];            // L2-resident rows, requested before A's window is consumed
+      supa = A.sup[(r >> SUPER_SHIFT) * SUP_STRIDE + c];
+      ni = rec_header(wb, c) + rec_count(wb, c, (u32)(i & (REC_POS - 1)));
+    }
+    u32 wa[16];
+    frontier_consume(fa, rec_a, window[wave], wa);
     if(active)
     {
-      const u32 jb = (u32)(i & (REC_POS - 1)), ja = (u32)(r & (REC_POS - 1));
-      c = rec_symbol(wb, jb);                                   // BWT_B[i]; 0 ends the chain (fmi.cpp:299)
+      const u32 ja = (u32)(r & (REC_POS - 1));
       if(c != 0)
       {
-        ni = B.sup[(i >> SUPER_SHIFT) * SUP_STRIDE + c] + rec_header(wb, c) + rec_count(wb, c, jb);
-        nr = A.sup[(r >> SUPER_SHIFT) * SUP_STRIDE + c] + rec_header(wa, c) + rec_count(wa, c, ja);
+        ni += supb;
+        nr = supa + rec_header(wa, c) + rec_count(wa, c, ja);
         // C[c]: kernel arguments cannot be indexed dynamically without scratch, hence the selects
         u64 cb = (c == 1 ? B.C[1] : (c == 2 ? B.C[2] : (c == 3 ? B.C[3] : (c == 4 ? B.C[4] : B.C[5]))));
         u64 ca = (c == 1 ? A.C[1] : (c == 2 ? A.C[2] : (c == 3 ? A.C[3] : (c == 4 ? A.C[4] : A.C[5]))));
