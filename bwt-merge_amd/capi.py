@@ -38,6 +38,7 @@ SYMBOLS = [
     ("bwtm_index_download_samples", C.c_int, [vp, p_u64, p_u64]),
     ("bwtm_rank_batch", C.c_int, [vp, p_u64, p_u8, u64, p_u64]),
     ("bwtm_inverse_select_batch", C.c_int, [vp, p_u64, u64, p_u64, p_u8]),
+    ("bwtm_find_batch", C.c_int, [vp, p_u8, p_u64, u64, p_u64, p_u64]),
     ("bwtm_extract", C.c_int, [vp, u64, u64, p_u8]),
     ("bwtm_ra_create", C.c_int, [vp, vp, C.POINTER(vp)]),
     ("bwtm_ra_buffer_bytes", u64, [vp, vp]),
@@ -211,6 +212,18 @@ class Index:
         c = np.zeros(positions.size, dtype=np.uint8)
         check(lib().bwtm_inverse_select_batch(self.h, pp, positions.size, r.ctypes.data_as(p_u64), c.ctypes.data_as(p_u8)))
         return r, c
+
+    def find(self, patterns):
+        """Backward search of a list of patterns (sequences of comp values); returns (sp, ep) arrays."""
+        lens = np.array([len(p) for p in patterns], dtype=np.uint64)
+        offsets = np.zeros(len(patterns) + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum(lens)
+        text = np.concatenate([np.asarray(p, dtype=np.uint8) for p in patterns] + [np.zeros(0, dtype=np.uint8)])
+        text, tp = _u8(text)
+        sp = np.zeros(len(patterns), dtype=np.uint64)
+        ep = np.zeros(len(patterns), dtype=np.uint64)
+        check(lib().bwtm_find_batch(self.h, tp, offsets.ctypes.data_as(p_u64), len(patterns), sp.ctypes.data_as(p_u64), ep.ctypes.data_as(p_u64)))
+        return sp, ep
 
     def extract(self, first, count):
         out = np.zeros(count, dtype=np.uint8)

@@ -182,23 +182,34 @@ struct DevBuf
   void swap(DevBuf& o) { std::swap(p, o.p); std::swap(bytes, o.bytes); }
 };
 
-// Exclusive scan of n u64 items (in place allowed).  OP 0 = sum, 1 = max.
+#define LAUNCH2D(name, kernel, gridx, gridy, block, ...) do { \
+  profile_begin(name); \
+  hipLaunchKernelGGL(kernel, dim3((unsigned)(gridx), (unsigned)(gridy)), dim3((unsigned)(block)), 0, g_ctx.stream, __VA_ARGS__); \
+  profile_end(); \
+  hipError_t le_ = hipGetLastError(); \
+  if(le_ != hipSuccess) { return fail(BWTM_ENODEV, "launch of %s failed: %s", name, hipGetErrorString(le_)); } } while(0)
+
+// Exclusive scan of `narrays` arrays of n u64 items each, `stride` items apart (in place allowed).
+// OP 0 = sum, 1 = max.
 template<int OP>
-int device_scan(const u64* in, u64* out, u64 n)
+int device_scan_multi(const u64* in, u64* out, u64 n, u64 narrays, u64 stride)
 {
-  if(n == 0) { return BWTM_OK; }
+  if(n == 0 || narrays == 0) { return BWTM_OK; }
   u64 tiles = div_up(n, SCAN_TILE);
   if(tiles == 1)
   {
-    LAUNCH("scan_apply", k_scan_apply<OP>, 1, BLOCK_THREADS, in, out, (const u64*)nullptr, n);
+    LAUNCH2D("scan_apply", k_scan_apply<OP>, 1, narrays, BLOCK_THREADS, in, out, (const u64*)nullptr, n, stride, (u64)0);
     return BWTM_OK;
   }
-  DevBuf partial; TRY(partial.alloc(tiles * sizeof(u64)));
-  LAUNCH("scan_reduce", k_scan_reduce<OP>, tiles, BLOCK_THREADS, in, partial.as<u64>(), n);
-  TRY(device_scan<OP>(partial.as<u64>(), partial.as<u64>(), tiles));
-  LAUNCH("scan_apply", k_scan_apply<OP>, tiles, BLOCK_THREADS, in, out, (const u64*)partial.as<u64>(), n);
+  DevBuf partial; TRY(partial.alloc(tiles * narrays * sizeof(u64)));
+  LAUNCH2D("scan_reduce", k_scan_reduce<OP>, tiles, narrays, BLOCK_THREADS, in, partial.as<u64>(), n, stride, tiles);
+  TRY(device_scan_multi<OP>(partial.as<u64>(), partial.as<u64>(), tiles, narrays, tiles));
+  LAUNCH2D("scan_apply", k_scan_apply<OP>, tiles, narrays, BLOCK_THREADS, in, out, (const u64*)partial.as<u64>(), n, stride, tiles);
   return BWTM_OK;                                   // `partial` returns to the pool (stream ordered)
 }
+
+template<int OP>
+int device_scan(const u64* in, u64* out, u64 n) { return device_scan_multi<OP>(in, out, n, 1, 0); }
 
 } // namespace
 
@@ -257,7 +268,7 @@ int native_samples(bwtm_index* x)
     LAUNCH("block_stats", k_block_stats, div_up(x->nblocks, BLOCK_THREADS), BLOCK_THREADS,
       x->data.as<const u8>(), x->nbytes, x->nblocks, x->cum.as<u64>(), stride);
   }
-  for(int c = 0; c < 6; c++) { TRY(device_scan<0>(x->cum.as<u64>() + c * stride, x->cum.as<u64>() + c * stride, stride)); }
+  TRY(device_scan_multi<0>(x->cum.as<u64>(), x->cum.as<u64>(), stride, 6, stride));
   LAUNCH("block_start", k_block_start, div_up(stride, BLOCK_THREADS), BLOCK_THREADS,
     x->cum.as<const u64>(), stride, stride, x->block_start.as<u64>());
   return BWTM_OK;
@@ -414,7 +425,7 @@ extern "C" int bwtm_index_from_symbols_device(const void* device_symbols, uint64
     DevBuf cnt; TRY(cnt.alloc(6 * stride * sizeof(u64), true));
     LAUNCH("sym_counts", k_sym_counts, div_up(x->nrecs, BLOCK_THREADS), BLOCK_THREADS,
       (const u8*)device_symbols, bases, x->nrecs, cnt.as<u64>(), stride);
-    for(int c = 0; c < 6; c++) { TRY(device_scan<0>(cnt.as<u64>() + c * stride, cnt.as<u64>() + c * stride, stride)); }
+    TRY(device_scan_multi<0>(cnt.as<u64>(), cnt.as<u64>(), stride, 6, stride));
     u64 totals[6];
     for(int c = 0; c < 6; c++)
     {
@@ -558,6 +569,24 @@ extern "C" int bwtm_inverse_select_batch(const bwtm_index* x, const uint64_t* po
   LAUNCH("inverse_select_batch", k_inverse_select_batch, div_up(count, BLOCK_THREADS), BLOCK_THREADS, x->view(), dp.as<const u64>(), count, dr.as<u64>(), dc.as<u8>());
   HIP_TRY(hipMemcpyAsync(out_ranks, dr.p, count * 8, hipMemcpyDeviceToHost, g_ctx.stream));
   HIP_TRY(hipMemcpyAsync(out_comps, dc.p, count, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_find_batch(const bwtm_index* x, const uint8_t* patterns, const uint64_t* offsets, uint64_t count, uint64_t* out_sp, uint64_t* out_ep)
+{
+  TRY(ensure_ready());
+  if(!x || !offsets || !out_sp || !out_ep) { return fail(BWTM_EINVAL, "bwtm_find_batch: null argument"); }
+  if(count == 0) { return BWTM_OK; }
+  u64 total = offsets[count];
+  if(total > 0 && !patterns) { return fail(BWTM_EINVAL, "bwtm_find_batch: null pattern text"); }
+  DevBuf dt, doff, dsp, dep;
+  TRY(dt.alloc(total + 16)); TRY(doff.alloc((count + 1) * 8)); TRY(dsp.alloc(count * 8)); TRY(dep.alloc(count * 8));
+  if(total > 0) { HIP_TRY(hipMemcpyAsync(dt.p, patterns, total, hipMemcpyHostToDevice, g_ctx.stream)); }
+  HIP_TRY(hipMemcpyAsync(doff.p, offsets, (count + 1) * 8, hipMemcpyHostToDevice, g_ctx.stream));
+  LAUNCH("find_batch", k_find_batch, div_up(count, BLOCK_THREADS), BLOCK_THREADS, x->view(), dt.as<const u8>(), doff.as<const u64>(), count, dsp.as<u64>(), dep.as<u64>());
+  HIP_TRY(hipMemcpyAsync(out_sp, dsp.p, count * 8, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipMemcpyAsync(out_ep, dep.p, count * 8, hipMemcpyDeviceToHost, g_ctx.stream));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   return BWTM_OK;
 }

@@ -152,10 +152,13 @@ __device__ inline u64 block_reduce(u64 v, u64* lds)
   return r;
 }
 
+// blockIdx.y selects one of several equally long arrays (stride elements apart): the six sample
+// arrays of an index are scanned by one launch.
 template<int OP>
-__global__ void __launch_bounds__(BLOCK_THREADS) k_scan_reduce(const u64* in, u64* partial, u64 n)
+__global__ void __launch_bounds__(BLOCK_THREADS) k_scan_reduce(const u64* in, u64* partial, u64 n, u64 stride, u64 partial_stride)
 {
   __shared__ u64 lds[BLOCK_THREADS / WAVE];
+  in += (u64)blockIdx.y * stride; partial += (u64)blockIdx.y * partial_stride;
   u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
   u64 acc = 0;
   for(int k = 0; k < SCAN_ITEMS; k++) { if(base + k < n) { acc = scan_op<OP>(acc, in[base + k]); } }
@@ -165,9 +168,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_scan_reduce(const u64* in, u6
 
 // Exclusive scan of one tile; carry[blockIdx.x] (may be null for a single tile) is added.
 template<int OP>
-__global__ void __launch_bounds__(BLOCK_THREADS) k_scan_apply(const u64* in, u64* out, const u64* carry, u64 n)
+__global__ void __launch_bounds__(BLOCK_THREADS) k_scan_apply(const u64* in, u64* out, const u64* carry, u64 n, u64 stride, u64 carry_stride)
 {
   __shared__ u64 lds[BLOCK_THREADS / WAVE];
+  in += (u64)blockIdx.y * stride; out += (u64)blockIdx.y * stride;
+  if(carry) { carry += (u64)blockIdx.y * carry_stride; }
   u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
   u64 item[SCAN_ITEMS];
   u64 acc = 0;
@@ -482,6 +487,38 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_extract(IndexView x, u64 firs
   u64 wbase = (i >> REC_SHIFT) * REC_WORDS + ((i >> 5) & 3) * 4;
   u32 t = (u32)(i & 31);
   out[k] = (u8)(((words[wbase] >> t) & 1u) | (((words[wbase + 1] >> t) & 1u) << 1) | (((words[wbase + 2] >> t) & 1u) << 2));
+}
+
+// Backward search of a batch of patterns (FMI::find, fmi.h:195-209): one lane per pattern.
+// Patterns are comp values, concatenated; pattern k is text[offsets[k] .. offsets[k + 1]).
+// Output: closed range [sp, ep] (empty when sp > ep, like Range::empty).
+__global__ void __launch_bounds__(BLOCK_THREADS) k_find_batch(IndexView x, const u8* text, const u64* offsets, u64 count, u64* out_sp, u64* out_ep)
+{
+  u64 k = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(k >= count) { return; }
+  u64 begin = offsets[k], end = offsets[k + 1];
+  if(begin == end) { out_sp[k] = 0; out_ep[k] = x.n - 1; return; }              // fmi.h:198
+  u64 pos = end - 1;
+  u32 c = text[pos];
+  if(c >= 6) { out_sp[k] = 1; out_ep[k] = 0; return; }
+  u64 Cc[7];
+#pragma unroll
+  for(int j = 0; j < 7; j++) { Cc[j] = x.C[j]; }
+  auto C_of = [&](u32 cc) { return (cc == 0 ? Cc[0] : (cc == 1 ? Cc[1] : (cc == 2 ? Cc[2] : (cc == 3 ? Cc[3] : (cc == 4 ? Cc[4] : (cc == 5 ? Cc[5] : Cc[6])))))); };
+  u64 sp = C_of(c), ep = C_of(c + 1) - 1;                                         // charRange, utils.h:318-323
+  while(sp + 1 <= ep + 1 && pos > begin)                                          // !Range::empty(range)
+  {
+    pos--;
+    c = text[pos];
+    if(c >= 6) { sp = 1; ep = 0; break; }
+    u64 rs[6], re[6];
+    index_ranks(x, sp, rs); index_ranks(x, (ep + 1 > x.n ? x.n : ep + 1), re);
+    u64 a, b;
+    if(c == 0) { a = sp - (rs[1] + rs[2] + rs[3] + rs[4] + rs[5]); b = (ep + 1) - (re[1] + re[2] + re[3] + re[4] + re[5]); }
+    else { a = (c == 1 ? rs[1] : (c == 2 ? rs[2] : (c == 3 ? rs[3] : (c == 4 ? rs[4] : rs[5])))); b = (c == 1 ? re[1] : (c == 2 ? re[2] : (c == 3 ? re[3] : (c == 4 ? re[4] : re[5])))); }
+    sp = C_of(c) + a; ep = C_of(c) + b - 1;                                       // LF(range, c), utils.h:350-355
+  }
+  out_sp[k] = sp; out_ep[k] = ep;
 }
 
 //------------------------------------------------------------------------------

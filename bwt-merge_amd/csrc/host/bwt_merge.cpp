@@ -39,7 +39,8 @@ static size_type readRows(const std::string& filename, std::vector<std::string>&
   return chars;
 }
 
-// Adds the number of occurrences of every pattern to `results`.
+// Adds the number of occurrences of every pattern to `results` (reference verifyFMI / queryFMI,
+// bwt_merge.cpp:240-285).  The backward searches run on the GPU in one batch.
 static void verifyFMI(const FMI& fmi, const std::string& name, const std::vector<std::string>& patterns, std::vector<size_type>& results)
 {
   size_type chars = 0;
@@ -48,23 +49,23 @@ static void verifyFMI(const FMI& fmi, const std::string& name, const std::vector
   if(chars > 0)
   {
     double start = readTimer();
-    std::atomic<size_type> found(0), matches(0), next(0);
-    std::vector<std::thread> workers;
-    for(size_type t = 0; t < Parallel::max_threads; t++)
+    std::vector<byte_type> text; text.reserve(chars);
+    std::vector<uint64_t> offsets(patterns.size() + 1, 0), sp(patterns.size()), ep(patterns.size());
+    for(size_type k = 0; k < patterns.size(); k++)
     {
-      workers.emplace_back([&]()
-      {
-        size_type f = 0, m = 0;
-        for(size_type k = next++; k < patterns.size(); k = next++)
-        {
-          range_type range = fmi.find(patterns[k]);
-          results[k] += Range::length(range);
-          if(!Range::empty(range)) { f++; m += Range::length(range); }
-        }
-        found += f; matches += m;
-      });
+      for(char ch : patterns[k]) { text.push_back(fmi.alpha.char2comp[(byte_type)ch]); }
+      offsets[k + 1] = text.size();
     }
-    for(std::thread& w : workers) { w.join(); }
+    bwtm_index* ix = fmi.bwt.upload(fmi.alpha.C);
+    gpuCheck(bwtm_find_batch(ix, text.data(), offsets.data(), patterns.size(), sp.data(), ep.data()), "verifyFMI()");
+    bwtm_index_free(ix);
+    size_type found = 0, matches = 0;
+    for(size_type k = 0; k < patterns.size(); k++)
+    {
+      range_type range(sp[k], ep[k]);
+      results[k] += Range::length(range);
+      if(!Range::empty(range)) { found++; matches += Range::length(range); }
+    }
     printTime(name, found, matches, chars, readTimer() - start);
   }
   std::cout << std::endl;

@@ -101,6 +101,11 @@ int bwtm_rank_batch(const bwtm_index* index, const uint64_t* positions, const ui
                     uint64_t count, uint64_t* out_ranks);
 int bwtm_inverse_select_batch(const bwtm_index* index, const uint64_t* positions, uint64_t count,
                               uint64_t* out_ranks, uint8_t* out_comps);
+/* Backward search of `count` patterns (FMI::find, fmi.h:195-209; what bwt_merge -v runs, bwt_merge.cpp:240-260).
+   Pattern k is the comp values patterns[offsets[k] .. offsets[k + 1]); results are closed ranges
+   [sp, ep], empty when sp > ep; the empty pattern matches [0, bases - 1]. */
+int bwtm_find_batch(const bwtm_index* index, const uint8_t* patterns, const uint64_t* offsets, uint64_t count,
+                    uint64_t* out_sp, uint64_t* out_ep);
 /* Plain symbols [first, first + count) (BWT::extract, bwt.h:134-164), one byte each. */
 int bwtm_extract(const bwtm_index* index, uint64_t first, uint64_t count, uint8_t* out);
 

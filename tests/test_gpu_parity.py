@@ -236,3 +236,62 @@ def test_partitioned_emit_rounds_fallbacks_and_variants(gpu, oracle):
         for k in ("walk_blocks", "walk_variant", "emit_path", "walk_kernel", "scatter_kernel", "l1_cap", "search_algo"):
             gpu.tune(k, 0)
         gpu.tune("round_emits", 1 << 33)
+
+
+def test_find_batch_matches_oracle_backward_search(gpu, oracle):
+    """FMI::find on the device (bwt_merge -v) against the oracle's backward search."""
+    t = oracle.generate_reads(77, 600, 80)
+    f = oracle.FMI.from_text(t)
+    ix = gpu.Index.upload(f.data, f.sequences, f.bases)
+    rng = np.random.default_rng(4)
+    pats = [np.zeros(0, dtype=np.uint8)]
+    for _ in range(300):
+        p = int(rng.integers(0, t.size - 30))
+        s = t[p:p + int(rng.integers(1, 25))]
+        pats.append(s[s != 0][:20] if rng.random() < 0.7 else rng.integers(1, 6, int(rng.integers(1, 12))).astype(np.uint8))
+    pats = [p for p in pats]
+    sp, ep = ix.find(pats)
+    for k, p in enumerate(pats):
+        osp, oep = oracle.FMI.find(f, p)
+        empty_o = (osp + 1) % (1 << 64) > (oep + 1) % (1 << 64)
+        empty_g = (int(sp[k]) + 1) % (1 << 64) > (int(ep[k]) + 1) % (1 << 64)
+        assert empty_o == empty_g, k
+        if not empty_o:
+            assert (int(sp[k]), int(ep[k])) == (osp, oep), k
+
+
+def test_mid_size_properties_merge_tree_associativity(gpu, oracle):
+    """Size-independent properties at a size the brute force cannot reach (2 x 3e5 reads = 60 Mbase):
+    the same collection merged along different trees gives the same bytes, the counts add up, and
+    reads extracted from the merged index by LF walk equal the generator's."""
+    import torch
+    from bwt_merge_amd import synth
+    dev = torch.device("cuda", 0)
+    n, L = 300_000, 100
+
+    def leaf(seed, first, count):
+        sym = synth.leaf_bwt(synth.generate_reads(seed, first, count, L, device=dev)).contiguous()
+        torch.cuda.synchronize()
+        return gpu.Index.from_symbols_device(sym.data_ptr(), sym.numel())
+
+    quarters = [(1001, 0, n // 2), (1001, n // 2, n - n // 2), (1002, 0, n // 2), (1002, n // 2, n - n // 2)]
+    # ((q0 + q1) + (q2 + q3))
+    a = synth.merge_indexes(gpu, leaf(*quarters[0]), leaf(*quarters[1]))
+    b = synth.merge_indexes(gpu, leaf(*quarters[2]), leaf(*quarters[3]))
+    m1 = gpu.merge(a, b)
+    # (((q0 + q1) + q2) + q3)
+    c = synth.merge_indexes(gpu, synth.merge_indexes(gpu, leaf(*quarters[0]), leaf(*quarters[1])), leaf(*quarters[2]))
+    m2 = gpu.merge(c, leaf(*quarters[3]))
+    d1, d2 = m1.data(), m2.data()
+    assert np.array_equal(d1, d2)
+    assert m1.bases == 2 * n * (L + 1) and m1.sequences == 2 * n
+    assert np.array_equal(m1.C, a.C + b.C)
+    be1, cum1 = m1.samples(); be2, cum2 = m2.samples()
+    assert np.array_equal(be1, be2) and np.array_equal(cum1, cum2)
+    # the stream decodes back to the same index (header check in upload) and sampled reads come out
+    r = gpu.Index.upload(d1, m1.sequences, m1.bases)
+    ids = np.sort(np.random.default_rng(8).integers(0, 2 * n, 64))
+    got = synth.extract_sequences(gpu, r, ids, max_len=L + 8)
+    for j, seq in zip(ids, got):
+        seed, idx = (1001, int(j)) if j < n else (1002, int(j - n))
+        assert seq == synth.generate_reads(seed, idx, 1, L)[0].tolist()
