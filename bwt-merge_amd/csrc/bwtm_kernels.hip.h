@@ -1211,7 +1211,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_tile_build(const unsigned sho
 // with equal suffixes); here every sequence keeps its own element, which yields the same multiset
 // of ranks.
 
-constexpr int FR_BLOCK = 512;                  // elements (= threads) per block
+constexpr int FR_BLOCK = 256;                  // elements (= threads) per block
 constexpr int FR_WINDOW = 64;                  // records per wave window
 constexpr int FR_SEGS = 31;                    // segment-table entries staged per block
 

@@ -295,3 +295,35 @@ def test_mid_size_properties_merge_tree_associativity(gpu, oracle):
     for j, seq in zip(ids, got):
         seed, idx = (1001, int(j)) if j < n else (1002, int(j - n))
         assert seq == synth.generate_reads(seed, idx, 1, L)[0].tolist()
+
+
+def test_sharded_search_with_caller_owned_buffers(gpu, oracle):
+    """What bench.py does at N > 1, on one GPU: every 'rank' searches its shard into its own zeroed
+    tensor, the tensors are summed (= all_reduce(SUM) = OR, the bits are disjoint), and the result is
+    finalized, interleaved and encoded."""
+    import torch
+    from bwt_merge_amd.dist import shard_range
+    a, b, ta, tb = reads_pair(oracle, 1500, 1300, 90, 110, seed=5)
+    A = gpu.Index.upload(a.data, a.sequences, a.bases)
+    B = gpu.Index.upload(b.data, b.sequences, b.bases)
+    world = 3
+    nbytes = gpu.ra_buffer_bytes(A, B)
+    bufs = []
+    for rank in range(world):
+        buf = torch.zeros(nbytes // 8, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        ra = gpu.RankArray(A, B, buf.data_ptr(), nbytes)
+        first, last = shard_range(b.sequences, rank, world)
+        ra.search(A, B, first, last)
+        gpu.synchronize()
+        ra.free()
+        bufs.append(buf)
+    total = bufs[0] + bufs[1] + bufs[2]
+    torch.cuda.synchronize()
+    ra = gpu.RankArray(A, B, total.data_ptr(), nbytes)
+    ra.finalize()
+    assert ra.values == b.bases
+    M = gpu.interleave(A, B, ra).encode()
+    m, _ = oracle.merge(a, b, threads=2)
+    assert np.array_equal(M.data(), m.data)
+    ra.free()
