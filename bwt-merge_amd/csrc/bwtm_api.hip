@@ -836,10 +836,10 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   const u64 nseg = 5 * nb_max;
   const u64 fcap = nb_max * FR_BLOCK;
 
-  DevBuf lo_i[2], hi_i[2], lo_r[2], hi_r[2], seg_len[2], seg_phys[2], seg_prefix, emit16, emit_base, bound;
+  DevBuf lo[2], hi[2], seg_len[2], seg_phys[2], seg_prefix, emit16, emit_base, bound;
   for(int k = 0; k < 2; k++)
   {
-    TRY(lo_i[k].alloc(fcap * 4)); TRY(hi_i[k].alloc(fcap)); TRY(lo_r[k].alloc(fcap * 4)); TRY(hi_r[k].alloc(fcap));
+    TRY(lo[k].alloc(fcap * 8)); TRY(hi[k].alloc(fcap * 2));
     TRY(seg_len[k].alloc((nseg + 1) * sizeof(u64), true)); TRY(seg_phys[k].alloc((nseg + 1) * sizeof(u64), true));
   }
   TRY(seg_prefix.alloc((nseg + 1) * sizeof(u64)));
@@ -855,7 +855,7 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   HIP_TRY(hipMemsetAsync(bound.p, 0xFF, EPOCH * (ntiles + 1) * sizeof(u32), g_ctx.stream));
 
   u64 init_items = (fcap > nseg + 1 ? fcap : nseg + 1);
-  LAUNCH("frontier_init", k_frontier_init, div_up(init_items, BLOCK_THREADS), BLOCK_THREADS, lo_i[0].as<u32>(), hi_i[0].as<u8>(), lo_r[0].as<u32>(), hi_r[0].as<u8>(),
+  LAUNCH("frontier_init", k_frontier_init, div_up(init_items, BLOCK_THREADS), BLOCK_THREADS, lo[0].as<uint2>(), hi[0].as<unsigned short>(),
     seg_len[0].as<u64>(), seg_phys[0].as<u64>(), nb_max, seq_first, count, a->m);
   int cur = 0;
   u64 in_epoch = 0;
@@ -871,8 +871,8 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
     }
     LAUNCH("frontier_prep", k_frontier_prep, 1, WAVE, seg_prefix.as<const u64>(), nseg, emit_base.as<u64>(), in_epoch);
     FrontierView f;
-    f.I_lo = lo_i[cur].as<const u32>(); f.I_hi = hi_i[cur].as<const u8>(); f.R_lo = lo_r[cur].as<const u32>(); f.R_hi = hi_r[cur].as<const u8>();
-    f.In_lo = lo_i[1 - cur].as<u32>(); f.In_hi = hi_i[1 - cur].as<u8>(); f.Rn_lo = lo_r[1 - cur].as<u32>(); f.Rn_hi = hi_r[1 - cur].as<u8>();
+    f.lo = lo[cur].as<const uint2>(); f.hi = hi[cur].as<const unsigned short>();
+    f.lo_next = lo[1 - cur].as<uint2>(); f.hi_next = hi[1 - cur].as<unsigned short>();
     f.seg_prefix = seg_prefix.as<const u64>(); f.seg_phys = seg_phys[cur].as<const u64>();
     f.seg_len_next = seg_len[1 - cur].as<u64>(); f.seg_phys_next = seg_phys[1 - cur].as<u64>();
     f.nb_max = nb_max;
@@ -905,7 +905,10 @@ extern "C" int bwtm_search(const bwtm_index* a, const bwtm_index* b, uint64_t se
   if(b->m == 0 || seq_first > seq_last) { return BWTM_OK; }       // empty range (utils.h:80-83)
   if(seq_last >= b->m) { return fail(BWTM_EINVAL, "bwtm_search: sequence %llu out of range (%llu sequences)", (unsigned long long)seq_last, (unsigned long long)b->m); }
   u64 count = seq_last - seq_first + 1;
-  if(g_tune.search_algo == 0 && g_tune.emit_path == 0 && g_tune.walk_kernel == 0) { return search_frontier(a, b, seq_first, count, ra); }
+  // The level-synchronous search costs a few launches per LF step, i.e. per symbol of the LONGEST sequence:
+  // it is the product path for read collections; collections of very long sequences take the per-chain walk.
+  const u64 avg_len = b->n / (b->m > 0 ? b->m : 1);
+  if(g_tune.search_algo == 0 && g_tune.emit_path == 0 && g_tune.walk_kernel == 0 && avg_len <= 4096) { return search_frontier(a, b, seq_first, count, ra); }
   if(g_tune.emit_path == 0 && g_tune.walk_emit == 0 && g_tune.walk_kernel == 0) { return search_partitioned(a, b, seq_first, count, ra); }
   return search_atomic(a, b, seq_first, count, ra);
 }

@@ -1217,9 +1217,10 @@ constexpr int FR_SEGS = 31;                    // segment-table entries staged p
 
 struct FrontierView
 {
-  // Coordinates are 40-bit: low 32 bits and high byte in separate arrays (10 bytes per element).
-  const u32* I_lo; const u8* I_hi; const u32* R_lo; const u8* R_hi;      // current frontier (physical layout)
-  u32* In_lo; u8* In_hi; u32* Rn_lo; u8* Rn_hi;                          // next frontier
+  // Coordinates are 40-bit: the low words of (i, r) share one 8-byte entry, the high bytes one
+  // 2-byte entry (10 bytes per element in two arrays).
+  const uint2* lo; const unsigned short* hi;                             // current frontier (physical layout)
+  uint2* lo_next; unsigned short* hi_next;                               // next frontier
   const u64* seg_prefix;                       // exclusive scan of seg_len (5 * nb_max + 1 entries); last = N_t
   const u64* seg_phys;                         // physical start of every segment
   u64* seg_len_next; u64* seg_phys_next;       // produced for the next step
@@ -1233,14 +1234,14 @@ struct FrontierView
   u64 step;
 };
 
-__global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_init(u32* I_lo, u8* I_hi, u32* R_lo, u8* R_hi, u64* seg_len, u64* seg_phys, u64 nb_max,
+__global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_init(uint2* lo, unsigned short* hi, u64* seg_len, u64* seg_phys, u64 nb_max,
   u64 seq_first, u64 count, u64 m_a)
 {
   u64 g = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
   if(g < count)
   {
     u64 i = seq_first + g;                                                // fmi.cpp:286: trie root "$"
-    I_lo[g] = (u32)i; I_hi[g] = (u8)(i >> 32); R_lo[g] = (u32)m_a; R_hi[g] = (u8)(m_a >> 32);
+    lo[g] = make_uint2((u32)i, (u32)m_a); hi[g] = (unsigned short)(((i >> 32) & 0xFF) | (((m_a >> 32) & 0xFF) << 8));
   }
   if(g < 5 * nb_max)
   {
@@ -1328,11 +1329,22 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
     if(blockIdx.x == 0 && threadIdx.x == 5) { f.seg_len_next[nseg] = 0; }
     return;
   }
-  if(threadIdx.x == 0)
+  if(wave == 0)
   {
-    u64 lo = 0, hi = nseg;                     // seg_prefix[lo] <= g0 < seg_prefix[hi]
-    while(hi - lo > 1) { u64 mid = (lo + hi) >> 1; if(f.seg_prefix[mid] <= g0) { lo = mid; } else { hi = mid; } }
-    s_first_seg = lo;
+    // 64-ary search by the first wave: seg_prefix[lo] <= g0 < seg_prefix[hi]  (4 rounds for 1M entries
+    // instead of 20 dependent loads of a binary search)
+    u64 lo = 0, hi = nseg;
+    while(hi - lo > 1)
+    {
+      u64 stepsz = (hi - lo + WAVE - 1) / WAVE;
+      u64 idx = lo + (u64)lane * stepsz;
+      bool le = (idx < hi ? f.seg_prefix[idx] <= g0 : false);
+      u32 k = (u32)__builtin_popcountll(__ballot(le));           // lanes 0 .. k-1 hold entries <= g0 (monotone), k >= 1
+      u64 nlo = lo + (u64)(k - 1) * stepsz;
+      u64 nhi = nlo + stepsz; if(nhi > hi) { nhi = hi; }
+      lo = nlo; hi = nhi;
+    }
+    if(lane == 0) { s_first_seg = lo; }
   }
   __syncthreads();
   // The block's elements live in a handful of segments: stage their table entries in LDS.
@@ -1360,8 +1372,9 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
       while(f.seg_prefix[sgm + 1] <= g) { sgm++; }
       phys = f.seg_phys[sgm] + (g - f.seg_prefix[sgm]);
     }
-    i = (u64)f.I_lo[phys] | ((u64)f.I_hi[phys] << 32);
-    r = (u64)f.R_lo[phys] | ((u64)f.R_hi[phys] << 32);
+    uint2 l = f.lo[phys]; u32 h = f.hi[phys];
+    i = (u64)l.x | ((u64)(h & 0xFF) << 32);
+    r = (u64)l.y | ((u64)(h >> 8) << 32);
   }
   const u64 any_active = __ballot(active);
   u32 c = 0;
@@ -1453,8 +1466,8 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
   if(active && c != 0)
   {
     u64 dst = g0 + class_base + before_waves + my_rank;
-    f.In_lo[dst] = (u32)ni; f.In_hi[dst] = (u8)(ni >> 32);
-    f.Rn_lo[dst] = (u32)nr; f.Rn_hi[dst] = (u8)(nr >> 32);
+    f.lo_next[dst] = make_uint2((u32)ni, (u32)nr);
+    f.hi_next[dst] = (unsigned short)(((ni >> 32) & 0xFF) | (((nr >> 32) & 0xFF) << 8));
   }
 }
 
