@@ -136,6 +136,61 @@ BWTM_HD void range_mask128(u32 from, u32 count, u64& lo, u64& hi)
 //------------------------------------------------------------------------------
 // Native run codec (support.h:221-286), decode side.  Reads one run at data[pos...].
 
+//------------------------------------------------------------------------------
+// Interleave helpers (mergeBWT, bwt.cpp:215-282).
+
+// Bit deposit ("expand", the inverse of compress): bit k of x goes to the position of the k-th
+// set bit of m.  The move masks depend on m only, so they are computed once and shared by the
+// three planes.  32-bit words: 5 rounds of a 5-step parallel suffix.
+struct ExpandMasks { u32 mv[5]; u32 m; };
+
+BWTM_HD ExpandMasks expand_masks(u32 m)
+{
+  ExpandMasks e; e.m = m;
+  u32 mk = ~m << 1;                           // counts the zeros to the right
+#pragma unroll
+  for(int i = 0; i < 5; i++)
+  {
+    u32 mp = mk ^ (mk << 1);
+    mp ^= mp << 2; mp ^= mp << 4; mp ^= mp << 8; mp ^= mp << 16;
+    u32 mv = mp & m;                          // bits that move by 1 << i
+    e.mv[i] = mv;
+    m = (m ^ mv) | (mv >> (1u << i));
+    mk &= ~mp;
+  }
+  return e;
+}
+
+BWTM_HD u32 expand32(u32 x, const ExpandMasks& e)
+{
+#pragma unroll
+  for(int i = 4; i >= 0; i--)
+  {
+    u32 t = x << (1u << i);
+    x = (x & ~e.mv[i]) | (t & e.mv[i]);
+  }
+  return x & e.m;
+}
+
+// Deposits the next symbols of A (where the mask bit is 0) and B (where it is 1) into 64
+// output positions.  a* / b* are 64-bit windows of the source planes.
+BWTM_HD void deposit64(u64 mask, u64 a0, u64 a1, u64 a2, u64 b0, u64 b1, u64 b2, u64& o0, u64& o1, u64& o2)
+{
+  u32 m = (u32)mask;
+  ExpandMasks eb = expand_masks(m), ea = expand_masks(~m);
+  u32 l0 = expand32((u32)b0, eb) | expand32((u32)a0, ea);
+  u32 l1 = expand32((u32)b1, eb) | expand32((u32)a1, ea);
+  u32 l2 = expand32((u32)b2, eb) | expand32((u32)a2, ea);
+  u32 nb = (u32)__builtin_popcount(m), na = 32 - nb;      // a 64-bit shift by 32 is fine (nb, na <= 32)
+  b0 >>= nb; b1 >>= nb; b2 >>= nb; a0 >>= na; a1 >>= na; a2 >>= na;
+  m = (u32)(mask >> 32);
+  eb = expand_masks(m); ea = expand_masks(~m);
+  u32 h0 = expand32((u32)b0, eb) | expand32((u32)a0, ea);
+  u32 h1 = expand32((u32)b1, eb) | expand32((u32)a1, ea);
+  u32 h2 = expand32((u32)b2, eb) | expand32((u32)a2, ea);
+  o0 = (u64)l0 | ((u64)h0 << 32); o1 = (u64)l1 | ((u64)h1 << 32); o2 = (u64)l2 | ((u64)h2 << 32);
+}
+
 BWTM_HD void run_decode(const u8* data, u64& pos, u32& sym, u64& len)
 {
   u32 code = data[pos]; pos++;

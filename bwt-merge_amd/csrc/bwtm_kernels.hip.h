@@ -1523,12 +1523,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_tile_build_frontier(const uns
   for(u32 k = threadIdx.x; k < (1u << (TILE_SHIFT - 5)); k += BLOCK_THREADS) { tile[k] = 0; }
   if(threadIdx.x == 0) { any = 0; }
   __syncthreads();
-  for(u64 t = 0; t < nsteps; t++)
+  // each wave takes every (BLOCK_THREADS / WAVE)-th step, so several bound -> run load chains are in flight
+  bool seen = false;
+  for(u64 t = threadIdx.x >> 6; t < nsteps; t += BLOCK_THREADS / WAVE)
   {
     const u32* row = bound + t * (ntiles + 1);
     u32 lo = row[T], hi = row[T + 1];
     const u64 base = emit_base[t];
-    for(u32 k = lo + threadIdx.x; k < hi; k += BLOCK_THREADS)
+    for(u32 k = lo + lane_id(); k < hi; k += WAVE)
     {
       if(base + k < emit_cap)
       {
@@ -1536,8 +1538,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_tile_build_frontier(const uns
         atomicOr(&tile[off >> 5], 1u << (off & 31));
       }
     }
-    if(threadIdx.x == 0 && hi > lo) { any = 1; }
+    seen |= (hi > lo);
   }
+  if(seen && lane_id() == 0) { any = 1; }
   __syncthreads();
   if(any == 0) { return; }
   u64 w0 = T << (TILE_SHIFT - 6);
@@ -1610,24 +1613,6 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_interleave_sup(IndexView A, I
   index_ranks(A, a_off, ra); index_ranks(B, b_off, rb);
   for(int c = 0; c < SUP_STRIDE; c++) { sup[s * SUP_STRIDE + c] = (c >= 1 && c < 6 ? ra[c] + rb[c] : 0); }
   (void)n_out;
-}
-
-// Deposits the next symbols of A (where the mask bit is 0) and B (where it is 1) into 64
-// output positions.  a* / b* are 64-bit windows of the source planes.
-__device__ inline void deposit64(u64 mask, u64 a0, u64 a1, u64 a2, u64 b0, u64 b1, u64 b2, u64& o0, u64& o1, u64& o2)
-{
-  o0 = 0; o1 = 0; o2 = 0;
-  for(u32 t = 0; t < 64; t++)
-  {
-    u64 bit = (mask >> t) & 1;
-    u64 sel = 0 - bit;                        // all ones when the symbol comes from B
-    o0 |= ((((b0 & sel) | (a0 & ~sel))) & 1) << t;
-    o1 |= ((((b1 & sel) | (a1 & ~sel))) & 1) << t;
-    o2 |= ((((b2 & sel) | (a2 & ~sel))) & 1) << t;
-    u32 sb = (u32)bit, sa = 1u - sb;
-    b0 >>= sb; b1 >>= sb; b2 >>= sb;
-    a0 >>= sa; a1 >>= sa; a2 >>= sa;
-  }
 }
 
 __global__ void __launch_bounds__(BLOCK_THREADS) k_interleave(IndexView A, IndexView B, const u64* bits, const u64* chunk_base,

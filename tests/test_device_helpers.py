@@ -28,6 +28,7 @@ def shim():
     L.shim_rec_count.restype = u32; L.shim_rec_count.argtypes = [C.c_void_p, u32, u32]
     L.shim_rec_symbol.restype = u32; L.shim_rec_symbol.argtypes = [C.c_void_p, u32]
     L.shim_range_mask128.argtypes = [u32, u32, C.c_void_p, C.c_void_p]
+    L.shim_deposit64.argtypes = [u64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.shim_run_decode.restype = u64; L.shim_run_decode.argtypes = [C.c_void_p, u64, C.c_void_p, C.c_void_p]
     return L
 
@@ -88,6 +89,29 @@ def test_range_mask(shim):
             shim.shim_range_mask128(a, n, C.byref(lo), C.byref(hi))
             v = lo.value | (hi.value << 64)
             assert v == ((1 << n) - 1) << a
+
+
+def test_deposit64_is_the_bitwise_interleave(shim):
+    """mergeBWT (bwt.cpp:215-282) restricted to 64 output positions: position t takes the next
+    symbol of B where the mask bit is set and the next symbol of A otherwise."""
+    rng = np.random.default_rng(7)
+    masks = [0, (1 << 64) - 1, 1, 1 << 63, 0xFFFFFFFF, 0xFFFFFFFF00000000, 0xAAAAAAAAAAAAAAAA]
+    masks += [int(x) for x in rng.integers(0, 1 << 63, 300, dtype=np.uint64)]
+    masks += [int(x) & int(y) & int(z) for x, y, z in rng.integers(0, 1 << 63, (100, 3), dtype=np.uint64)]   # sparse
+    masks += [(int(x) | int(y) | int(z) | (1 << 63)) for x, y, z in rng.integers(0, 1 << 63, (100, 3), dtype=np.uint64)]   # dense
+    for mask in masks:
+        a = rng.integers(0, 1 << 63, 3, dtype=np.uint64) * 2 + rng.integers(0, 2, 3, dtype=np.uint64)
+        b = rng.integers(0, 1 << 63, 3, dtype=np.uint64) * 2 + rng.integers(0, 2, 3, dtype=np.uint64)
+        o = np.zeros(3, dtype=np.uint64)
+        shim.shim_deposit64(mask, a.ctypes.data, b.ctypes.data, o.ctypes.data)
+        for plane in range(3):
+            av, bv, expect = int(a[plane]), int(b[plane]), 0
+            for t in range(64):
+                if (mask >> t) & 1:
+                    expect |= (bv & 1) << t; bv >>= 1
+                else:
+                    expect |= (av & 1) << t; av >>= 1
+            assert int(o[plane]) == expect, (hex(mask), plane)
 
 
 def test_run_decode_matches_oracle(shim, oracle):
