@@ -96,8 +96,9 @@ def main():
 
     # ---------------------------------------------------------------- one step
     def step(keep=False):
-        A = pkg.Index.from_device(ptr_a, bytes_a, A0.sequences, n_a)
-        B = pkg.Index.from_device(ptr_b, bytes_b, B0.sequences, n_b)
+        # BWT::load of both inputs: the resident native bytes are read in place (no second copy in HBM)
+        A = pkg.Index.from_device(ptr_a, bytes_a, A0.sequences, n_a, borrow=True)
+        B = pkg.Index.from_device(ptr_b, bytes_b, B0.sequences, n_b, borrow=True)
         if world == 1:
             M = pkg.merge(A, B)
         else:

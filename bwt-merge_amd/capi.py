@@ -24,6 +24,7 @@ SYMBOLS = [
     ("bwtm_tune", C.c_int, [C.c_char_p, C.c_longlong]),
     ("bwtm_index_upload", C.c_int, [p_u8, u64, u64, u64, p_u64, C.POINTER(vp)]),
     ("bwtm_index_from_device", C.c_int, [vp, u64, u64, u64, p_u64, C.POINTER(vp)]),
+    ("bwtm_index_from_device_borrowed", C.c_int, [vp, u64, u64, u64, p_u64, C.POINTER(vp)]),
     ("bwtm_index_from_symbols_device", C.c_int, [vp, u64, C.POINTER(vp)]),
     ("bwtm_index_free", None, [vp]),
     ("bwtm_index_bases", u64, [vp]),
@@ -147,12 +148,14 @@ class Index:
         return Index(out)
 
     @staticmethod
-    def from_device(ptr, nbytes, sequences, bases, C_array=None):
+    def from_device(ptr, nbytes, sequences, bases, C_array=None, borrow=False):
+        """borrow=True: the index reads the caller's buffer in place (it must outlive the index)."""
         out = vp()
         cp = None
         if C_array is not None:
             C_array, cp = _u64(C_array)
-        check(lib().bwtm_index_from_device(vp(ptr), nbytes, sequences, bases, cp, C.byref(out)))
+        f = lib().bwtm_index_from_device_borrowed if borrow else lib().bwtm_index_from_device
+        check(f(vp(ptr), nbytes, sequences, bases, cp, C.byref(out)))
         return Index(out)
 
     @staticmethod

@@ -225,6 +225,8 @@ struct bwtm_index
   // Native form (present after upload or encode):
   bool has_native = false;
   DevBuf data; u64 nbytes = 0; u64 nblocks = 0;
+  const void* borrowed = nullptr;     // caller-owned native bytes (bwtm_index_from_device_borrowed) instead of `data`
+  const u8* native_bytes() const { return borrowed ? (const u8*)borrowed : data.as<const u8>(); }
   DevBuf cum;                         // 6 x (nblocks + 1) u64: cumulative symbol counts at block starts
   DevBuf block_start;                 // nblocks + 1 u64
 
@@ -256,17 +258,28 @@ struct bwtm_ra
 namespace
 {
 
+// Buffer for a native byte stream: 16 zero bytes of padding keep the last partial block readable with
+// 16-byte loads.  Only the padding is cleared; the stream itself is written by the caller.
+int alloc_native(DevBuf& buf, u64 nbytes)
+{
+  TRY(buf.alloc(nbytes + 16));
+  HIP_TRY(hipMemsetAsync((u8*)buf.p + nbytes, 0, 16, g_ctx.stream));
+  return BWTM_OK;
+}
+
 // Per-block statistics + scans of a native byte stream: fills cum and block_start.
 int native_samples(bwtm_index* x)
 {
   x->nblocks = div_up(x->nbytes, RLE_BLOCK);
   u64 stride = x->nblocks + 1;
-  TRY(x->cum.alloc(6 * stride * sizeof(u64), true));
+  TRY(x->cum.alloc(6 * stride * sizeof(u64)));
   TRY(x->block_start.alloc(stride * sizeof(u64)));
+  // k_block_stats fills columns [0, nblocks); only the extra column of the exclusive scan needs zeroing
+  HIP_TRY(hipMemset2DAsync(x->cum.as<u64>() + x->nblocks, stride * sizeof(u64), 0, sizeof(u64), 6, g_ctx.stream));
   if(x->nblocks > 0)
   {
     LAUNCH("block_stats", k_block_stats, div_up(x->nblocks, BLOCK_THREADS), BLOCK_THREADS,
-      x->data.as<const u8>(), x->nbytes, x->nblocks, x->cum.as<u64>(), stride);
+      x->native_bytes(), x->nbytes, x->nblocks, x->cum.as<u64>(), stride);
   }
   TRY(device_scan_multi<0>(x->cum.as<u64>(), x->cum.as<u64>(), stride, 6, stride));
   LAUNCH("block_start", k_block_start, div_up(stride, BLOCK_THREADS), BLOCK_THREADS,
@@ -282,10 +295,10 @@ int transcode(bwtm_index* x)
   TRY(x->sup.alloc(x->nsup * SUP_STRIDE * sizeof(u64)));
   u64 stride = x->nblocks + 1;
   LAUNCH("build_sup", k_build_sup, div_up(x->nsup, BLOCK_THREADS), BLOCK_THREADS,
-    x->data.as<const u8>(), x->nbytes, x->block_start.as<const u64>(), x->cum.as<const u64>(), stride, x->nblocks, x->n,
+    x->native_bytes(), x->nbytes, x->block_start.as<const u64>(), x->cum.as<const u64>(), stride, x->nblocks, x->n,
     x->sup.as<u64>(), x->nsup);
   LAUNCH("build_recs", k_build_recs, div_up(x->nrecs, BLOCK_THREADS), BLOCK_THREADS,   // one wave per 64 records
-    x->data.as<const u8>(), x->nbytes, x->block_start.as<const u64>(), x->cum.as<const u64>(), stride, x->nblocks, x->n,
+    x->native_bytes(), x->nbytes, x->block_start.as<const u64>(), x->cum.as<const u64>(), stride, x->nblocks, x->n,
     x->sup.as<const u64>(), x->recs.as<uint4>(), x->nrecs);
   return BWTM_OK;
 }
@@ -381,7 +394,7 @@ extern "C" int bwtm_index_upload(const uint8_t* data, uint64_t nbytes, uint64_t 
   if(!out || (nbytes > 0 && !data)) { return fail(BWTM_EINVAL, "bwtm_index_upload: null argument"); }
   bwtm_index* x = new bwtm_index();
   x->nbytes = nbytes;
-  int rc = x->data.alloc(nbytes + 16, true);      // padding keeps the last partial block readable
+  int rc = alloc_native(x->data, nbytes);
   if(rc == BWTM_OK && nbytes > 0)
   {
     hipError_t e = hipMemcpyAsync(x->data.p, data, nbytes, hipMemcpyHostToDevice, g_ctx.stream);
@@ -400,13 +413,27 @@ extern "C" int bwtm_index_from_device(const void* device_data, uint64_t nbytes, 
   if(!out || (nbytes > 0 && !device_data)) { return fail(BWTM_EINVAL, "bwtm_index_from_device: null argument"); }
   bwtm_index* x = new bwtm_index();
   x->nbytes = nbytes;
-  int rc = x->data.alloc(nbytes + 16, true);
+  int rc = alloc_native(x->data, nbytes);
   if(rc == BWTM_OK && nbytes > 0)
   {
     hipError_t e = hipMemcpyAsync(x->data.p, device_data, nbytes, hipMemcpyDeviceToDevice, g_ctx.stream);
     if(e != hipSuccess) { rc = fail(BWTM_ENODEV, "D2D copy failed: %s", hipGetErrorString(e)); }
   }
   if(rc == BWTM_OK) { rc = finish_native_index(x, sequences, bases, C); }
+  if(rc != BWTM_OK) { delete x; return rc; }
+  *out = x;
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_index_from_device_borrowed(const void* device_data, uint64_t nbytes, uint64_t sequences, uint64_t bases,
+  const uint64_t* C, bwtm_index** out)
+{
+  TRY(ensure_ready());
+  if(!out || !device_data) { return fail(BWTM_EINVAL, "bwtm_index_from_device_borrowed: null argument"); }
+  if(((uintptr_t)device_data & 15) != 0) { return fail(BWTM_EINVAL, "bwtm_index_from_device_borrowed: the buffer must be 16-byte aligned"); }
+  bwtm_index* x = new bwtm_index();
+  x->nbytes = nbytes; x->borrowed = device_data;
+  int rc = finish_native_index(x, sequences, bases, C);
   if(rc != BWTM_OK) { delete x; return rc; }
   *out = x;
   return BWTM_OK;
@@ -450,6 +477,7 @@ extern "C" int bwtm_index_from_symbols_device(const void* device_symbols, uint64
 
 extern "C" void bwtm_index_free(bwtm_index* index)
 {
+  if(index && index->borrowed) { (void)hipStreamSynchronize(g_ctx.stream); }   // queued readers of the caller's buffer
   delete index;                                     // buffers return to the pool (stream ordered)
 }
 
@@ -462,6 +490,7 @@ extern "C" void bwtm_index_C(const bwtm_index* x, uint64_t* C) { for(int c = 0; 
 extern "C" int bwtm_index_drop_native(bwtm_index* x)
 {
   if(!x) { return fail(BWTM_EINVAL, "null index"); }
+  if(x->borrowed) { HIP_TRY(hipStreamSynchronize(g_ctx.stream)); x->borrowed = nullptr; }
   x->data.release(); x->cum.release(); x->block_start.release();
   x->has_native = false; x->nbytes = 0; x->nblocks = 0;
   return BWTM_OK;
@@ -496,11 +525,11 @@ extern "C" int bwtm_index_encode(bwtm_index* x)
     HIP_TRY(hipMemcpyAsync(&total, group_base.as<u64>() + ngroups, sizeof(u64), hipMemcpyDeviceToHost, g_ctx.stream));
     HIP_TRY(hipStreamSynchronize(g_ctx.stream));
     x->nbytes = total;
-    TRY(x->data.alloc(total + 16, true));
+    TRY(alloc_native(x->data, total));
     LAUNCH("enc_emit", k_enc_emit, wave_grid, BLOCK_THREADS, x->recs.as<const uint4>(), x->nrecs, x->n, ntiles, nseg,
       lasthead.as<const u64>(), seg_base.as<const u64>(), x->data.as<u8>());
   }
-  else { TRY(x->data.alloc(16, true)); }
+  else { TRY(alloc_native(x->data, 0)); }
   TRY(native_samples(x));                       // BWT::build, bwt.cpp:476-512
   x->has_native = true;
   return BWTM_OK;
@@ -512,7 +541,7 @@ extern "C" int bwtm_index_device_data(bwtm_index* x, void** device_ptr, uint64_t
   if(!x || !device_ptr || !nbytes) { return fail(BWTM_EINVAL, "bwtm_index_device_data: null argument"); }
   if(!x->has_native) { return fail(BWTM_EINVAL, "index has no native byte stream (call bwtm_index_encode first)"); }
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-  *device_ptr = x->data.p; *nbytes = x->nbytes;
+  *device_ptr = (void*)x->native_bytes(); *nbytes = x->nbytes;
   return BWTM_OK;
 }
 
@@ -521,7 +550,7 @@ extern "C" int bwtm_index_download_data(bwtm_index* x, uint8_t* out, uint64_t ca
   TRY(ensure_ready());
   if(!x || !x->has_native) { return fail(BWTM_EINVAL, "index has no native byte stream (call bwtm_index_encode first)"); }
   if(capacity < x->nbytes) { return fail(BWTM_EINVAL, "buffer too small: %llu < %llu", (unsigned long long)capacity, (unsigned long long)x->nbytes); }
-  if(x->nbytes > 0) { HIP_TRY(hipMemcpyAsync(out, x->data.p, x->nbytes, hipMemcpyDeviceToHost, g_ctx.stream)); }
+  if(x->nbytes > 0) { HIP_TRY(hipMemcpyAsync(out, x->native_bytes(), x->nbytes, hipMemcpyDeviceToHost, g_ctx.stream)); }
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   return BWTM_OK;
 }

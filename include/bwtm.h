@@ -67,6 +67,12 @@ int bwtm_index_upload(const uint8_t* data, uint64_t nbytes, uint64_t sequences, 
 /* Same, from a device buffer that already holds the native bytes (the bytes are copied). */
 int bwtm_index_from_device(const void* device_data, uint64_t nbytes, uint64_t sequences, uint64_t bases,
                            const uint64_t C[BWTM_SIGMA + 1], bwtm_index** out);
+/* Same, without the copy: the index reads the caller's device buffer in place (BWT::load without a
+   second resident copy of BWT::data).  The buffer must be 16-byte aligned, readable up to the next
+   multiple of 16 bytes after `nbytes`, and must stay valid and unmodified until the index is freed or
+   bwtm_index_drop_native() is called (both wait for the library's queued readers). */
+int bwtm_index_from_device_borrowed(const void* device_data, uint64_t nbytes, uint64_t sequences, uint64_t bases,
+                                    const uint64_t C[BWTM_SIGMA + 1], bwtm_index** out);
 /* Builds an index directly from a plain symbol string on the device (one comp value 0..5
    per byte, `bases` of them; sequences = number of 0 symbols).  Used by the input tooling. */
 int bwtm_index_from_symbols_device(const void* device_symbols, uint64_t bases, bwtm_index** out);

@@ -63,6 +63,35 @@ def test_upload_builds_exact_rank_structure(gpu, oracle):
         ix.free()
 
 
+def test_index_from_borrowed_device_buffer(gpu, oracle):
+    """bwtm_index_from_device_borrowed reads the caller's buffer in place: same index as the copying
+    constructors, also when the bytes after the stream are garbage and the stream ends mid-block."""
+    import torch
+    rng = np.random.default_rng(11)
+    for nruns in (1, 50, 777, 3000, 4099):
+        sym = run_symbols(rng, nruns, [1, 1, 2, 3, 41, 42, 170, 5000])
+        f = oracle.FMI.from_symbols(sym)
+        host = np.full(f.nbytes + 64, 0xFF, dtype=np.uint8)         # 0xFF = continuation bytes of a long run
+        host[:f.nbytes] = f.data
+        buf = torch.from_numpy(host).to("cuda:0")
+        ix = gpu.Index.from_device(buf.data_ptr(), f.nbytes, f.sequences, f.bases, borrow=True)
+        assert (ix.sequences, ix.nbytes, ix.blocks) == (f.sequences, f.nbytes, f.blocks)
+        check_index(ix, sym, rng, nq=500)
+        be, cum = ix.samples()
+        obe, ocum = f.samples
+        assert np.array_equal(be, obe) and np.array_equal(cum, ocum)
+        assert np.array_equal(ix.data(), f.data)
+        ptr, nb = ix.device_data()
+        assert (ptr, nb) == (buf.data_ptr(), f.nbytes)
+        ix.drop_native()                                             # releases the claim on `buf`
+        del buf
+        assert np.array_equal(ix.extract(0, sym.size), sym)
+        ix.free()
+    with pytest.raises(gpu.BwtmError):
+        buf = torch.zeros(64, dtype=torch.uint8, device="cuda:0")
+        gpu.Index.from_device(buf.data_ptr() + 1, 8, 0, 8, borrow=True)   # misaligned
+
+
 def test_upload_rejects_inconsistent_header(gpu, oracle):
     f = oracle.FMI.from_symbols(np.array([1, 2, 0, 3, 0], dtype=np.uint8))
     with pytest.raises(gpu.BwtmError):
