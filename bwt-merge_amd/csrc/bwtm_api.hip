@@ -227,8 +227,9 @@ struct bwtm_index
   DevBuf data; u64 nbytes = 0; u64 nblocks = 0;
   const void* borrowed = nullptr;     // caller-owned native bytes (bwtm_index_from_device_borrowed) instead of `data`
   const u8* native_bytes() const { return borrowed ? (const u8*)borrowed : data.as<const u8>(); }
-  DevBuf cum;                         // 6 x (nblocks + 1) u64: cumulative symbol counts at block starts
   DevBuf block_start;                 // nblocks + 1 u64
+  DevBuf gcum; u64 ngroups = 0;       // 6 x (ngroups + 1) u64: cumulative symbol counts at the starts of the 62-block groups
+  DevBuf cum;                         // 6 x (nblocks + 1) u64: cumulative symbol counts at block starts (built on demand)
 
   IndexView view() const
   {
@@ -267,23 +268,37 @@ int alloc_native(DevBuf& buf, u64 nbytes)
   return BWTM_OK;
 }
 
-// Per-block statistics + scans of a native byte stream: fills cum and block_start.
-int native_samples(bwtm_index* x)
+// Scan of a native byte stream: block_start (positions before every block) and gcum (symbol counts
+// before every 62-block group).  `stream_flags` (optional) receives the k_block_len flags after the
+// next stream synchronisation.
+int native_samples(bwtm_index* x, u32* stream_flags)
 {
   x->nblocks = div_up(x->nbytes, RLE_BLOCK);
-  u64 stride = x->nblocks + 1;
+  x->ngroups = std::max<u64>(1, div_up(x->nblocks, (u64)GROUP));
+  const u64 gstride = x->ngroups + 1;
+  x->cum.release();
+  TRY(x->block_start.alloc((x->nblocks + 1) * sizeof(u64)));
+  TRY(x->gcum.alloc(6 * gstride * sizeof(u64)));
+  DevBuf flags; TRY(flags.alloc(sizeof(u32), true));
+  // the kernel fills columns [0, nblocks) / [0, ngroups); the extra column of each exclusive scan is zeroed here
+  HIP_TRY(hipMemsetAsync(x->block_start.as<u64>() + x->nblocks, 0, sizeof(u64), g_ctx.stream));
+  HIP_TRY(hipMemset2DAsync(x->gcum.as<u64>() + x->ngroups, gstride * sizeof(u64), 0, sizeof(u64), 6, g_ctx.stream));
+  LAUNCH("block_len", k_block_len, div_up(x->ngroups, BLOCK_THREADS / WAVE), BLOCK_THREADS,
+    x->native_bytes(), x->nbytes, x->nblocks, x->ngroups, x->block_start.as<u64>(), x->gcum.as<u64>(), gstride, flags.as<u32>());
+  TRY(device_scan<0>(x->block_start.as<u64>(), x->block_start.as<u64>(), x->nblocks + 1));
+  TRY(device_scan_multi<0>(x->gcum.as<u64>(), x->gcum.as<u64>(), gstride, 6, gstride));
+  if(stream_flags) { HIP_TRY(hipMemcpyAsync(stream_flags, flags.p, sizeof(u32), hipMemcpyDeviceToHost, g_ctx.stream)); }
+  return BWTM_OK;
+}
+
+// samples[c] at the block starts (bwt.cpp:489-511), from block_start and the rank structure.
+int ensure_block_cum(bwtm_index* x)
+{
+  if(x->cum.p) { return BWTM_OK; }
+  const u64 stride = x->nblocks + 1;
   TRY(x->cum.alloc(6 * stride * sizeof(u64)));
-  TRY(x->block_start.alloc(stride * sizeof(u64)));
-  // k_block_stats fills columns [0, nblocks); only the extra column of the exclusive scan needs zeroing
-  HIP_TRY(hipMemset2DAsync(x->cum.as<u64>() + x->nblocks, stride * sizeof(u64), 0, sizeof(u64), 6, g_ctx.stream));
-  if(x->nblocks > 0)
-  {
-    LAUNCH("block_stats", k_block_stats, div_up(x->nblocks, BLOCK_THREADS), BLOCK_THREADS,
-      x->native_bytes(), x->nbytes, x->nblocks, x->cum.as<u64>(), stride);
-  }
-  TRY(device_scan_multi<0>(x->cum.as<u64>(), x->cum.as<u64>(), stride, 6, stride));
-  LAUNCH("block_start", k_block_start, div_up(stride, BLOCK_THREADS), BLOCK_THREADS,
-    x->cum.as<const u64>(), stride, stride, x->block_start.as<u64>());
+  LAUNCH("block_cum", k_block_cum, div_up(stride, BLOCK_THREADS), BLOCK_THREADS,
+    x->view(), x->block_start.as<const u64>(), stride, x->cum.as<u64>(), stride);
   return BWTM_OK;
 }
 
@@ -293,12 +308,12 @@ int transcode(bwtm_index* x)
   x->nrecs = num_records(x->n); x->nsup = num_supers(x->n);
   TRY(x->recs.alloc(x->nrecs * 64));
   TRY(x->sup.alloc(x->nsup * SUP_STRIDE * sizeof(u64)));
-  u64 stride = x->nblocks + 1;
-  LAUNCH("build_sup", k_build_sup, div_up(x->nsup, BLOCK_THREADS), BLOCK_THREADS,
-    x->native_bytes(), x->nbytes, x->block_start.as<const u64>(), x->cum.as<const u64>(), stride, x->nblocks, x->n,
+  const u64 gstride = x->ngroups + 1;
+  LAUNCH("build_sup", k_build_sup, div_up(x->nsup * WAVE, BLOCK_THREADS), BLOCK_THREADS,   // one wave per super
+    x->native_bytes(), x->nbytes, x->block_start.as<const u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, x->n,
     x->sup.as<u64>(), x->nsup);
-  LAUNCH("build_recs", k_build_recs, div_up(x->nrecs, BLOCK_THREADS), BLOCK_THREADS,   // one wave per 64 records
-    x->native_bytes(), x->nbytes, x->block_start.as<const u64>(), x->cum.as<const u64>(), stride, x->nblocks, x->n,
+  LAUNCH("build_recs", k_build_recs, div_up(x->ngroups, BLOCK_THREADS / WAVE), BLOCK_THREADS,   // one wave per group
+    x->native_bytes(), x->nbytes, x->block_start.as<const u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, x->n,
     x->sup.as<const u64>(), x->recs.as<uint4>(), x->nrecs);
   return BWTM_OK;
 }
@@ -306,15 +321,15 @@ int transcode(bwtm_index* x)
 int finish_native_index(bwtm_index* x, uint64_t sequences, uint64_t bases, const uint64_t* C)
 {
   x->n = bases; x->m = sequences;
-  TRY(native_samples(x));
+  u32 flags = 0;
+  TRY(native_samples(x, &flags));
   // Validate the header against the stream and derive C (Alphabet(counts), support.cpp:84-91).
-  u64 stride = x->nblocks + 1;
+  const u64 gstride = x->ngroups + 1;
   u64 totals[6];
-  for(int c = 0; c < 6; c++)
-  {
-    HIP_TRY(hipMemcpyAsync(&totals[c], x->cum.as<u64>() + c * stride + x->nblocks, sizeof(u64), hipMemcpyDeviceToHost, g_ctx.stream));
-  }
+  HIP_TRY(hipMemcpy2DAsync(totals, sizeof(u64), x->gcum.as<u64>() + x->ngroups, gstride * sizeof(u64), sizeof(u64), 6,
+    hipMemcpyDeviceToHost, g_ctx.stream));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  if(flags & 1u) { return fail(BWTM_EINVAL, "not a canonical run-length stream: a full 64-byte block encodes fewer than 64 positions"); }
   u64 sum = 0; for(int c = 0; c < 6; c++) { sum += totals[c]; }
   if(sum != bases) { return fail(BWTM_EINVAL, "native stream decodes to %llu positions, header says %llu", (unsigned long long)sum, (unsigned long long)bases); }
   if(totals[0] != sequences) { return fail(BWTM_EINVAL, "native stream holds %llu endmarkers, header says %llu sequences", (unsigned long long)totals[0], (unsigned long long)sequences); }
@@ -491,7 +506,7 @@ extern "C" int bwtm_index_drop_native(bwtm_index* x)
 {
   if(!x) { return fail(BWTM_EINVAL, "null index"); }
   if(x->borrowed) { HIP_TRY(hipStreamSynchronize(g_ctx.stream)); x->borrowed = nullptr; }
-  x->data.release(); x->cum.release(); x->block_start.release();
+  x->data.release(); x->cum.release(); x->gcum.release(); x->block_start.release();
   x->has_native = false; x->nbytes = 0; x->nblocks = 0;
   return BWTM_OK;
 }
@@ -530,7 +545,8 @@ extern "C" int bwtm_index_encode(bwtm_index* x)
       lasthead.as<const u64>(), seg_base.as<const u64>(), x->data.as<u8>());
   }
   else { TRY(alloc_native(x->data, 0)); }
-  TRY(native_samples(x));                       // BWT::build, bwt.cpp:476-512
+  TRY(native_samples(x, nullptr));              // BWT::build, bwt.cpp:476-512
+  TRY(ensure_block_cum(x));
   x->has_native = true;
   return BWTM_OK;
 }
@@ -560,6 +576,7 @@ extern "C" int bwtm_index_download_samples(bwtm_index* x, uint64_t* block_end, u
   TRY(ensure_ready());
   if(!x || !x->has_native) { return fail(BWTM_EINVAL, "index has no native samples (call bwtm_index_encode first)"); }
   u64 stride = x->nblocks + 1;
+  TRY(ensure_block_cum(x));
   if(x->nblocks > 0)
   {
     DevBuf be; TRY(be.alloc(x->nblocks * sizeof(u64)));

@@ -3,8 +3,8 @@
   interleave path.  Included by bwtm_api.hip only.
 
   Kernel map (reference code each one replaces):
-    k_block_stats      BWT::build scan of the run stream            bwt.cpp:487-502
-    k_block_start      block_boundaries (block start positions)     bwt.cpp:496
+    k_block_len        BWT::build scan of the run stream            bwt.cpp:487-502
+    k_block_cum        samples[c] at the block starts               bwt.cpp:489-511
     k_build_sup/recs   native blocks -> device records ("transcode at upload")
     k_sym_*            plain symbols -> device records (input tooling)
     k_lf_walk          buildRA + BWT::inverse_select + BWT::rank    fmi.cpp:272-334, bwt.cpp:318-341, 445-464
@@ -198,38 +198,56 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_scan_apply(const u64* in, u64
 }
 
 //------------------------------------------------------------------------------
-// K0a / K5: per native 64-byte block, the number of occurrences of every symbol
-// (BWT::build, bwt.cpp:487-502).  One lane per block.  cnt is SoA: cnt[c * stride + b].
+// K0: native byte stream -> device rank structure (BWT::load + BWT::build, bwt.cpp:132-148, 476-512).
+//
+// The stream is cut into GROUPs of 62 consecutive 64-byte blocks; one wave owns one group and one
+// lane decodes one block, so the byte stream is read exactly once per kernel with coalesced loads.
+//
+//   k_block_len   : positions per block (-> exclusive scan = block_start, the set bits of
+//                   block_boundaries, bwt.cpp:496) and symbol counts per group (-> exclusive scan)
+//   k_build_sup   : absolute counts at the super boundaries
+//   k_build_recs  : the records
+//   k_block_cum   : cumulative symbol counts at the block starts (samples[c], bwt.cpp:489-511),
+//                   read back from the finished rank structure
+//
+// Every full block of a stream written by Run::write encodes at least 64 positions (a run of k bytes
+// is at least k long, support.h:256-282); k_block_len verifies this and the other kernels rely on it.
 
-// Each wave stages its 64 blocks (4 KiB) in LDS with coalesced 16-byte loads, then every lane
-// decodes its own block from LDS (row stride 17 words: conflict-free for 32-bit reads).
-constexpr int STAGE_WORDS = 17;
+constexpr int GROUP = 62;                 // blocks owned by one wave; 2 more are staged as lookahead
+constexpr int STAGE_WORDS = 17;           // LDS row stride of a staged block: conflict-free 32-bit reads
+constexpr int STAGE_ROWS = 64;
 
-__global__ void __launch_bounds__(BLOCK_THREADS) k_block_stats(const u8* data, u64 nbytes, u64 nblocks, u64* cnt, u64 stride)
+__device__ inline void wave_sync_lds()
 {
-  __shared__ u32 stage[(BLOCK_THREADS / WAVE) * 64 * STAGE_WORDS];
-  const u32 lane = lane_id(), wave = threadIdx.x >> 6;
-  u32* rows = stage + wave * 64 * STAGE_WORDS;
-  const u64 first = ((u64)blockIdx.x * BLOCK_THREADS + (u64)wave * WAVE);      // first block of this wave
-  if(first >= nblocks) { return; }
-  // 64 blocks = 256 chunks of 16 bytes; lane handles chunks lane, lane + 64, ...
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Stages blocks [first, first + count), count <= 64, into rows of STAGE_WORDS words (coalesced 16-byte loads).
+__device__ inline void stage_blocks(const u8* data, u64 nbytes, u64 first, u32 count, u32* rows)
+{
+  const u32 lane = lane_id();
   const uint4* src = (const uint4*)(data + first * RLE_BLOCK);
-  const u64 chunks_avail = (nbytes + 15 - first * RLE_BLOCK) / 16;              // the buffer is padded by 16 zero bytes
+  const u64 chunks_avail = (nbytes + 15 - first * RLE_BLOCK) / 16;    // the buffer is readable up to the next multiple of 16
 #pragma unroll
   for(int k = 0; k < 4; k++)
   {
     u32 g = (u32)k * 64 + lane;
-    uint4 v = (g < chunks_avail ? src[g] : make_uint4(0, 0, 0, 0));
-    u32* dst = rows + (g >> 2) * STAGE_WORDS + (g & 3) * 4;
-    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    if(g < 4 * count)
+    {
+      uint4 v = (g < chunks_avail ? src[g] : make_uint4(0, 0, 0, 0));
+      u32* dst = rows + (g >> 2) * STAGE_WORDS + (g & 3) * 4;
+      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
   }
-  __builtin_amdgcn_wave_barrier();
-  const u64 b = first + lane;
-  if(b >= nblocks) { return; }
-  u64 begin = b * RLE_BLOCK;
-  u32 valid = (nbytes - begin >= RLE_BLOCK ? (u32)RLE_BLOCK : (u32)(nbytes - begin));
-  const u32* row = rows + lane * STAGE_WORDS;
-  u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+}
+
+// Calls f(sym, len) for every run of a staged block (`valid` bytes), in order.  A byte-wise state
+// machine without dynamic indexing; a run cut off by the end of the stream is dropped.
+template<class F>
+__device__ inline void for_each_run(const u32* row, u32 valid, F&& f)
+{
   u32 sym = 0, shift = 0; u64 len = 0; bool cont = false;
 #pragma unroll 1
   for(int w = 0; w < 16; w++)
@@ -238,29 +256,64 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_block_stats(const u8* data, u
 #pragma unroll
     for(int k = 0; k < 4; k++)
     {
-      u32 byte = (word >> (8 * k)) & 0xFF;
-      bool active = ((u32)(4 * w + k) < valid);
-      bool done;
-      if(!cont) { sym = byte % 6; len = byte / 6 + 1; shift = 0; cont = (len >= MAX_RUN); done = !cont; }
-      else { len += (u64)(byte & 0x7F) << shift; shift += 7; cont = (byte & 0x80) != 0; done = !cont; }
-      if(!active) { done = false; cont = false; }
-      u64 add = (done ? len : 0);
-      c0 += (sym == 0 ? add : 0); c1 += (sym == 1 ? add : 0); c2 += (sym == 2 ? add : 0);
-      c3 += (sym == 3 ? add : 0); c4 += (sym == 4 ? add : 0); c5 += (sym == 5 ? add : 0);
+      if((u32)(4 * w + k) < valid)
+      {
+        u32 byte = (word >> (8 * k)) & 0xFF;
+        if(!cont) { u32 q = (byte * 171u) >> 10; sym = byte - 6 * q; len = q + 1; shift = 0; cont = (q + 1 >= MAX_RUN); }   // q = byte / 6, exact for byte < 256
+        else { len += (u64)(byte & 0x7F) << shift; shift += 7; cont = (byte & 0x80) != 0; }
+        if(!cont) { f(sym, len); }
+      }
     }
   }
-  cnt[0 * stride + b] = c0; cnt[1 * stride + b] = c1; cnt[2 * stride + b] = c2;
-  cnt[3 * stride + b] = c3; cnt[4 * stride + b] = c4; cnt[5 * stride + b] = c5;
 }
 
-// block_start[b] = sum over c of cum[c][b], b in [0, nblocks].
-__global__ void __launch_bounds__(BLOCK_THREADS) k_block_start(const u64* cum, u64 stride, u64 count, u64* block_start)
+// blen[b] = positions encoded by block b; gcount[c * gstride + g] = occurrences of c in group g.
+// flags bit 0: a block other than the last one encodes fewer than 64 positions.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_block_len(const u8* data, u64 nbytes, u64 nblocks, u64 ngroups,
+  u64* blen, u64* gcount, u64 gstride, u32* flags)
 {
-  u64 b = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
-  if(b >= count) { return; }
-  u64 s = 0;
-  for(int c = 0; c < 6; c++) { s += cum[c * stride + b]; }
-  block_start[b] = s;
+  __shared__ u32 stage[BLOCK_THREADS / WAVE][STAGE_ROWS * STAGE_WORDS];
+  const u32 lane = lane_id(), wave = threadIdx.x >> 6;
+  const u64 g = (u64)blockIdx.x * (BLOCK_THREADS / WAVE) + wave;
+  if(g >= ngroups) { return; }
+  const u64 first = g * GROUP;
+  const u32 nb = (nblocks > first ? (nblocks - first > (u64)GROUP ? (u32)GROUP : (u32)(nblocks - first)) : 0u);
+  u32* rows = stage[wave];
+  if(nb > 0) { stage_blocks(data, nbytes, first, nb, rows); }
+  wave_sync_lds();
+  // Short runs (< 42) are counted in packed 16-bit fields (at most 64 * 41 per block), long ones in 64 bits.
+  u64 packed03 = 0; u32 packed45 = 0;
+  u64 l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0, l5 = 0;
+  const u64 b = first + lane;
+  if(lane < nb)
+  {
+    u64 begin = b * RLE_BLOCK;
+    u32 valid = (nbytes - begin >= RLE_BLOCK ? (u32)RLE_BLOCK : (u32)(nbytes - begin));
+    for_each_run(rows + lane * STAGE_WORDS, valid, [&](u32 sym, u64 len)
+    {
+      if(len < MAX_RUN)
+      {
+        u32 l = (u32)len;
+        if(sym < 4) { packed03 += (u64)l << (16 * sym); } else { packed45 += l << (16 * (sym - 4)); }
+      }
+      else
+      {
+        l0 += (sym == 0 ? len : 0); l1 += (sym == 1 ? len : 0); l2 += (sym == 2 ? len : 0);
+        l3 += (sym == 3 ? len : 0); l4 += (sym == 4 ? len : 0); l5 += (sym == 5 ? len : 0);
+      }
+    });
+    l0 += packed03 & 0xFFFF; l1 += (packed03 >> 16) & 0xFFFF; l2 += (packed03 >> 32) & 0xFFFF; l3 += packed03 >> 48;
+    l4 += packed45 & 0xFFFF; l5 += packed45 >> 16;
+    u64 total = l0 + l1 + l2 + l3 + l4 + l5;
+    blen[b] = total;
+    if(total < RLE_BLOCK && b + 1 < nblocks) { atomicOr(flags, 1u); }
+  }
+  u64 t0 = wave_sum(l0), t1 = wave_sum(l1), t2 = wave_sum(l2), t3 = wave_sum(l3), t4 = wave_sum(l4), t5 = wave_sum(l5);
+  if(lane == 0)
+  {
+    gcount[0 * gstride + g] = t0; gcount[1 * gstride + g] = t1; gcount[2 * gstride + g] = t2;
+    gcount[3 * gstride + g] = t3; gcount[4 * gstride + g] = t4; gcount[5 * gstride + g] = t5;
+  }
 }
 
 // block_end[b] = block_start[b + 1] - 1 (the set bits of block_boundaries, bwt.cpp:496).
@@ -282,117 +335,163 @@ __device__ inline u64 find_block(const u64* block_start, u64 nblocks, u64 p)
   return lo;
 }
 
-// Cursor over the native run stream positioned so that the current run covers position p.
-struct RunCursor
+// Super table from the native stream: one wave per super.  The counts at position p are the counts at
+// the start of p's group plus the runs of the group's blocks before p (one lane per block).
+__global__ void __launch_bounds__(BLOCK_THREADS) k_build_sup(const u8* data, u64 nbytes, const u64* block_start,
+  const u64* gcum, u64 gstride, u64 nblocks, u64 ngroups, u64 n, u64* sup, u64 nsup)
 {
-  const u8* data; u64 nbytes;
-  u64 rle;            // next byte to decode
-  u32 sym; u64 left;  // current run: symbol and positions left (including the one at the cursor)
-};
-
-// Positions the cursor at p (< n) and returns the counts of symbols 1..5 in [0, p).
-__device__ inline void seek_native(const u8* data, u64 nbytes, const u64* block_start, const u64* cum, u64 stride,
-  u64 nblocks, u64 p, RunCursor& cur, u64 abs[6])
-{
-  u64 b = find_block(block_start, nblocks, p);
-  u64 pos = block_start[b];
-  for(int c = 1; c < 6; c++) { abs[c] = cum[c * stride + b]; }
-  cur.data = data; cur.nbytes = nbytes; cur.rle = b * RLE_BLOCK;
-  while(true)
+  const u32 lane = lane_id();
+  const u64 s = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
+  if(s >= nsup) { return; }
+  const u64 p = s << SUPER_SHIFT;
+  u64 g = ngroups;                                  // column of the totals
+  u64 c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+  if(p < n)
   {
-    u32 sym; u64 len;
-    run_decode(data, cur.rle, sym, len);
-    u64 take = (pos + len > p ? p - pos : len);
-    abs[1] += (sym == 1 ? take : 0); abs[2] += (sym == 2 ? take : 0); abs[3] += (sym == 3 ? take : 0);
-    abs[4] += (sym == 4 ? take : 0); abs[5] += (sym == 5 ? take : 0);
-    if(pos + len > p) { cur.sym = sym; cur.left = len - take; return; }
-    pos += len;
+    const u64 b = find_block(block_start, nblocks, p);   // wave-uniform
+    g = b / GROUP;
+    const u64 blk = g * GROUP + lane;
+    if(lane < (u32)GROUP && blk <= b)
+    {
+      u64 pos = block_start[blk], rle = blk * RLE_BLOCK;
+      const u64 end = (nbytes - rle >= RLE_BLOCK ? rle + RLE_BLOCK : nbytes);
+      while(rle < end && pos < p)
+      {
+        u32 sym; u64 len; run_decode(data, rle, sym, len);
+        u64 take = (p - pos < len ? p - pos : len);
+        c1 += (sym == 1 ? take : 0); c2 += (sym == 2 ? take : 0); c3 += (sym == 3 ? take : 0);
+        c4 += (sym == 4 ? take : 0); c5 += (sym == 5 ? take : 0);
+        pos += len;
+      }
+    }
+  }
+  c1 = wave_sum(c1); c2 = wave_sum(c2); c3 = wave_sum(c3); c4 = wave_sum(c4); c5 = wave_sum(c5);
+  if(lane == 0)
+  {
+    u64* out = sup + s * SUP_STRIDE;
+    out[0] = 0; out[6] = 0; out[7] = 0;
+    out[1] = gcum[1 * gstride + g] + c1; out[2] = gcum[2 * gstride + g] + c2; out[3] = gcum[3 * gstride + g] + c3;
+    out[4] = gcum[4 * gstride + g] + c4; out[5] = gcum[5 * gstride + g] + c5;
   }
 }
 
-// K0b: super table from the native stream.  One lane per super.
-__global__ void __launch_bounds__(BLOCK_THREADS) k_build_sup(const u8* data, u64 nbytes, const u64* block_start,
-  const u64* cum, u64 stride, u64 nblocks, u64 n, u64* sup, u64 nsup)
-{
-  u64 s = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
-  if(s >= nsup) { return; }
-  u64 p = s << SUPER_SHIFT;
-  u64 abs[6] = {0, 0, 0, 0, 0, 0};
-  if(p >= n) { for(int c = 1; c < 6; c++) { abs[c] = cum[c * stride + nblocks]; } }
-  else { RunCursor cur; seek_native(data, nbytes, block_start, cum, stride, nblocks, p, cur, abs); }
-  for(int c = 0; c < SUP_STRIDE; c++) { sup[s * SUP_STRIDE + c] = (c >= 1 && c < 6 ? abs[c] : 0); }
-}
-
-// K0c: records from the native stream.  One wave per 64 consecutive records (8192 positions):
-// one binary search per wave finds the first block, the <= 132 blocks that can cover the span
-// (a full block holds >= 64 positions) and their start positions are staged in LDS with
-// coalesced loads, and every lane decodes its record from LDS.
-constexpr int BR_BLOCKS = 132;
+// Records from the native stream.  The wave of group g owns the records that START inside the group's
+// position range [S, E) (the last group also owns the rest); they may extend up to 127 positions into
+// the next group, which the two lookahead blocks cover.  Positions are processed in windows of
+// BR_WINDOW: every lane deposits the runs of its block into three LDS bit-planes (word-wise OR,
+// accumulated in registers while consecutive runs stay inside one word), then lane r assembles record
+// r of the window: planes from LDS, header = counts before the group + carried counts of the earlier
+// windows + wave prefix of the records' own counts.  One window is the common case (a group of
+// random-read BWT covers ~5300 positions); compressible streams take more windows over fewer bytes.
+constexpr u32 BR_WINDOW = 8192;
 
 __global__ void __launch_bounds__(BLOCK_THREADS) k_build_recs(const u8* data, u64 nbytes, const u64* block_start,
-  const u64* cum, u64 stride, u64 nblocks, u64 n, const u64* sup, uint4* recs, u64 nrecs)
+  const u64* gcum, u64 gstride, u64 nblocks, u64 ngroups, u64 n, const u64* sup, uint4* recs, u64 nrecs)
 {
-  __shared__ uint4 staged[BLOCK_THREADS / WAVE][BR_BLOCKS * 4];
-  __shared__ u64 starts[BLOCK_THREADS / WAVE][BR_BLOCKS + 1];
+  __shared__ u32 stage[BLOCK_THREADS / WAVE][STAGE_ROWS * STAGE_WORDS];
+  __shared__ uint4 planes[BLOCK_THREADS / WAVE][3][BR_WINDOW / 128];
   const u32 lane = lane_id(), wave = threadIdx.x >> 6;
-  const u64 q0 = ((u64)blockIdx.x * (BLOCK_THREADS / WAVE) + wave) * WAVE;
-  if(q0 >= nrecs) { return; }
-  const u64 p0 = q0 << REC_SHIFT;
-  const u64 b0 = (p0 >= n ? nblocks : find_block(block_start, nblocks, p0));      // wave-uniform
-  u32 nb = (nblocks - b0 > (u64)BR_BLOCKS ? (u32)BR_BLOCKS : (u32)(nblocks - b0));
-  const uint4* src = (const uint4*)(data + b0 * RLE_BLOCK);
-  const u64 chunks_avail = (b0 * RLE_BLOCK <= nbytes ? (nbytes + 15 - b0 * RLE_BLOCK) / 16 : 0);
-  for(u32 g = lane; g < nb * 4; g += WAVE) { staged[wave][g] = (g < chunks_avail ? src[g] : make_uint4(0, 0, 0, 0)); }
-  for(u32 k = lane; k <= nb; k += WAVE) { starts[wave][k] = block_start[b0 + k]; }
-  __builtin_amdgcn_wave_barrier();
-
-  const u64 q = q0 + lane;
-  if(q >= nrecs) { return; }
-  const u64 p = q << REC_SHIFT;
-  u64 abs[6] = {0, 0, 0, 0, 0, 0};
-  u64 lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0, lo2 = 0, hi2 = 0;
-  if(p >= n) { for(int c = 1; c < 6; c++) { abs[c] = cum[c * stride + nblocks]; } }
-  else
+  const u64 g = (u64)blockIdx.x * (BLOCK_THREADS / WAVE) + wave;
+  if(g >= ngroups) { return; }
+  const u64 first = g * GROUP;
+  const bool last_group = (g + 1 == ngroups);
+  const u32 nb = (nblocks > first ? (nblocks - first > (u64)STAGE_ROWS ? (u32)STAGE_ROWS : (u32)(nblocks - first)) : 0u);
+  const u64 S = (nb > 0 ? block_start[first] : 0);
+  const u64 q_lo = (S + REC_POS - 1) >> REC_SHIFT;
+  const u64 q_hi = (last_group ? nrecs : (block_start[first + GROUP] + REC_POS - 1) >> REC_SHIFT);
+  if(q_lo >= q_hi) { return; }                                  // wave-uniform: no record starts in this group
+  u32* rows = stage[wave];
+  if(nb > 0) { stage_blocks(data, nbytes, first, nb, rows); }
+  const bool have = (lane < nb);
+  const u64 b = first + lane;
+  const u64 bstart = (have ? block_start[b] : 0), bend = (have ? block_start[b + 1] : 0);
+  const u32 valid = (have ? (nbytes - b * RLE_BLOCK >= RLE_BLOCK ? (u32)RLE_BLOCK : (u32)(nbytes - b * RLE_BLOCK)) : 0u);
+  u64 a1 = gcum[1 * gstride + g], a2 = gcum[2 * gstride + g], a3 = gcum[3 * gstride + g],
+      a4 = gcum[4 * gstride + g], a5 = gcum[5 * gstride + g];   // counts before the first record of the window
+  const u64 pos_end = ((q_hi << REC_SHIFT) < n ? (q_hi << REC_SHIFT) : n);
+  u32* pl = (u32*)planes[wave];                                 // plane k: words [256 k, 256 k + 256)
+  for(u64 ws = S & ~(u64)(REC_POS - 1); (ws >> REC_SHIFT) < q_hi; ws += BR_WINDOW)
   {
-    const u64* st = starts[wave];
-    u32 lo = 0, hi = nb;                          // st[lo] <= p < st[hi]
-    while(hi - lo > 1) { u32 mid = (lo + hi) >> 1; if(st[mid] <= p) { lo = mid; } else { hi = mid; } }
-    for(int c = 1; c < 6; c++) { abs[c] = cum[c * stride + b0 + lo]; }
-    const u8* bytes = (const u8*)staged[wave];
-    u64 rle = (u64)lo * RLE_BLOCK, pos = st[lo];
-    u32 sym = 0; u64 left = 0;
-    while(true)                                   // skip to p inside the block
+#pragma unroll
+    for(int k = 0; k < 12; k++) { pl[k * 64 + lane] = 0; }
+    wave_sync_lds();
+    const u64 we = (ws + BR_WINDOW < pos_end ? ws + BR_WINDOW : pos_end);
+    if(have && bstart < we && bend > ws)
     {
-      u64 len; run_decode(bytes, rle, sym, len);
-      u64 take = (pos + len > p ? p - pos : len);
-      abs[1] += (sym == 1 ? take : 0); abs[2] += (sym == 2 ? take : 0); abs[3] += (sym == 3 ? take : 0);
-      abs[4] += (sym == 4 ? take : 0); abs[5] += (sym == 5 ? take : 0);
-      if(pos + len > p) { left = len - take; break; }
-      pos += len;
+      u64 pos = bstart;
+      u32 cur = 0, acc0 = 0, acc1 = 0, acc2 = 0;
+      for_each_run(rows + lane * STAGE_WORDS, valid, [&](u32 sym, u64 len)
+      {
+        const u64 from = pos, to = pos + len;
+        pos = to;
+        if(sym != 0 && to > ws && from < we)
+        {
+          u32 a = (from > ws ? (u32)(from - ws) : 0u);
+          const u32 e = (to < we ? (u32)(to - ws) : (u32)(we - ws));
+          while(a < e)
+          {
+            const u32 w = a >> 5;
+            if(w != cur)
+            {
+              if(acc0) { atomicOr(&pl[cur], acc0); } if(acc1) { atomicOr(&pl[256 + cur], acc1); } if(acc2) { atomicOr(&pl[512 + cur], acc2); }
+              cur = w; acc0 = 0; acc1 = 0; acc2 = 0;
+            }
+            const u32 stop = (e < ((w + 1) << 5) ? e : ((w + 1) << 5));
+            const u32 count = stop - a;
+            const u32 mask = (count == 32 ? ~0u : ((1u << count) - 1u) << (a & 31));
+            acc0 |= (sym & 1 ? mask : 0u); acc1 |= (sym & 2 ? mask : 0u); acc2 |= (sym & 4 ? mask : 0u);
+            a = stop;
+          }
+        }
+      });
+      if(acc0) { atomicOr(&pl[cur], acc0); } if(acc1) { atomicOr(&pl[256 + cur], acc1); } if(acc2) { atomicOr(&pl[512 + cur], acc2); }
     }
-    u32 t = 0;
-    u64 avail = n - p;
-    u32 limit = (avail >= REC_POS ? (u32)REC_POS : (u32)avail);
-    while(t < limit)
+    wave_sync_lds();
+    // record `lane` of the window
+    const uint4 P0 = planes[wave][0][lane], P1 = planes[wave][1][lane], P2 = planes[wave][2][lane];
+    u32 n1 = 0, n2 = 0, n3 = 0, n4 = 0, n5 = 0;
+#define BWTM_COUNT_WORD(f) \
+    n1 += (u32)__builtin_popcount(plane_match(P0.f, P1.f, P2.f, 1)); n2 += (u32)__builtin_popcount(plane_match(P0.f, P1.f, P2.f, 2)); \
+    n3 += (u32)__builtin_popcount(plane_match(P0.f, P1.f, P2.f, 3)); n4 += (u32)__builtin_popcount(plane_match(P0.f, P1.f, P2.f, 4)); \
+    n5 += (u32)__builtin_popcount(plane_match(P0.f, P1.f, P2.f, 5));
+    BWTM_COUNT_WORD(x) BWTM_COUNT_WORD(y) BWTM_COUNT_WORD(z) BWTM_COUNT_WORD(w)
+#undef BWTM_COUNT_WORD
+    const u64 own14 = (u64)n1 | ((u64)n2 << 16) | ((u64)n3 << 32) | ((u64)n4 << 48);   // wave totals <= 8192 per field
+    const u64 incl14 = wave_incl_sum(own14), incl5 = wave_incl_sum((u64)n5);
+    const u64 before14 = incl14 - own14, before5 = incl5 - n5;
+    const u64 q = (ws >> REC_SHIFT) + lane;
+    if(q >= q_lo && q < q_hi)
     {
-      if(left == 0) { run_decode(bytes, rle, sym, left); }
-      u32 take = (left > (u64)(limit - t) ? limit - t : (u32)left);
-      u64 ml, mh; range_mask128(t, take, ml, mh);
-      if(sym & 1) { lo0 |= ml; hi0 |= mh; }
-      if(sym & 2) { lo1 |= ml; hi1 |= mh; }
-      if(sym & 4) { lo2 |= ml; hi2 |= mh; }
-      t += take; left -= take;
+      const u64 p = q << REC_SHIFT;
+      const u64* sp = sup + (p >> SUPER_SHIFT) * SUP_STRIDE;
+      u32 rel[6]; u32 h[4];
+      rel[0] = 0;
+      rel[1] = (u32)(a1 + (before14 & 0xFFFF) - sp[1]); rel[2] = (u32)(a2 + ((before14 >> 16) & 0xFFFF) - sp[2]);
+      rel[3] = (u32)(a3 + ((before14 >> 32) & 0xFFFF) - sp[3]); rel[4] = (u32)(a4 + (before14 >> 48) - sp[4]);
+      rel[5] = (u32)(a5 + before5 - sp[5]);
+      pack_header(rel, h);
+      uint4* dst = recs + 4 * q;
+      dst[0] = make_uint4(P0.x, P1.x, P2.x, h[0]);
+      dst[1] = make_uint4(P0.y, P1.y, P2.y, h[1]);
+      dst[2] = make_uint4(P0.z, P1.z, P2.z, h[2]);
+      dst[3] = make_uint4(P0.w, P1.w, P2.w, h[3]);
     }
+    const u64 tot14 = shfl_u64(incl14, WAVE - 1), tot5 = shfl_u64(incl5, WAVE - 1);
+    a1 += tot14 & 0xFFFF; a2 += (tot14 >> 16) & 0xFFFF; a3 += (tot14 >> 32) & 0xFFFF; a4 += tot14 >> 48; a5 += tot5;
+    wave_sync_lds();                                             // the planes are cleared again by the next window
   }
-  const u64* s = sup + (p >> SUPER_SHIFT) * SUP_STRIDE;
-  u32 rel[6]; u32 h[4];
-  for(int c = 1; c < 6; c++) { rel[c] = (u32)(abs[c] - s[c]); }
-  pack_header(rel, h);
-  uint4* dst = recs + 4 * q;
-  dst[0] = make_uint4((u32)lo0, (u32)lo1, (u32)lo2, h[0]);
-  dst[1] = make_uint4((u32)(lo0 >> 32), (u32)(lo1 >> 32), (u32)(lo2 >> 32), h[1]);
-  dst[2] = make_uint4((u32)hi0, (u32)hi1, (u32)hi2, h[2]);
-  dst[3] = make_uint4((u32)(hi0 >> 32), (u32)(hi1 >> 32), (u32)(hi2 >> 32), h[3]);
+}
+
+// cum[c * stride + b] = occurrences of c before the start of block b, b in [0, nblocks]
+// (CumulativeArray::sum(b) of samples[c], support.h:338-343), from the rank structure.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_block_cum(IndexView x, const u64* block_start, u64 count, u64* cum, u64 stride)
+{
+  u64 b = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(b >= count) { return; }
+  u64 p = block_start[b];
+  u64 r[6]; index_ranks(x, p, r);
+  cum[0 * stride + b] = p - (r[1] + r[2] + r[3] + r[4] + r[5]);
+  cum[1 * stride + b] = r[1]; cum[2 * stride + b] = r[2]; cum[3 * stride + b] = r[3]; cum[4 * stride + b] = r[4]; cum[5 * stride + b] = r[5];
 }
 
 //------------------------------------------------------------------------------

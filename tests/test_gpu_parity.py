@@ -98,6 +98,11 @@ def test_upload_rejects_inconsistent_header(gpu, oracle):
         gpu.Index.upload(f.data, f.sequences, f.bases + 1)
     with pytest.raises(gpu.BwtmError):
         gpu.Index.upload(f.data, f.sequences + 1, f.bases)
+    # A full block that encodes fewer than 64 positions (redundant varint continuation bytes) cannot come
+    # from Run::write (support.h:256-282); the transcode kernels rely on that and the upload refuses it.
+    padded = np.array([247] + [0x80] * 62 + [0x00] + [2], dtype=np.uint8)      # (1, 42) in 64 bytes, then (2, 1)
+    with pytest.raises(gpu.BwtmError, match="canonical"):
+        gpu.Index.upload(padded, 0, 43)
 
 
 def test_rank_structure_across_super_blocks(gpu, oracle):
