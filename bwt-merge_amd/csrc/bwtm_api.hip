@@ -540,13 +540,21 @@ extern "C" int bwtm_index_encode(bwtm_index* x)
     HIP_TRY(hipMemcpyAsync(&total, group_base.as<u64>() + ngroups, sizeof(u64), hipMemcpyDeviceToHost, g_ctx.stream));
     HIP_TRY(hipStreamSynchronize(g_ctx.stream));
     x->nbytes = total;
+    x->nblocks = div_up(total, RLE_BLOCK);
     TRY(alloc_native(x->data, total));
+    // k_enc_emit records the position at which every 64-byte block starts; the entry after the last block is n
+    TRY(x->block_start.alloc((x->nblocks + 1) * sizeof(u64)));
+    HIP_TRY(hipMemcpyAsync(x->block_start.as<u64>() + x->nblocks, &x->n, sizeof(u64), hipMemcpyHostToDevice, g_ctx.stream));
     LAUNCH("enc_emit", k_enc_emit, wave_grid, BLOCK_THREADS, x->recs.as<const uint4>(), x->nrecs, x->n, ntiles, nseg,
-      lasthead.as<const u64>(), seg_base.as<const u64>(), x->data.as<u8>());
+      lasthead.as<const u64>(), seg_base.as<const u64>(), x->data.as<u8>(), x->block_start.as<u64>());
   }
-  else { TRY(alloc_native(x->data, 0)); }
-  TRY(native_samples(x, nullptr));              // BWT::build, bwt.cpp:476-512
-  TRY(ensure_block_cum(x));
+  else
+  {
+    TRY(alloc_native(x->data, 0));
+    TRY(x->block_start.alloc(sizeof(u64), true));
+  }
+  x->gcum.release(); x->ngroups = 0; x->cum.release();
+  TRY(ensure_block_cum(x));                     // BWT::build, bwt.cpp:476-512: samples of the new stream
   x->has_native = true;
   return BWTM_OK;
 }

@@ -1960,7 +1960,7 @@ __global__ void __launch_bounds__(WAVE) k_fold_seg(const u32* table, u64 nseg, c
 }
 
 __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 nseg,
-  const u64* prevhead, const u64* seg_base, u8* out)
+  const u64* prevhead, const u64* seg_base, u8* out, u64* block_start)
 {
   __shared__ __attribute__((aligned(16))) u8 stage[BLOCK_THREADS / WAVE][4096 + 32];
   u64 seg = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
@@ -2002,6 +2002,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
         if(pos > 0)
         {
           u64 len = pos + 1 - cur;
+          if(((off - a + idx) & (RLE_BLOCK - 1)) == 0) { block_start[(off - a + idx) >> 6] = cur - 1; }   // this run opens a block
           lds[idx++] = (u8)(event_symbol(ti, b) + 6 * (len - 1));     // Run::encodeBasic, support.h:231-234
         }
         cur = pos + 1;
@@ -2041,11 +2042,15 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
           {
             u64 len = pos + 1 - cur;
             u32 sym = event_symbol(tt, b);
-            if(len < MAX_RUN) { if(lane_id() == 0) { out[off] = (u8)(sym + 6 * (len - 1)); } off += 1; }
+            if(len < MAX_RUN)
+            {
+              if(lane_id() == 0) { out[off] = (u8)(sym + 6 * (len - 1)); if((off & (RLE_BLOCK - 1)) == 0) { block_start[off >> 6] = cur - 1; } }
+              off += 1;
+            }
             else
             {
               u64 nb = long_run_bytes(off, len);
-              if(lane_id() == 0) { long_run_write(out, off, sym, len); }
+              if(lane_id() == 0) { long_run_write(out, off, sym, len, block_start, cur - 1); }
               off += nb;
             }
           }

@@ -28,6 +28,7 @@ def shim():
     L.shim_rec_count.restype = u32; L.shim_rec_count.argtypes = [C.c_void_p, u32, u32]
     L.shim_rec_symbol.restype = u32; L.shim_rec_symbol.argtypes = [C.c_void_p, u32]
     L.shim_range_mask128.argtypes = [u32, u32, C.c_void_p, C.c_void_p]
+    L.shim_encode_runs.restype = u64; L.shim_encode_runs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u64, C.c_void_p]
     L.shim_deposit64.argtypes = [u64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.shim_run_decode.restype = u64; L.shim_run_decode.argtypes = [C.c_void_p, u64, C.c_void_p, C.c_void_p]
     return L
@@ -89,6 +90,29 @@ def test_range_mask(shim):
             shim.shim_range_mask128(a, n, C.byref(lo), C.byref(hi))
             v = lo.value | (hi.value << 64)
             assert v == ((1 << n) - 1) << a
+
+
+def test_encoder_block_starts_match_oracle_samples(shim, oracle):
+    """Run::write splits long runs at block boundaries (support.h:256-282); the block start positions the
+    encoder records while writing must be the reference's block_boundaries (bwt.cpp:496)."""
+    rng = np.random.default_rng(3)
+    for lengths in ([1, 2, 3], [1, 41, 42, 43, 169, 170, 171], [1, 5000, 16425, 16426, 2 ** 21, 2 ** 35 + 7], [41, 42]):
+        nruns = 700
+        syms = rng.integers(0, 6, nruns)
+        for k in range(1, nruns):
+            if syms[k] == syms[k - 1]:
+                syms[k] = (syms[k] + 1) % 6
+        syms = syms.astype(np.uint8)
+        lens = rng.choice(np.array(lengths, dtype=np.uint64), nruns)
+        out = np.zeros(16 * nruns, dtype=np.uint8)
+        bs = np.full(16 * nruns // 64 + 2, 2 ** 64 - 1, dtype=np.uint64)
+        nbytes = shim.shim_encode_runs(out.ctypes.data, syms.ctypes.data, lens.ctypes.data, nruns, bs.ctypes.data)
+        bases = int(lens.sum()); sequences = int(lens[syms == 0].sum())
+        f = oracle.FMI.from_native(out[:nbytes], sequences, bases)       # the oracle scans the stream (BWT::build)
+        assert (f.bases, f.nbytes) == (bases, nbytes)
+        obe, _ = f.samples
+        assert bs[0] == 0 and np.array_equal(bs[1:f.blocks] - 1, obe[:-1])
+        assert np.all(bs[f.blocks:] == 2 ** 64 - 1)
 
 
 def test_deposit64_is_the_bitwise_interleave(shim):
