@@ -225,11 +225,13 @@ __device__ inline void wave_sync_lds()
 }
 
 // Stages blocks [first, first + count), count <= 64, into rows of STAGE_WORDS words (coalesced 16-byte loads).
+// Bytes past the end of the stream are staged as zeros (= runs of one endmarker, which deposit no bits).
 __device__ inline void stage_blocks(const u8* data, u64 nbytes, u64 first, u32 count, u32* rows)
 {
   const u32 lane = lane_id();
   const uint4* src = (const uint4*)(data + first * RLE_BLOCK);
-  const u64 chunks_avail = (nbytes + 15 - first * RLE_BLOCK) / 16;    // the buffer is readable up to the next multiple of 16
+  const u64 left = nbytes - first * RLE_BLOCK;                        // bytes of the stream from `first` on
+  const u64 chunks_avail = (left + 15) / 16;                          // the buffer is readable up to the next multiple of 16
 #pragma unroll
   for(int k = 0; k < 4; k++)
   {
@@ -237,16 +239,27 @@ __device__ inline void stage_blocks(const u8* data, u64 nbytes, u64 first, u32 c
     if(g < 4 * count)
     {
       uint4 v = (g < chunks_avail ? src[g] : make_uint4(0, 0, 0, 0));
+      if((u64)16 * g + 16 > left && g < chunks_avail)                 // the chunk that holds the last byte
+      {
+        u32 keep = (u32)(left - (u64)16 * g);                          // 1..15 bytes
+        u32 m[4];
+#pragma unroll
+        for(u32 j = 0; j < 4; j++) { m[j] = (keep >= 4 * j + 4 ? ~0u : (keep <= 4 * j ? 0u : (1u << (8 * (keep - 4 * j))) - 1u)); }
+        v.x &= m[0]; v.y &= m[1]; v.z &= m[2]; v.w &= m[3];
+      }
       u32* dst = rows + (g >> 2) * STAGE_WORDS + (g & 3) * 4;
       dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
     }
   }
 }
 
-// Calls f(sym, len) for every run of a staged block (`valid` bytes), in order.  A byte-wise state
-// machine without dynamic indexing; a run cut off by the end of the stream is dropped.
-template<class F>
-__device__ inline void for_each_run(const u32* row, u32 valid, F&& f)
+// Walks the runs of a staged block in order: on_short(sym, len) for runs of 1..41 (one byte, the common
+// case, kept straight-line), on_long(sym, len) for runs with a varint extension (support.h:236-250).
+// A byte-wise state machine without dynamic indexing.  CHECK_VALID: only the first `valid` bytes
+// belong to the stream and a run cut off there is dropped; otherwise all 64 bytes are decoded (bytes
+// staged past the end of the stream are zeros).
+template<bool CHECK_VALID, class FS, class FL>
+__device__ inline void for_each_run(const u32* row, u32 valid, FS&& on_short, FL&& on_long)
 {
   u32 sym = 0, shift = 0; u64 len = 0; bool cont = false;
 #pragma unroll 1
@@ -256,12 +269,20 @@ __device__ inline void for_each_run(const u32* row, u32 valid, F&& f)
 #pragma unroll
     for(int k = 0; k < 4; k++)
     {
-      if((u32)(4 * w + k) < valid)
+      if(!CHECK_VALID || (u32)(4 * w + k) < valid)
       {
         u32 byte = (word >> (8 * k)) & 0xFF;
-        if(!cont) { u32 q = (byte * 171u) >> 10; sym = byte - 6 * q; len = q + 1; shift = 0; cont = (q + 1 >= MAX_RUN); }   // q = byte / 6, exact for byte < 256
-        else { len += (u64)(byte & 0x7F) << shift; shift += 7; cont = (byte & 0x80) != 0; }
-        if(!cont) { f(sym, len); }
+        if(cont)
+        {
+          len += (u64)(byte & 0x7F) << shift; shift += 7; cont = (byte & 0x80) != 0;
+          if(!cont) { on_long(sym, len); }
+        }
+        else
+        {
+          u32 q = (byte * 171u) >> 10; sym = byte - 6 * q;           // q = byte / 6, exact for byte < 256
+          if(q + 1 >= MAX_RUN) { len = q + 1; shift = 0; cont = true; }
+          else { on_short(sym, q + 1); }
+        }
       }
     }
   }
@@ -289,19 +310,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_block_len(const u8* data, u64
   {
     u64 begin = b * RLE_BLOCK;
     u32 valid = (nbytes - begin >= RLE_BLOCK ? (u32)RLE_BLOCK : (u32)(nbytes - begin));
-    for_each_run(rows + lane * STAGE_WORDS, valid, [&](u32 sym, u64 len)
-    {
-      if(len < MAX_RUN)
+    for_each_run<true>(rows + lane * STAGE_WORDS, valid,
+      [&](u32 sym, u32 l)
       {
-        u32 l = (u32)len;
         if(sym < 4) { packed03 += (u64)l << (16 * sym); } else { packed45 += l << (16 * (sym - 4)); }
-      }
-      else
+      },
+      [&](u32 sym, u64 len)
       {
         l0 += (sym == 0 ? len : 0); l1 += (sym == 1 ? len : 0); l2 += (sym == 2 ? len : 0);
         l3 += (sym == 3 ? len : 0); l4 += (sym == 4 ? len : 0); l5 += (sym == 5 ? len : 0);
-      }
-    });
+      });
     l0 += packed03 & 0xFFFF; l1 += (packed03 >> 16) & 0xFFFF; l2 += (packed03 >> 32) & 0xFFFF; l3 += packed03 >> 48;
     l4 += packed45 & 0xFFFF; l5 += packed45 >> 16;
     u64 total = l0 + l1 + l2 + l3 + l4 + l5;
@@ -416,34 +434,59 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_build_recs(const u8* data, u6
     for(int k = 0; k < 12; k++) { pl[k * 64 + lane] = 0; }
     wave_sync_lds();
     const u64 we = (ws + BR_WINDOW < pos_end ? ws + BR_WINDOW : pos_end);
-    if(have && bstart < we && bend > ws)
+    const bool inside = (have && bstart >= ws && bend <= ws + BR_WINDOW);
+    if(inside)
     {
-      u64 pos = bstart;
+      // The block lies inside the LDS window (the common case): its runs are appended to three bit
+      // streams, one per plane, through 64-bit shift accumulators that release a word whenever 32 bits
+      // are complete.  No clipping: bits past the last owned record are never read.
+      u64 acc0 = 0, acc1 = 0, acc2 = 0;
+      u32 fill = (u32)(bstart - ws) & 31u, wi = (u32)(bstart - ws) >> 5;
+      auto append = [&](u32 sym, u32 take)                      // 1 <= take <= 32, fill < 32
+      {
+        const u64 v = ((1ull << take) - 1ull) << fill;
+        acc0 |= (sym & 1 ? v : 0ull); acc1 |= (sym & 2 ? v : 0ull); acc2 |= (sym & 4 ? v : 0ull);
+        fill += take;
+        if(fill >= 32)
+        {
+          atomicOr(&pl[wi], (u32)acc0); atomicOr(&pl[256 + wi], (u32)acc1); atomicOr(&pl[512 + wi], (u32)acc2);   // edge words are shared with the neighbours
+          acc0 >>= 32; acc1 >>= 32; acc2 >>= 32; fill -= 32; wi++;
+        }
+      };
+      for_each_run<false>(rows + lane * STAGE_WORDS, valid,
+        [&](u32 sym, u32 l) { append(sym, (l < 32 ? l : 32u)); if(l > 32) { append(sym, l - 32); } },
+        [&](u32 sym, u64 len) { u32 l = (u32)len; while(l > 0) { u32 take = (l < 32 ? l : 32u); append(sym, take); l -= take; } });
+      if(fill > 0 && wi < BR_WINDOW / 32) { atomicOr(&pl[wi], (u32)acc0); atomicOr(&pl[256 + wi], (u32)acc1); atomicOr(&pl[512 + wi], (u32)acc2); }
+    }
+    else if(have && bstart < we && bend > ws)
+    {
+      // The block straddles a window edge: general path with clipping, word-wise OR.
       u32 cur = 0, acc0 = 0, acc1 = 0, acc2 = 0;
-      for_each_run(rows + lane * STAGE_WORDS, valid, [&](u32 sym, u64 len)
+      auto deposit = [&](u32 sym, u32 a, u32 e)                 // window-relative positions [a, e)
+      {
+        while(a < e)
+        {
+          const u32 w = a >> 5;
+          if(w != cur)
+          {
+            if(acc0) { atomicOr(&pl[cur], acc0); } if(acc1) { atomicOr(&pl[256 + cur], acc1); } if(acc2) { atomicOr(&pl[512 + cur], acc2); }
+            cur = w; acc0 = 0; acc1 = 0; acc2 = 0;
+          }
+          const u32 stop = (e < ((w + 1) << 5) ? e : ((w + 1) << 5));
+          const u32 count = stop - a;
+          const u32 mask = (count == 32 ? ~0u : ((1u << count) - 1u) << (a & 31));
+          acc0 |= (sym & 1 ? mask : 0u); acc1 |= (sym & 2 ? mask : 0u); acc2 |= (sym & 4 ? mask : 0u);
+          a = stop;
+        }
+      };
+      u64 pos = bstart;
+      auto run = [&](u32 sym, u64 len)
       {
         const u64 from = pos, to = pos + len;
         pos = to;
-        if(sym != 0 && to > ws && from < we)
-        {
-          u32 a = (from > ws ? (u32)(from - ws) : 0u);
-          const u32 e = (to < we ? (u32)(to - ws) : (u32)(we - ws));
-          while(a < e)
-          {
-            const u32 w = a >> 5;
-            if(w != cur)
-            {
-              if(acc0) { atomicOr(&pl[cur], acc0); } if(acc1) { atomicOr(&pl[256 + cur], acc1); } if(acc2) { atomicOr(&pl[512 + cur], acc2); }
-              cur = w; acc0 = 0; acc1 = 0; acc2 = 0;
-            }
-            const u32 stop = (e < ((w + 1) << 5) ? e : ((w + 1) << 5));
-            const u32 count = stop - a;
-            const u32 mask = (count == 32 ? ~0u : ((1u << count) - 1u) << (a & 31));
-            acc0 |= (sym & 1 ? mask : 0u); acc1 |= (sym & 2 ? mask : 0u); acc2 |= (sym & 4 ? mask : 0u);
-            a = stop;
-          }
-        }
-      });
+        if(sym != 0 && to > ws && from < we) { deposit(sym, (from > ws ? (u32)(from - ws) : 0u), (to < we ? (u32)(to - ws) : (u32)(we - ws))); }
+      };
+      for_each_run<false>(rows + lane * STAGE_WORDS, valid, [&](u32 sym, u32 l) { run(sym, (u64)l); }, run);
       if(acc0) { atomicOr(&pl[cur], acc0); } if(acc1) { atomicOr(&pl[256 + cur], acc1); } if(acc2) { atomicOr(&pl[512 + cur], acc2); }
     }
     wave_sync_lds();
