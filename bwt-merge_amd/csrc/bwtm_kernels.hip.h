@@ -1898,20 +1898,24 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_lasthead(const uint4* rec
   if(lane_id() == 0) { lasthead[seg] = best; }
 }
 
-// Per-lane event statistics of a tile: number of events and of long events.
-// `before` = (position of the last head before this tile) + 1.
+// Per-lane event statistics of a tile: number of events, and whether any of them is a run of >= 42
+// (a head with no other head among the 41 positions before it).  `before` = (position of the last head
+// before this tile) + 1.  nlong is 0 or 1.
 __device__ inline void tile_event_stats(const TileInfo& ti, u64 tile_base, u64 before, u32& nev, u32& nlong)
 {
   nev = (u32)__builtin_popcountll(ti.E); nlong = 0;
-  u64 h = ti.H;
-  u64 last = before;                 // position + 1 of the most recent head
-  while(h)
-  {
-    u32 t = (u32)__builtin_ctzll(h); h &= h - 1;
-    u64 pos = tile_base + t;
-    if(pos > 0 && (pos + 1 - last) >= MAX_RUN) { nlong++; }
-    last = pos + 1;
-  }
+  const u64 H = ti.H;
+  if(H == 0) { return; }
+  // covered = OR of H << k for k = 1..41: positions that have a head among the 41 positions before them
+  u64 s = H << 1;
+  s |= s << 1; s |= s << 2; s |= s << 4;          // k = 1..8
+  const u64 s9 = s | (H << 9);                     // k = 1..9
+  s |= s << 8; s |= s << 16;                       // k = 1..32
+  const u64 covered = s | (s9 << 32);              // k = 1..41
+  const u64 later = H & (H - 1);                   // heads other than the first one of the tile
+  if((later & ~covered) != 0) { nlong = 1; return; }
+  const u64 pos = tile_base + (u32)__builtin_ctzll(H);   // first head: its run started before the tile
+  if(pos > 0 && pos + 1 - before >= MAX_RUN) { nlong = 1; }
 }
 
 __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_size(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 nseg,
@@ -2037,18 +2041,34 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
       u8* lds = stage[threadIdx.x >> 6];
       const u32 a = (u32)(off & 15);
       u32 idx = a + (u32)(ev_incl - nev);
-      u64 h = ti.H, cur = before, tb = T << 6;
-      while(h)
+      if(ti.H != 0)
       {
-        u32 b = (u32)__builtin_ctzll(h); h &= h - 1;
-        u64 pos = tb + b;
-        if(pos > 0)
+        // Events of the tile in position order.  The run that ends at head b has the symbol found at the
+        // previous head and the length b - (previous head); only the first head needs the 64-bit state
+        // carried in from the tiles before.  The tile is walked as two 32-bit halves.
+        const u64 tb = T << 6;
+        const u32 phase = (u32)((off - a) & (RLE_BLOCK - 1));            // byte (off - a + idx) opens a block iff ((phase + idx) & 63) == 0
+        const u32 b0 = (u32)__builtin_ctzll(ti.H);
+        u64 h = ti.H;
+        int prev_bit; u32 run_sym;
+        if(tb + b0 == 0) { h &= h - 1; prev_bit = 0; run_sym = (u32)(ti.p0 & 1) | ((u32)(ti.p1 & 1) << 1) | ((u32)(ti.p2 & 1) << 2); }   // position 0 is a head without an event
+        else { prev_bit = (int)b0 - (int)(u32)(tb + b0 + 1 - before); run_sym = event_symbol(ti, b0); }
+#pragma unroll
+        for(int half = 0; half < 2; half++)
         {
-          u64 len = pos + 1 - cur;
-          if(((off - a + idx) & (RLE_BLOCK - 1)) == 0) { block_start[(off - a + idx) >> 6] = cur - 1; }   // this run opens a block
-          lds[idx++] = (u8)(event_symbol(ti, b) + 6 * (len - 1));     // Run::encodeBasic, support.h:231-234
+          u32 hh = (u32)(h >> (32 * half));
+          const u32 q0 = (u32)(ti.p0 >> (32 * half)), q1 = (u32)(ti.p1 >> (32 * half)), q2 = (u32)(ti.p2 >> (32 * half));
+          while(hh)
+          {
+            const u32 bb = (u32)__builtin_ctz(hh); hh &= hh - 1;
+            const int bit = (int)bb + 32 * half;
+            const u32 len = (u32)(bit - prev_bit);
+            if(((phase + idx) & (u32)(RLE_BLOCK - 1)) == 0) { block_start[(off - a + idx) >> 6] = tb + (u64)(long long)prev_bit; }   // this run opens a block
+            lds[idx++] = (u8)(run_sym + 6 * (len - 1));                  // Run::encodeBasic, support.h:231-234
+            run_sym = ((q0 >> bb) & 1u) | (((q1 >> bb) & 1u) << 1) | (((q2 >> bb) & 1u) << 2);
+            prev_bit = bit;
+          }
         }
-        cur = pos + 1;
       }
       __builtin_amdgcn_wave_barrier();
       const u32 total = a + (u32)chunk_events;
