@@ -897,6 +897,7 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
     TRY(seg_len[k].alloc((nseg + 1) * sizeof(u64), true)); TRY(seg_phys[k].alloc((nseg + 1) * sizeof(u64), true));
   }
   TRY(seg_prefix.alloc((nseg + 1) * sizeof(u64)));
+  DevBuf first_seg; TRY(first_seg.alloc((nb_max + 1) * sizeof(u32)));
   // An epoch emits at most one value per position of b; a shard of the sequences usually far less.
   // Emits past the capacity take the exact atomicOr fallback.
   const u64 per_seq = b->n / (b->m > 0 ? b->m : 1) + 1;
@@ -923,11 +924,12 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
       HIP_TRY(hipStreamSynchronize(g_ctx.stream));
       if(alive == 0) { break; }
     }
-    LAUNCH("frontier_prep", k_frontier_prep, 1, WAVE, seg_prefix.as<const u64>(), nseg, emit_base.as<u64>(), in_epoch);
+    LAUNCH("frontier_prep", k_frontier_prep, div_up(nseg, BLOCK_THREADS), BLOCK_THREADS, seg_prefix.as<const u64>(), nseg, first_seg.as<u32>(),
+      emit_base.as<u64>(), in_epoch);
     FrontierView f;
     f.lo = lo[cur].as<const uint2>(); f.hi = hi[cur].as<const unsigned short>();
     f.lo_next = lo[1 - cur].as<uint2>(); f.hi_next = hi[1 - cur].as<unsigned short>();
-    f.seg_prefix = seg_prefix.as<const u64>(); f.seg_phys = seg_phys[cur].as<const u64>();
+    f.seg_prefix = seg_prefix.as<const u64>(); f.seg_phys = seg_phys[cur].as<const u64>(); f.first_seg = first_seg.as<const u32>();
     f.seg_len_next = seg_len[1 - cur].as<u64>(); f.seg_phys_next = seg_phys[1 - cur].as<u64>();
     f.nb_max = nb_max;
     f.emit16 = emit16.as<unsigned short>(); f.emit_base = emit_base.as<const u64>(); f.emit_cap = emit_cap; f.bits32 = ra->bits_as<u32>();

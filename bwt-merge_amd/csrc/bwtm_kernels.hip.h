@@ -1365,6 +1365,7 @@ struct FrontierView
   uint2* lo_next; unsigned short* hi_next;                               // next frontier
   const u64* seg_prefix;                       // exclusive scan of seg_len (5 * nb_max + 1 entries); last = N_t
   const u64* seg_phys;                         // physical start of every segment
+  const u32* first_seg;                        // per block: the segment that holds its first element (k_frontier_prep)
   u64* seg_len_next; u64* seg_phys_next;       // produced for the next step
   u64 nb_max;                                  // blocks per class in the segment tables
   // Dense emit of this step (EMIT == 0): the frontier is sorted, so are its bit positions p = i + r.
@@ -1457,7 +1458,6 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
 {
   __shared__ uint4 window[FR_BLOCK / WAVE][4 * FR_WINDOW];
   __shared__ u32 wave_cnt[FR_BLOCK / WAVE][6];
-  __shared__ u64 s_first_seg;
   __shared__ u64 s_prefix[FR_SEGS + 1], s_phys[FR_SEGS + 1];
   const u64 nseg = 5 * f.nb_max;
   const u64 N = f.seg_prefix[nseg];
@@ -1471,26 +1471,8 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
     if(blockIdx.x == 0 && threadIdx.x == 5) { f.seg_len_next[nseg] = 0; }
     return;
   }
-  if(wave == 0)
-  {
-    // 64-ary search by the first wave: seg_prefix[lo] <= g0 < seg_prefix[hi]  (4 rounds for 1M entries
-    // instead of 20 dependent loads of a binary search)
-    u64 lo = 0, hi = nseg;
-    while(hi - lo > 1)
-    {
-      u64 stepsz = (hi - lo + WAVE - 1) / WAVE;
-      u64 idx = lo + (u64)lane * stepsz;
-      bool le = (idx < hi ? f.seg_prefix[idx] <= g0 : false);
-      u32 k = (u32)__builtin_popcountll(__ballot(le));           // lanes 0 .. k-1 hold entries <= g0 (monotone), k >= 1
-      u64 nlo = lo + (u64)(k - 1) * stepsz;
-      u64 nhi = nlo + stepsz; if(nhi > hi) { nhi = hi; }
-      lo = nlo; hi = nhi;
-    }
-    if(lane == 0) { s_first_seg = lo; }
-  }
-  __syncthreads();
   // The block's elements live in a handful of segments: stage their table entries in LDS.
-  const u64 first_seg = s_first_seg;
+  const u64 first_seg = f.first_seg[blockIdx.x];
   if(threadIdx.x <= FR_SEGS)
   {
     u64 sidx = first_seg + threadIdx.x; if(sidx > nseg) { sidx = nseg; }
@@ -1613,10 +1595,18 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
   }
 }
 
-// Per-step bookkeeping of the dense emit: emit_base[t + 1] = emit_base[t] + N_t.
-__global__ void k_frontier_prep(const u64* seg_prefix, u64 nseg, u64* emit_base, u64 step)
+// Per-step bookkeeping.  first_seg[b] = the segment that holds logical element b * FR_BLOCK: a segment
+// has at most FR_BLOCK elements, so it covers at most one block boundary and every non-empty segment
+// can publish "its" block directly (replaces a search of seg_prefix by every block of the step kernel).
+// Dense emit: emit_base[t + 1] = emit_base[t] + N_t.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_prep(const u64* seg_prefix, u64 nseg, u32* first_seg, u64* emit_base, u64 step)
 {
-  if(threadIdx.x == 0 && blockIdx.x == 0) { emit_base[step + 1] = emit_base[step] + seg_prefix[nseg]; }
+  u64 sgm = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(sgm == 0) { emit_base[step + 1] = emit_base[step] + seg_prefix[nseg]; }
+  if(sgm >= nseg) { return; }
+  u64 begin = seg_prefix[sgm], end = seg_prefix[sgm + 1];
+  u64 b = (begin + FR_BLOCK - 1) / FR_BLOCK;
+  if(b * FR_BLOCK < end) { first_seg[b] = (u32)sgm; }
 }
 
 // Row t of the boundary table: bound[T] = logical index of the first element of step t whose bit

@@ -8,9 +8,10 @@ per = collections.defaultdict(list)
 for r in rows:
     name = r["Kernel_Name"].split("bwtm::")[1].split("(")[0].split("<")[0]
     per[(name, r["Counter_Name"])].append((int(r["Start_Timestamp"]), float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
-# the last merge step starts at the last k_block_stats triple -> use the start of the third-from-last k_block_stats launch
-starts = sorted(set(t for (n, c), v in per.items() if n == "k_block_stats" for t, _, _ in v))
-t0 = starts[-3] if len(starts) >= 3 else 0
+# the last merge step starts with the k_block_len launches of its two inputs (the output's block starts come
+# from the encoder) -> use the start of the second-from-last k_block_len launch
+starts = sorted(set(t for (n, c), v in per.items() if n == "k_block_len" for t, _, _ in v))
+t0 = starts[-2] if len(starts) >= 2 else 0
 for (name, counter), v in sorted(per.items()):
     sel = [(val, dur) for t, val, dur in v if t >= t0]
     if sel:
