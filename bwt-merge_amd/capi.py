@@ -7,7 +7,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbwtm.so")
+# BWTM_LIB selects another build of the same library (A/B measurements of kernel variants on one GPU box)
+LIB_PATH = os.environ.get("BWTM_LIB") or os.path.join(HERE, "libbwtm.so")
 SIGMA = 6
 
 u64 = C.c_uint64
