@@ -1625,24 +1625,43 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_tile_build_frontier(const uns
   for(u32 k = threadIdx.x; k < (1u << (TILE_SHIFT - 5)); k += BLOCK_THREADS) { tile[k] = 0; }
   if(threadIdx.x == 0) { any = 0; }
   __syncthreads();
-  // each wave takes every (BLOCK_THREADS / WAVE)-th step, so several bound -> run load chains are in flight
+  // Wave w takes the steps w, w + 4, ...  The run bounds of 64 of its steps are fetched at once (lane j
+  // holds step w + 4 j) and handed out by shuffles, so that only the loads of the runs themselves are
+  // dependent; four of those are in flight per lane.
+  constexpr u32 NW = BLOCK_THREADS / WAVE;
+  const u32 lane = lane_id(), wv = threadIdx.x >> 6;
   bool seen = false;
-  for(u64 t = threadIdx.x >> 6; t < nsteps; t += BLOCK_THREADS / WAVE)
+  for(u64 t0 = wv; t0 < nsteps; t0 += (u64)NW * WAVE)
   {
-    const u32* row = bound + t * (ntiles + 1);
-    u32 lo = row[T], hi = row[T + 1];
-    const u64 base = emit_base[t];
-    for(u32 k = lo + lane_id(); k < hi; k += WAVE)
+    const u64 tj = t0 + (u64)NW * lane;
+    u32 my_lo = 0, my_hi = 0; u64 my_base = 0;
+    if(tj < nsteps)
     {
-      if(base + k < emit_cap)
+      const u32* row = bound + tj * (ntiles + 1);
+      my_lo = row[T]; my_hi = row[T + 1]; my_base = emit_base[tj];
+    }
+    const u64 left = (nsteps - t0 + NW - 1) / NW;                  // steps of this wave from t0 on
+    const u32 cnt = (left < (u64)WAVE ? (u32)left : (u32)WAVE);
+    for(u32 j = 0; j < cnt; j++)
+    {
+      const u32 lo = (u32)__shfl((int)my_lo, (int)j, WAVE), hi = (u32)__shfl((int)my_hi, (int)j, WAVE);
+      const u64 base = shfl_u64(my_base, (int)j);
+      seen |= (hi > lo);
+      for(u32 k = lo + lane; k < hi; k += 4 * WAVE)
       {
-        u32 off = emit16[base + k];
-        atomicOr(&tile[off >> 5], 1u << (off & 31));
+        u32 off[4];
+#pragma unroll
+        for(u32 u = 0; u < 4; u++)
+        {
+          const u32 kk = k + u * WAVE;
+          off[u] = (kk < hi && base + kk < emit_cap ? (u32)emit16[base + kk] : 0xFFFFFFFFu);
+        }
+#pragma unroll
+        for(u32 u = 0; u < 4; u++) { if(off[u] != 0xFFFFFFFFu) { atomicOr(&tile[off[u] >> 5], 1u << (off[u] & 31)); } }
       }
     }
-    seen |= (hi > lo);
   }
-  if(seen && lane_id() == 0) { any = 1; }
+  if(seen && lane == 0) { any = 1; }
   __syncthreads();
   if(any == 0) { return; }
   u64 w0 = T << (TILE_SHIFT - 6);
