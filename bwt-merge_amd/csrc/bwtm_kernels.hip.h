@@ -265,7 +265,21 @@ __device__ inline void for_each_run(const u32* row, u32 valid, FS&& on_short, FL
 #pragma unroll 1
   for(int w = 0; w < 16; w++)
   {
-    u32 word = row[w];
+    const u32 word = row[w];
+    // bytes >= 246 (heads of runs with a varint extension): high bit set and low 7 bits >= 0x76
+    const u32 long_heads = ((word & 0x7F7F7F7Fu) + 0x0A0A0A0Au) & word & 0x80808080u;
+    if(!cont && long_heads == 0 && (!CHECK_VALID || (u32)(4 * w + 3) < valid))
+    {
+      // four one-byte runs: no state, no branches
+#pragma unroll
+      for(int k = 0; k < 4; k++)
+      {
+        const u32 byte = (word >> (8 * k)) & 0xFF;
+        const u32 q = (byte * 171u) >> 10;                           // q = byte / 6, exact for byte < 256
+        on_short(byte - 6 * q, q + 1);
+      }
+      continue;
+    }
 #pragma unroll
     for(int k = 0; k < 4; k++)
     {
@@ -279,7 +293,7 @@ __device__ inline void for_each_run(const u32* row, u32 valid, FS&& on_short, FL
         }
         else
         {
-          u32 q = (byte * 171u) >> 10; sym = byte - 6 * q;           // q = byte / 6, exact for byte < 256
+          u32 q = (byte * 171u) >> 10; sym = byte - 6 * q;
           if(q + 1 >= MAX_RUN) { len = q + 1; shift = 0; cont = true; }
           else { on_short(sym, q + 1); }
         }
@@ -313,7 +327,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_block_len(const u8* data, u64
     for_each_run<true>(rows + lane * STAGE_WORDS, valid,
       [&](u32 sym, u32 l)
       {
-        if(sym < 4) { packed03 += (u64)l << (16 * sym); } else { packed45 += l << (16 * (sym - 4)); }
+        const u64 add = (u64)l << (16 * (sym & 3));                    // symbols 4 and 5 use fields 0 and 1 of packed45
+        packed03 += (sym < 4 ? add : 0ull); packed45 += (sym < 4 ? 0u : (u32)add);
       },
       [&](u32 sym, u64 len)
       {
