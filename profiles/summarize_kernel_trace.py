@@ -3,7 +3,7 @@
 restricted to the TIMED steps of the bench (the input tooling launches the same kernels).
 
 The timed region is recognised structurally: every merge step ends with the encoder
-(k_enc_emit) followed by the sample builder (..., k_block_start); the last `steps` emits are
+(k_enc_emit) followed by the sample builder (k_block_cum); the last `steps` emits are
 the timed steps.  Usage: summarize_kernel_trace.py kernel_trace.csv steps > summary.md
 """
 import csv
@@ -24,9 +24,10 @@ def main():
     rows.sort()
     emits = [k for k, r in enumerate(rows) if r[2] == "k_enc_emit"]
     first = emits[-(steps + 1)] if len(emits) > steps else -1
-    t_begin = rows[first][1] if first >= 0 else 0
+    # the step before the timed ones ends with its own k_block_cum
+    t_begin = next(r[1] for r in rows[first:] if r[2] == "k_block_cum") if first >= 0 else 0
     last_emit = emits[-1]
-    t_end = next(r[1] for r in rows[last_emit:] if r[2] == "k_block_start")
+    t_end = next(r[1] for r in rows[last_emit:] if r[2] == "k_block_cum")
     sel = [r for r in rows if r[0] >= t_begin and r[1] <= t_end]
     agg = defaultdict(list)
     for s, e, short, r in sel:
