@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--readlen", type=int, default=100)
     ap.add_argument("--leaf-reads", type=int, default=1 << 19)
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="reads per set for the CPU baseline sample (0 = auto)")
+    ap.add_argument("--workload", choices=("iid", "genome"), default="iid",
+                    help="iid = the headline distribution; genome = reads from a shared random genome, 30x coverage, 1 %% substitutions (SURVEY 8(d), secondary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
@@ -77,7 +79,8 @@ def main():
         def progress(done, total, k=k):
             if rank == 0 and (done == total or (done // args.leaf_reads) % 16 == 0):
                 log("input%d: %d / %d reads (%.0f s)" % (k + 1, done, total, time.time() - t_gen))
-        ix = synth.build_index(pkg, seed, args.reads, args.readlen, leaf_reads=args.leaf_reads, device=dev, progress=progress)
+        ix = synth.build_index(pkg, seed, args.reads, args.readlen, leaf_reads=args.leaf_reads, device=dev, progress=progress,
+                               workload=args.workload)
         ix.encode()
         sets.append(ix)
     torch.cuda.empty_cache()
@@ -183,7 +186,7 @@ def main():
         got = synth.extract_sequences(pkg, last, ids, max_len=args.readlen + 8)
         for j, seq in zip(ids, got):
             seed, idx = (1001, int(j)) if j < A0.sequences else (1002, int(j - A0.sequences))
-            ref = synth.generate_reads(seed, idx, 1, args.readlen)[0].tolist()
+            ref = synth.make_reads(args.workload, seed, idx, 1, args.readlen, args.reads)[0].tolist()
             verified = verified and (seq == ref)
         # the emitted native stream must decode back to the merged index (header check in upload)
         p, nb = last.device_data()
@@ -206,8 +209,9 @@ def main():
             "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(sec_per_step * 1e3, 2), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "two %.3g Gbase synthetic %d bp read sets (sigma=6), native format, inputs resident in HBM" %
-                       (n_a / 1e9, args.readlen), "reads_per_set": args.reads, "read_length": args.readlen,
+            "config": {"workload": "two %.3g Gbase synthetic %d bp read sets (%s), native format, inputs resident in HBM" %
+                       (n_a / 1e9, args.readlen, "sigma=6" if args.workload == "iid" else "reads from a shared random genome, 30x coverage, 1% substitutions"),
+                       "reads_per_set": args.reads, "read_length": args.readlen,
                        "bases": [n_a, n_b], "native_bytes": [bytes_a, bytes_b, out_bytes],
                        "parallelism": "sequence blocks of input2 sharded over %d GPU(s)%s" %
                        (world, ", RCCL all-reduce of the rank-array bitvector" if world > 1 else "")},
@@ -233,7 +237,7 @@ def cpu_baseline(pkg, synth, torch, np, dev, args):
     t0 = time.time()
     fm = []
     for seed in (1001, 1002):
-        sym = synth.leaf_bwt(synth.generate_reads(seed, 0, n, args.readlen, device=dev)).cpu().numpy()
+        sym = synth.leaf_bwt(synth.make_reads(args.workload, seed, 0, n, args.readlen, n, device=dev)).cpu().numpy()
         fm.append(orc.FMI.from_symbols(sym))
     a, b = fm
     A = pkg.Index.upload(a.data, a.sequences, a.bases)

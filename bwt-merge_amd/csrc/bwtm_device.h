@@ -229,26 +229,28 @@ BWTM_HD u64 long_run_bytes(u64 offset, u64 length)
   return bytes;
 }
 
-// Writes the encoding at out[offset...]; returns the number of bytes written.  When `block_start` is
-// given, every piece of the run that opens a 64-byte block records the sequence position it starts at
-// (`run_start` = position of the run): block_start[b] - 1 are the set bits of block_boundaries, bwt.cpp:496.
-BWTM_HD u64 long_run_write(u8* out, u64 offset, u32 sym, u64 length, u64* block_start = nullptr, u64 run_start = 0)
+// Writes the encoding of a run appended at byte offset `offset` of the stream; returns the number of bytes
+// written.  The bytes go to out[offset - origin ...] (origin = stream offset of out[0]: a staging buffer
+// holds a window of the stream).  When `block_start` is given, every piece of the run that opens a 64-byte
+// block records the sequence position it starts at (`run_start` = position of the run): block_start[b] - 1
+// are the set bits of block_boundaries, bwt.cpp:496.
+BWTM_HD u64 long_run_write(u8* out, u64 offset, u32 sym, u64 length, u64* block_start = nullptr, u64 run_start = 0, u64 origin = 0)
 {
   u64 start = offset;
   while(length > 0)
   {
     if(block_start && (offset % RLE_BLOCK) == 0) { block_start[offset / RLE_BLOCK] = run_start; }
-    if(length < MAX_RUN) { out[offset++] = (u8)(sym + 6 * (length - 1)); break; }
+    if(length < MAX_RUN) { out[offset - origin] = (u8)(sym + 6 * (length - 1)); offset++; break; }
     u64 remaining = RLE_BLOCK - (offset % RLE_BLOCK);
     u64 basic = (remaining > 1 ? MAX_RUN : MAX_RUN - 1);
-    out[offset++] = (u8)(sym + 6 * (basic - 1)); length -= basic; run_start += basic; remaining--;
+    out[offset - origin] = (u8)(sym + 6 * (basic - 1)); offset++; length -= basic; run_start += basic; remaining--;
     if(remaining > 0)
     {
       u64 ext = length;
       if(bit_length64(length) > 7 * remaining) { ext = (~0ull) >> (64 - 7 * remaining); }
       length -= ext; run_start += ext;
-      while(ext > 0x7F) { out[offset++] = (u8)((ext & 0x7F) | 0x80); ext >>= 7; }
-      out[offset++] = (u8)ext;
+      while(ext > 0x7F) { out[offset - origin] = (u8)((ext & 0x7F) | 0x80); offset++; ext >>= 7; }
+      out[offset - origin] = (u8)ext; offset++;
     }
   }
   return offset - start;

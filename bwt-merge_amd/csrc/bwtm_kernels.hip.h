@@ -1892,12 +1892,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_lasthead(const uint4* rec
   if(lane_id() == 0) { lasthead[seg] = best; }
 }
 
-// Per-lane event statistics of a tile: number of events, and whether any of them is a run of >= 42
-// (a head with no other head among the 41 positions before it).  `before` = (position of the last head
-// before this tile) + 1.  nlong is 0 or 1.
-__device__ inline void tile_event_stats(const TileInfo& ti, u64 tile_base, u64 before, u32& nev, u32& nlong)
+// Per-lane event statistics of a tile: number of events and the LONG events among them (heads that end a
+// run of >= 42: no other head among the 41 positions before them; at most two per tile).  `before` =
+// (position of the last head before this tile) + 1.
+__device__ inline void tile_event_stats(const TileInfo& ti, u64 tile_base, u64 before, u32& nev, u64& long_mask)
 {
-  nev = (u32)__builtin_popcountll(ti.E); nlong = 0;
+  nev = (u32)__builtin_popcountll(ti.E); long_mask = 0;
   const u64 H = ti.H;
   if(H == 0) { return; }
   // covered = OR of H << k for k = 1..41: positions that have a head among the 41 positions before them
@@ -1907,9 +1907,33 @@ __device__ inline void tile_event_stats(const TileInfo& ti, u64 tile_base, u64 b
   s |= s << 8; s |= s << 16;                       // k = 1..32
   const u64 covered = s | (s9 << 32);              // k = 1..41
   const u64 later = H & (H - 1);                   // heads other than the first one of the tile
-  if((later & ~covered) != 0) { nlong = 1; return; }
+  long_mask = later & ~covered;
   const u64 pos = tile_base + (u32)__builtin_ctzll(H);   // first head: its run started before the tile
-  if(pos > 0 && pos + 1 - before >= MAX_RUN) { nlong = 1; }
+  if(pos > 0 && pos + 1 - before >= MAX_RUN) { long_mask |= H & (0 - H); }
+}
+
+// The long events of a chunk in position order.  f(t, bit, g, len): tile (lane) t, head bit, number of
+// events of the chunk before this one, run length.  All arguments are wave-uniform.
+template<class F>
+__device__ inline void for_each_long_event(const TileInfo& ti, u64 first_tile, u64 before, u64 long_mask, u32 ev_excl, F&& f)
+{
+  u64 pending = __ballot(long_mask != 0);
+  while(pending)
+  {
+    const int t = (int)__builtin_ctzll(pending); pending &= pending - 1;
+    u64 lm = shfl_u64(long_mask, t);
+    const u64 H = shfl_u64(ti.H, t), E = shfl_u64(ti.E, t), bf = shfl_u64(before, t);
+    const u32 ex = (u32)__shfl((int)ev_excl, t, WAVE);
+    const u64 tb = (first_tile + (u64)t) << 6;
+    while(lm)
+    {
+      const u32 b = (u32)__builtin_ctzll(lm); lm &= lm - 1;
+      const u64 below = (1ull << b) - 1;
+      const u64 hb = H & below;
+      const u64 prev1 = (hb != 0 ? tb + (63 - (u64)__builtin_clzll(hb)) + 1 : bf);     // (previous head) + 1
+      f((u32)t, b, ex + (u32)__builtin_popcountll(E & below), tb + b + 1 - prev1);
+    }
+  }
 }
 
 __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_size(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 nseg,
@@ -1935,34 +1959,19 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_size(const uint4* recs, u
     u64 before = shfl_up_u64(incl, 1);
     if(lane_id() == 0) { before = NONE; }
     if(last > before) { before = last; }
-    u32 nev, nlong;
-    tile_event_stats(ti, T << 6, before, nev, nlong);
-    u64 chunk_events = wave_sum(nev);
-    bool slow = (__ballot(nlong > 0) != 0);
-    if(!slow) { acc += chunk_events; }
-    else
+    u32 nev; u64 long_mask;
+    tile_event_stats(ti, T << 6, before, nev, long_mask);
+    const u64 ev_incl = wave_incl_sum(nev);
+    const u32 chunk_events = (u32)shfl_u64(ev_incl, WAVE - 1);
+    // Events shorter than 42 are one byte under every hypothesis; only the long ones are resolved in order.
+    u32 last_g = 0;
+    for_each_long_event(ti, ft, before, long_mask, (u32)(ev_incl - nev), [&](u32, u32, u32 g, u64 len)
     {
-      for(int t = 0; t < WAVE; t++)
-      {
-        u32 t_nlong = (u32)__shfl((int)nlong, t, WAVE);
-        u32 t_nev = (u32)__shfl((int)nev, t, WAVE);
-        if(t_nlong == 0) { acc += t_nev; continue; }
-        u64 h = shfl_u64(ti.H, t);
-        u64 cur = shfl_u64(before, t);
-        u64 tb = (ft + (u64)t) << 6;
-        while(h)
-        {
-          u32 b = (u32)__builtin_ctzll(h); h &= h - 1;
-          u64 pos = tb + b;
-          if(pos > 0)
-          {
-            u64 len = pos + 1 - cur;
-            acc += (len < MAX_RUN ? 1 : long_run_bytes((u64)o + acc, len));
-          }
-          cur = pos + 1;
-        }
-      }
-    }
+      acc += g - last_g;
+      acc += long_run_bytes((u64)o + acc, len);
+      last_g = g + 1;
+    });
+    acc += chunk_events - last_g;
     u64 m = shfl_u64(incl, WAVE - 1);
     if(m > last) { last = m; }
   }
@@ -2023,11 +2032,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
     u64 before = shfl_up_u64(incl, 1);
     if(lane_id() == 0) { before = NONE; }
     if(last > before) { before = last; }
-    u32 nev, nlong;
-    tile_event_stats(ti, T << 6, before, nev, nlong);
+    u32 nev; u64 long_mask;
+    tile_event_stats(ti, T << 6, before, nev, long_mask);
     u64 ev_incl = wave_incl_sum(nev);
     u64 chunk_events = shfl_u64(ev_incl, WAVE - 1);
-    bool slow = (__ballot(nlong > 0) != 0);
+    bool slow = (__ballot(long_mask != 0) != 0);
     if(!slow)
     {
       // Every event is a run shorter than 42: one byte each, in position order.  The bytes are
@@ -2082,38 +2091,62 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
     }
     else
     {
-      // Some run of >= 42 ends here: encode the chunk sequentially (all lanes follow, lane 0 writes).
-      for(int t = 0; t < WAVE; t++)
+      // Some runs of >= 42 end in this chunk.  Their sizes depend on their byte offsets, so they are resolved
+      // in order (a handful per chunk); every other event is one byte at (its event index + the extra bytes
+      // of the long events before it), and all lanes write their tiles in parallel as above.
+      u8* lds = stage[threadIdx.x >> 6];
+      const u32 a = (u32)(off & 15);
+      const u64 origin = off - a;                                      // stream offset of lds[0]
+      const u32 ev_excl = (u32)(ev_incl - nev);
+      u32 extra = 0, shift = 0;                                      // extra bytes of all long events / of those in earlier tiles
+      for_each_long_event(ti, ft, before, long_mask, ev_excl, [&](u32 t, u32, u32 g, u64 len)
       {
-        TileInfo tt;
-        tt.p0 = shfl_u64(ti.p0, t); tt.p1 = shfl_u64(ti.p1, t); tt.p2 = shfl_u64(ti.p2, t);
-        tt.prev = (u32)__shfl((int)ti.prev, t, WAVE);
-        u64 h = shfl_u64(ti.H, t);
-        u64 cur = shfl_u64(before, t);
-        u64 tb = (ft + (u64)t) << 6;
+        const u32 sz = (u32)long_run_bytes(off + g + extra, len);
+        if(lane_id() > t) { shift += sz - 1; }
+        extra += sz - 1;
+      });
+      if(ti.H != 0)
+      {
+        const u64 tb = T << 6;
+        u32 idx = a + ev_excl + shift;
+        u64 h = ti.H;
+        const u32 b0 = (u32)__builtin_ctzll(h);
+        u64 prev1;                                                     // (previous head) + 1
+        u32 run_sym;
+        if(tb + b0 == 0) { h &= h - 1; prev1 = 1; run_sym = (u32)(ti.p0 & 1) | ((u32)(ti.p1 & 1) << 1) | ((u32)(ti.p2 & 1) << 2); }
+        else { prev1 = before; run_sym = event_symbol(ti, b0); }
         while(h)
         {
-          u32 b = (u32)__builtin_ctzll(h); h &= h - 1;
-          u64 pos = tb + b;
-          if(pos > 0)
+          const u32 b = (u32)__builtin_ctzll(h); h &= h - 1;
+          const u64 pos = tb + b, len = pos + 1 - prev1;
+          if((long_mask >> b) & 1)
           {
-            u64 len = pos + 1 - cur;
-            u32 sym = event_symbol(tt, b);
-            if(len < MAX_RUN)
-            {
-              if(lane_id() == 0) { out[off] = (u8)(sym + 6 * (len - 1)); if((off & (RLE_BLOCK - 1)) == 0) { block_start[off >> 6] = cur - 1; } }
-              off += 1;
-            }
-            else
-            {
-              u64 nb = long_run_bytes(off, len);
-              if(lane_id() == 0) { long_run_write(out, off, sym, len, block_start, cur - 1); }
-              off += nb;
-            }
+            idx += (u32)long_run_write(lds, origin + idx, run_sym, len, block_start, prev1 - 1, origin);
           }
-          cur = pos + 1;
+          else
+          {
+            if(((origin + idx) & (RLE_BLOCK - 1)) == 0) { block_start[(origin + idx) >> 6] = prev1 - 1; }
+            lds[idx++] = (u8)(run_sym + 6 * (len - 1));
+          }
+          run_sym = (u32)((ti.p0 >> b) & 1) | ((u32)((ti.p1 >> b) & 1) << 1) | ((u32)((ti.p2 >> b) & 1) << 2);
+          prev1 = pos + 1;
         }
       }
+      __builtin_amdgcn_wave_barrier();
+      const u32 total = a + (u32)chunk_events + extra;
+      u8* base = out + origin;                                         // 16-byte aligned
+      for(u32 j = lane_id(); j * 16 < total; j += WAVE)
+      {
+        u32 lo = 16 * j, hi = lo + 16;
+        if(lo >= a && hi <= total) { *(uint4*)(base + lo) = *(const uint4*)(lds + lo); }
+        else
+        {
+          u32 from = (lo > a ? lo : a), to = (hi < total ? hi : total);
+          for(u32 t = from; t < to; t++) { base[t] = lds[t]; }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      off += chunk_events + extra;
     }
     u64 m = shfl_u64(incl, WAVE - 1);
     if(m > last) { last = m; }

@@ -54,6 +54,35 @@ def generate_reads(seed, first_read, nreads, readlen, device="cpu"):
     return base.to(torch.uint8)
 
 
+GENOME_SEED = 7777
+
+
+def generate_genome_reads(seed, first_read, nreads, readlen, genome_len, device="cpu", error_percent=1):
+    """Secondary distribution of SURVEY.md 8(d): reads sampled uniformly from a random ACGT genome (the same
+    genome for every set, base k = 1 + splitmix64(k) % 4) with `error_percent` % substitutions.  Counter-based
+    like generate_reads, so any read can be regenerated on its own.  [nreads, readlen] uint8, comp values 1..4."""
+    j = torch.arange(first_read, first_read + nreads, dtype=torch.int64, device=device).unsqueeze(1)
+    t = torch.arange(readlen, dtype=torch.int64, device=device).unsqueeze(0)
+    span = max(1, genome_len - readlen + 1)
+    start = _lsr(_mix(j * _s64(_GAMMA) + _s64(seed * 3 + 1)), 1) % span
+    pos = start + t
+    g = _mix(pos * _s64(_GAMMA) + _s64(GENOME_SEED)) & 3
+    z = _mix((j * 256 + t) * _s64(2 * _GAMMA) + _s64(seed + 5 * _GAMMA))
+    is_sub = (_lsr(z, 8) % 100) < error_percent
+    other = (g + 1 + ((z & 0xFF) % 3)) & 3                                  # one of the three other bases
+    return (1 + torch.where(is_sub, other, g)).to(torch.uint8)
+
+
+def make_reads(workload, seed, first_read, nreads, readlen, total_reads, device="cpu"):
+    """Reads first_read .. first_read + nreads - 1 of set `seed` for a named workload: "iid" (the headline
+    distribution) or "genome" (30x coverage of a shared random genome, 1 % substitutions)."""
+    if workload == "iid":
+        return generate_reads(seed, first_read, nreads, readlen, device=device)
+    if workload == "genome":
+        return generate_genome_reads(seed, first_read, nreads, readlen, max(readlen, total_reads * readlen // 30), device=device)
+    raise ValueError("unknown workload %r" % workload)
+
+
 def leaf_bwt(reads):
     """BWT (one comp value per byte, endmarkers 0) of the collection reads[0], reads[1], ...
     Suffixes are compared symbol by symbol with the endmarker smallest; equal suffixes (both
@@ -100,12 +129,12 @@ def merge_indexes(pkg, a, b, free_inputs=True):
     return out
 
 
-def build_index(pkg, seed, nreads, readlen=100, leaf_reads=1 << 19, device="cuda", progress=None):
+def build_index(pkg, seed, nreads, readlen=100, leaf_reads=1 << 19, device="cuda", progress=None, workload="iid"):
     """Index of the synthetic set `seed` (reads 0 .. nreads-1 in generation order)."""
     stack = []                               # (level, index); adjacent entries are adjacent read ranges
     for first in range(0, nreads, leaf_reads):
         count = min(leaf_reads, nreads - first)
-        reads = generate_reads(seed, first, count, readlen, device=device)
+        reads = make_reads(workload, seed, first, count, readlen, nreads, device=device)
         sym = leaf_bwt(reads).contiguous()
         if sym.is_cuda:
             torch.cuda.synchronize()
