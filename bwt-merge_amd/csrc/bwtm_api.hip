@@ -312,9 +312,15 @@ int transcode(bwtm_index* x)
   LAUNCH("build_sup", k_build_sup, div_up(x->nsup * WAVE, BLOCK_THREADS), BLOCK_THREADS,   // one wave per super
     x->native_bytes(), x->nbytes, x->block_start.as<const u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, x->n,
     x->sup.as<u64>(), x->nsup);
-  LAUNCH("build_recs", k_build_recs, div_up(x->ngroups, BLOCK_THREADS / WAVE), BLOCK_THREADS,   // one wave per group
-    x->native_bytes(), x->nbytes, x->block_start.as<const u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, x->n,
-    x->sup.as<const u64>(), x->recs.as<uint4>(), x->nrecs);
+  // one wave per group; LDS window sized to the positions a group covers on average (iid reads: ~5300)
+  const u64 per_group = x->n / x->ngroups;
+#define BUILD_RECS(W, WAVES) LAUNCH("build_recs", (k_build_recs<W, WAVES>), div_up(x->ngroups, WAVES), WAVES * WAVE, \
+    x->native_bytes(), x->nbytes, x->block_start.as<const u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, x->n, \
+    x->sup.as<const u64>(), x->recs.as<uint4>(), x->nrecs)
+  if(per_group <= 6500) { BUILD_RECS(8192, 4); }
+  else if(per_group <= 14000) { BUILD_RECS(16384, 4); }
+  else { BUILD_RECS(32768, 2); }
+#undef BUILD_RECS
   return BWTM_OK;
 }
 

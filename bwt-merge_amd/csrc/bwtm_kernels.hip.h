@@ -416,15 +416,17 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_build_sup(const u8* data, u64
 // r of the window: planes from LDS, header = counts before the group + carried counts of the earlier
 // windows + wave prefix of the records' own counts.  One window is the common case (a group of
 // random-read BWT covers ~5300 positions); compressible streams take more windows over fewer bytes.
-constexpr u32 BR_WINDOW = 8192;
-
-__global__ void __launch_bounds__(BLOCK_THREADS) k_build_recs(const u8* data, u64 nbytes, const u64* block_start,
+// The window is a template parameter: 8192 positions for streams around the iid density, larger windows
+// (fewer waves per workgroup) for compressible streams whose groups cover more positions.
+template<u32 BR_WINDOW, int WAVES>
+__global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64 nbytes, const u64* block_start,
   const u64* gcum, u64 gstride, u64 nblocks, u64 ngroups, u64 n, const u64* sup, uint4* recs, u64 nrecs)
 {
-  __shared__ u32 stage[BLOCK_THREADS / WAVE][STAGE_ROWS * STAGE_WORDS];
-  __shared__ uint4 planes[BLOCK_THREADS / WAVE][3][BR_WINDOW / 128];
+  constexpr u32 PW = BR_WINDOW / 32;                             // words per plane
+  __shared__ u32 stage[WAVES][STAGE_ROWS * STAGE_WORDS];
+  __shared__ uint4 planes[WAVES][3][BR_WINDOW / 128];
   const u32 lane = lane_id(), wave = threadIdx.x >> 6;
-  const u64 g = (u64)blockIdx.x * (BLOCK_THREADS / WAVE) + wave;
+  const u64 g = (u64)blockIdx.x * WAVES + wave;
   if(g >= ngroups) { return; }
   const u64 first = g * GROUP;
   const bool last_group = (g + 1 == ngroups);
@@ -442,11 +444,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_build_recs(const u8* data, u6
   u64 a1 = gcum[1 * gstride + g], a2 = gcum[2 * gstride + g], a3 = gcum[3 * gstride + g],
       a4 = gcum[4 * gstride + g], a5 = gcum[5 * gstride + g];   // counts before the first record of the window
   const u64 pos_end = ((q_hi << REC_SHIFT) < n ? (q_hi << REC_SHIFT) : n);
-  u32* pl = (u32*)planes[wave];                                 // plane k: words [256 k, 256 k + 256)
+  u32* pl = (u32*)planes[wave];                                 // plane k: words [PW k, PW k + PW)
   for(u64 ws = S & ~(u64)(REC_POS - 1); (ws >> REC_SHIFT) < q_hi; ws += BR_WINDOW)
   {
 #pragma unroll
-    for(int k = 0; k < 12; k++) { pl[k * 64 + lane] = 0; }
+    for(u32 k = 0; k < 3 * PW / WAVE; k++) { pl[k * 64 + lane] = 0; }
     wave_sync_lds();
     const u64 we = (ws + BR_WINDOW < pos_end ? ws + BR_WINDOW : pos_end);
     const bool inside = (have && bstart >= ws && bend <= ws + BR_WINDOW);
@@ -464,14 +466,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_build_recs(const u8* data, u6
         fill += take;
         if(fill >= 32)
         {
-          atomicOr(&pl[wi], (u32)acc0); atomicOr(&pl[256 + wi], (u32)acc1); atomicOr(&pl[512 + wi], (u32)acc2);   // edge words are shared with the neighbours
+          atomicOr(&pl[wi], (u32)acc0); atomicOr(&pl[PW + wi], (u32)acc1); atomicOr(&pl[2 * PW + wi], (u32)acc2);   // edge words are shared with the neighbours
           acc0 >>= 32; acc1 >>= 32; acc2 >>= 32; fill -= 32; wi++;
         }
       };
       for_each_run<false>(rows + lane * STAGE_WORDS, valid,
         [&](u32 sym, u32 l) { append(sym, (l < 32 ? l : 32u)); if(l > 32) { append(sym, l - 32); } },
         [&](u32 sym, u64 len) { u32 l = (u32)len; while(l > 0) { u32 take = (l < 32 ? l : 32u); append(sym, take); l -= take; } });
-      if(fill > 0 && wi < BR_WINDOW / 32) { atomicOr(&pl[wi], (u32)acc0); atomicOr(&pl[256 + wi], (u32)acc1); atomicOr(&pl[512 + wi], (u32)acc2); }
+      if(fill > 0 && wi < BR_WINDOW / 32) { atomicOr(&pl[wi], (u32)acc0); atomicOr(&pl[PW + wi], (u32)acc1); atomicOr(&pl[2 * PW + wi], (u32)acc2); }
     }
     else if(have && bstart < we && bend > ws)
     {
@@ -484,7 +486,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_build_recs(const u8* data, u6
           const u32 w = a >> 5;
           if(w != cur)
           {
-            if(acc0) { atomicOr(&pl[cur], acc0); } if(acc1) { atomicOr(&pl[256 + cur], acc1); } if(acc2) { atomicOr(&pl[512 + cur], acc2); }
+            if(acc0) { atomicOr(&pl[cur], acc0); } if(acc1) { atomicOr(&pl[PW + cur], acc1); } if(acc2) { atomicOr(&pl[2 * PW + cur], acc2); }
             cur = w; acc0 = 0; acc1 = 0; acc2 = 0;
           }
           const u32 stop = (e < ((w + 1) << 5) ? e : ((w + 1) << 5));
@@ -502,11 +504,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_build_recs(const u8* data, u6
         if(sym != 0 && to > ws && from < we) { deposit(sym, (from > ws ? (u32)(from - ws) : 0u), (to < we ? (u32)(to - ws) : (u32)(we - ws))); }
       };
       for_each_run<false>(rows + lane * STAGE_WORDS, valid, [&](u32 sym, u32 l) { run(sym, (u64)l); }, run);
-      if(acc0) { atomicOr(&pl[cur], acc0); } if(acc1) { atomicOr(&pl[256 + cur], acc1); } if(acc2) { atomicOr(&pl[512 + cur], acc2); }
+      if(acc0) { atomicOr(&pl[cur], acc0); } if(acc1) { atomicOr(&pl[PW + cur], acc1); } if(acc2) { atomicOr(&pl[2 * PW + cur], acc2); }
     }
     wave_sync_lds();
-    // record `lane` of the window
-    const uint4 P0 = planes[wave][0][lane], P1 = planes[wave][1][lane], P2 = planes[wave][2][lane];
+    // records rr * 64 + lane of the window
+    for(u32 rr = 0; rr < BR_WINDOW / 8192; rr++)
+    {
+    const uint4 P0 = planes[wave][0][rr * 64 + lane], P1 = planes[wave][1][rr * 64 + lane], P2 = planes[wave][2][rr * 64 + lane];
     u32 n1 = 0, n2 = 0, n3 = 0, n4 = 0, n5 = 0;
 #define BWTM_COUNT_WORD(f) \
     n1 += (u32)__builtin_popcount(plane_match(P0.f, P1.f, P2.f, 1)); n2 += (u32)__builtin_popcount(plane_match(P0.f, P1.f, P2.f, 2)); \
@@ -517,7 +521,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_build_recs(const u8* data, u6
     const u64 own14 = (u64)n1 | ((u64)n2 << 16) | ((u64)n3 << 32) | ((u64)n4 << 48);   // wave totals <= 8192 per field
     const u64 incl14 = wave_incl_sum(own14), incl5 = wave_incl_sum((u64)n5);
     const u64 before14 = incl14 - own14, before5 = incl5 - n5;
-    const u64 q = (ws >> REC_SHIFT) + lane;
+    const u64 q = (ws >> REC_SHIFT) + rr * 64 + lane;
     if(q >= q_lo && q < q_hi)
     {
       const u64 p = q << REC_SHIFT;
@@ -536,6 +540,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_build_recs(const u8* data, u6
     }
     const u64 tot14 = shfl_u64(incl14, WAVE - 1), tot5 = shfl_u64(incl5, WAVE - 1);
     a1 += tot14 & 0xFFFF; a2 += (tot14 >> 16) & 0xFFFF; a3 += (tot14 >> 32) & 0xFFFF; a4 += tot14 >> 48; a5 += tot5;
+    }
     wave_sync_lds();                                             // the planes are cleared again by the next window
   }
 }

@@ -50,8 +50,9 @@ def check_index(ix, sym, rng, nq=4000):
 
 def test_upload_builds_exact_rank_structure(gpu, oracle):
     rng = np.random.default_rng(1)
-    for lengths in ([1, 1, 1, 2, 3], [1, 2, 41, 42, 43, 169, 170, 5000], [16425, 16426, 100000, 1, 7]):
-        sym = run_symbols(rng, 3000, lengths)
+    # run-length mixes chosen so that all three LDS window sizes of the transcode are used (positions per 62-block group)
+    for lengths in ([1, 1, 1, 2, 3], [2, 3, 4], [1, 2, 41, 42, 43, 169, 170, 5000], [16425, 16426, 100000, 1, 7]):
+        sym = run_symbols(rng, 3000 if max(lengths) > 4 else 60000, lengths)
         f = oracle.FMI.from_symbols(sym)
         ix = gpu.Index.upload(f.data, f.sequences, f.bases)
         assert (ix.sequences, ix.nbytes, ix.blocks) == (f.sequences, f.nbytes, f.blocks)
