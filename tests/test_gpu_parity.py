@@ -192,7 +192,7 @@ def test_empty_increment_and_empty_base(gpu, oracle):
     assert np.array_equal(gpu.merge(E, A).data(), a.data)
 
 
-@pytest.mark.parametrize("case", ["mixed", "boundaries", "giant", "tiny", "alternating"])
+@pytest.mark.parametrize("case", ["mixed", "boundaries", "sparse_long", "giant", "tiny", "alternating"])
 def test_encoder_block_rule(gpu, oracle, case):
     """Run::write's offset-dependent forms (support.h:256-282), including runs that end in
     chunks far from where they start, against the oracle's encoder."""
@@ -203,6 +203,11 @@ def test_encoder_block_rule(gpu, oracle, case):
     elif case == "boundaries":
         # many long runs so that every offset mod 64 is met by 41/42/43/169/170-length runs
         syms = [run_symbols(rng, 60000, [41, 42, 43, 44, 168, 169, 170, 171, 1])]
+    elif case == "sparse_long":
+        # chunks of mostly one-byte events with a few runs >= 42 among them: the parallel long-event path
+        # (offsets of the short events shifted by the extra bytes of the long ones before them)
+        syms = [run_symbols(rng, 400000, [1] * 30 + [2] * 10 + [3, 7, 42, 45, 100, 171, 200, 3000]),
+                run_symbols(rng, 100000, [1] * 6 + [41, 42, 50, 64, 65, 127, 128, 129])]
     elif case == "giant":
         syms = [np.full(5_000_000, 3, dtype=np.uint8),
                 np.concatenate([np.full(70000, 1, np.uint8), np.full(1, 2, np.uint8), np.full(4096 * 64 * 16 + 5, 4, np.uint8)])]
