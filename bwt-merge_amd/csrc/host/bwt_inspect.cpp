@@ -1,0 +1,48 @@
+/*
+  bwt_inspect -- prints the headers of BWT files (reference bwt_inspect.cpp:38-108): native, SGA and
+  RopeBWT files identify themselves by their tags; everything else is "Unknown format".
+*/
+#include "fmi.h"
+
+using namespace bwtmerge;
+
+size_type Parallel::max_threads = 1;
+
+int main(int argc, char** argv)
+{
+  if(argc < 2) { std::cerr << "Usage: bwt_inspect input1 [input2 ...]" << std::endl << std::endl; std::exit(EXIT_SUCCESS); }
+
+  std::cout << "Inspecting BWT files" << std::endl << std::endl;
+
+  size_type total_sequences = 0, total_bases = 0;
+  for(int arg = 1; arg < argc; arg++)
+  {
+    std::cout << argv[arg] << ": "; std::cout.flush();
+    std::ifstream in(argv[arg], std::ios_base::binary);
+    if(!in) { std::cerr << "bwt_inspect: Cannot open input file " << argv[arg] << std::endl; continue; }
+
+    NativeHeader native; native.load(in);
+    if(in && native.check())
+    {
+      total_sequences += native.sequences; total_bases += native.bases;
+      std::cout << NativeFormat::name() << ": " << native.sequences << " sequences, " << native.bases << " bases, "
+                << alphabetName(native.order()) << " alphabet" << std::endl;
+      continue;
+    }
+    in.clear(); in.seekg(0);
+    SGAHeader sga; sga.load(in);
+    if(in && sga.check())
+    {
+      total_sequences += sga.sequences; total_bases += sga.bases;
+      std::cout << SGAFormat::name() << ": " << sga.sequences << " sequences, " << sga.bases << " bases, " << sga.bytes << " bytes" << std::endl;
+      continue;
+    }
+    in.clear(); in.seekg(0);
+    RopeHeader rope; rope.load(in);
+    if(in && rope.check()) { std::cout << RopeFormat::name() << std::endl; continue; }
+    std::cout << "Unknown format" << std::endl;
+  }
+  std::cout << std::endl;
+  std::cout << "Total: " << total_sequences << " sequences, " << total_bases << " bases" << std::endl << std::endl;
+  return 0;
+}

@@ -1,6 +1,6 @@
 /*
   bwt_merge -- merges BWT files, with the hot path on an MI355X.  Same command line and the
-  same stdout lines as the reference tool (bwt_merge.cpp:47-299); formats: native, plain_default.
+  same stdout lines as the reference tool (bwt_merge.cpp:47-299); all formats of formats.h.
 */
 #include <atomic>
 #include <sstream>

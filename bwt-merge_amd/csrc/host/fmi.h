@@ -206,60 +206,67 @@ inline void FMI::load<NativeFormat>(const std::string& filename)
   sdsl_compat::read_member(alpha.sigma, in);
 }
 
-// One character per base (reference PlainData, formats.cpp:126-188).
-template<>
-inline void FMI::serialize<PlainFormatD>(const std::string& filename) const
-{
-  std::ofstream out(filename.c_str(), std::ios_base::binary);
-  if(!out) { std::cerr << "BWT::serialize(): Cannot open output file " << filename << std::endl; return; }
-  std::vector<char> buffer;
-  for(size_type rle_pos = 0; rle_pos < bwt.bytes(); )
-  {
-    range_type run = Run::read(bwt.data, rle_pos);
-    buffer.insert(buffer.end(), run.second, (char)alpha.comp2char[run.first]);
-    if(buffer.size() >= MEGABYTE) { out.write(buffer.data(), buffer.size()); buffer.clear(); }
-  }
-  out.write(buffer.data(), buffer.size());
-}
-
-template<>
-inline void FMI::load<PlainFormatD>(const std::string& filename)
+// Foreign formats (reference FMI::load / serialize<Format>, fmi.h:114-134; BWT::load<Format>, bwt.h:90-104).
+// The file's items become maximal runs first (RunBuffer) and are mapped to comp values afterwards, like the
+// reference does (formats.cpp:147-156: 'a' next to 'A' stays two runs); comp values outside the alphabet map to 0
+// (the identity alphabet of formats.cpp:228, support.cpp:100-104).
+template<class Format>
+inline void FMI::load(const std::string& filename)
 {
   std::ifstream in(filename.c_str(), std::ios_base::binary);
   if(!in) { std::cerr << "BWT::load(): Cannot open input file " << filename << std::endl; std::exit(EXIT_FAILURE); }
-  alpha = Alphabet();
+  const Alphabet order_alpha = createAlphabet(Format::order());
   bwt.data.clear();
-  // Runs are formed on the raw characters and mapped afterwards, like the reference does
-  // (formats.cpp:147-156), so 'a' next to 'A' stays two runs.
   RunBuffer run_buffer;
-  std::vector<char> buffer(MEGABYTE);
-  while(in)
+  auto emit_run = [&](range_type run)
   {
-    in.read(buffer.data(), buffer.size());
-    for(std::streamsize k = 0; k < in.gcount(); k++)
-    {
-      if(run_buffer.add((byte_type)buffer[k])) { Run::write(bwt.data, alpha.char2comp[run_buffer.run.first], run_buffer.run.second); }
-    }
-  }
-  run_buffer.flush(); Run::write(bwt.data, alpha.char2comp[run_buffer.run.first], run_buffer.run.second);
-  bwt.buildFromData(AO_DEFAULT);
+    size_type comp = (Format::characters ? order_alpha.char2comp[run.first & 0xFF] : (run.first < BWT::SIGMA ? run.first : 0));
+    Run::write(bwt.data, (comp_type)comp, run.second);
+  };
+  Format::decode(in, [&](size_type value, size_type length) { if(run_buffer.add(value, length)) { emit_run(run_buffer.run); } });
+  run_buffer.flush(); emit_run(run_buffer.run);
+  bwt.buildFromData(Format::order());
   std::vector<size_type> counts(BWT::SIGMA);
   for(size_type c = 0; c < BWT::SIGMA; c++) { counts[c] = bwt.count(c); }
-  alpha = Alphabet(counts);
+  alpha = Alphabet(counts, order_alpha.char2comp, order_alpha.comp2char);
+  bwt.header.setOrder(identifyAlphabet(alpha));
+}
+
+template<class Format>
+inline void FMI::serialize(const std::string& filename) const
+{
+  if(!compatible(alpha, Format::order()))
+  {
+    std::cerr << "FMI::serialize(): Warning: " << Format::name() << " is not compatible with "
+              << alphabetName(identifyAlphabet(alpha)) << " alphabets!" << std::endl;
+  }
+  std::ofstream out(filename.c_str(), std::ios_base::binary);
+  if(!out) { std::cerr << "BWT::serialize(): Cannot open output file " << filename << std::endl; return; }
+  const Alphabet order_alpha = createAlphabet(Format::order());
+  Format::encode(out, bwt.header, [&](auto&& f)
+  {
+    for(size_type rle_pos = 0; rle_pos < bwt.bytes(); )
+    {
+      range_type run = Run::read(bwt.data, rle_pos);
+      f((size_type)(Format::characters ? order_alpha.comp2char[run.first] : run.first), run.second);
+    }
+  });
 }
 
 inline void serialize(const FMI& fmi, const std::string& filename, const std::string& format)
 {
-  if(format == NativeFormat::tag()) { fmi.serialize<NativeFormat>(filename); }
-  else if(format == PlainFormatD::tag()) { fmi.serialize<PlainFormatD>(filename); }
-  else { std::cerr << "serialize(): Invalid BWT format: " << format << std::endl; std::exit(EXIT_FAILURE); }
+  if(!withFormat(format, [&](auto f) { fmi.serialize<decltype(f)>(filename); }))
+  {
+    std::cerr << "serialize(): Invalid BWT format: " << format << std::endl; std::exit(EXIT_FAILURE);
+  }
 }
 
 inline void load(FMI& fmi, const std::string& filename, const std::string& format)
 {
-  if(format == NativeFormat::tag()) { fmi.load<NativeFormat>(filename); }
-  else if(format == PlainFormatD::tag()) { fmi.load<PlainFormatD>(filename); }
-  else { std::cerr << "load(): Invalid BWT format: " << format << std::endl; std::exit(EXIT_FAILURE); }
+  if(!withFormat(format, [&](auto f) { fmi.load<decltype(f)>(filename); }))
+  {
+    std::cerr << "load(): Invalid BWT format: " << format << std::endl; std::exit(EXIT_FAILURE);
+  }
 }
 
 // Bytes the native serialization takes (stands in for sdsl::size_in_bytes in the size report).

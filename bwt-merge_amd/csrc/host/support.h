@@ -31,6 +31,13 @@ public:
     for(size_type c = 0; c < counts.size() && c < sigma; c++) { C[c + 1] = C[c] + counts[c]; }
   }
 
+  // counts + explicit maps (reference support.cpp:93-105): what FMI::load<Format> builds for a foreign format
+  Alphabet(const std::vector<size_type>& counts, const std::vector<byte_type>& _char2comp, const std::vector<byte_type>& _comp2char) :
+    char2comp(_char2comp), comp2char(_comp2char), C(_comp2char.size() + 1, 0), sigma(_comp2char.size())
+  {
+    for(size_type c = 0; c < counts.size() && c < sigma; c++) { C[c + 1] = C[c] + counts[c]; }
+  }
+
   bool sorted() const
   {
     for(size_type c = 1; c < sigma; c++) { if(comp2char[c - 1] >= comp2char[c]) { return false; } }
