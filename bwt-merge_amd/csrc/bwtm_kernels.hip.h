@@ -1917,27 +1917,39 @@ __device__ inline void tile_event_stats(const TileInfo& ti, u64 tile_base, u64 b
   if(pos > 0 && pos + 1 - before >= MAX_RUN) { long_mask |= H & (0 - H); }
 }
 
-// The long events of a chunk in position order.  f(t, bit, g, len): tile (lane) t, head bit, number of
-// events of the chunk before this one, run length.  All arguments are wave-uniform.
+// The long events of a chunk in position order.  f(t, g, len): tile (lane) t, number of events of the
+// chunk before this one, run length; all arguments are wave-uniform.  Every lane first works out its own
+// (at most two) long events in parallel; the ordered walk then only broadcasts them.
 template<class F>
 __device__ inline void for_each_long_event(const TileInfo& ti, u64 first_tile, u64 before, u64 long_mask, u32 ev_excl, F&& f)
 {
+  u32 g0 = 0, g1 = 0; u64 len0 = 0, len1 = 0;
+  if(long_mask != 0)
+  {
+    const u64 tb = (first_tile + lane_id()) << 6;
+    u64 lm = long_mask;
+#pragma unroll
+    for(int k = 0; k < 2; k++)
+    {
+      if(lm != 0)
+      {
+        const u32 b = (u32)__builtin_ctzll(lm); lm &= lm - 1;
+        const u64 below = (1ull << b) - 1;
+        const u64 hb = ti.H & below;
+        const u64 prev1 = (hb != 0 ? tb + (63 - (u64)__builtin_clzll(hb)) + 1 : before);     // (previous head) + 1
+        const u32 g = ev_excl + (u32)__builtin_popcountll(ti.E & below);
+        const u64 len = tb + b + 1 - prev1;
+        if(k == 0) { g0 = g; len0 = len; } else { g1 = g; len1 = len; }
+      }
+    }
+  }
   u64 pending = __ballot(long_mask != 0);
   while(pending)
   {
     const int t = (int)__builtin_ctzll(pending); pending &= pending - 1;
-    u64 lm = shfl_u64(long_mask, t);
-    const u64 H = shfl_u64(ti.H, t), E = shfl_u64(ti.E, t), bf = shfl_u64(before, t);
-    const u32 ex = (u32)__shfl((int)ev_excl, t, WAVE);
-    const u64 tb = (first_tile + (u64)t) << 6;
-    while(lm)
-    {
-      const u32 b = (u32)__builtin_ctzll(lm); lm &= lm - 1;
-      const u64 below = (1ull << b) - 1;
-      const u64 hb = H & below;
-      const u64 prev1 = (hb != 0 ? tb + (63 - (u64)__builtin_clzll(hb)) + 1 : bf);     // (previous head) + 1
-      f((u32)t, b, ex + (u32)__builtin_popcountll(E & below), tb + b + 1 - prev1);
-    }
+    f((u32)t, (u32)__shfl((int)g0, t, WAVE), shfl_u64(len0, t));
+    const u64 second = shfl_u64(len1, t);
+    if(second != 0) { f((u32)t, (u32)__shfl((int)g1, t, WAVE), second); }
   }
 }
 
@@ -1970,7 +1982,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_size(const uint4* recs, u
     const u32 chunk_events = (u32)shfl_u64(ev_incl, WAVE - 1);
     // Events shorter than 42 are one byte under every hypothesis; only the long ones are resolved in order.
     u32 last_g = 0;
-    for_each_long_event(ti, ft, before, long_mask, (u32)(ev_incl - nev), [&](u32, u32, u32 g, u64 len)
+    for_each_long_event(ti, ft, before, long_mask, (u32)(ev_incl - nev), [&](u32, u32 g, u64 len)
     {
       acc += g - last_g;
       acc += long_run_bytes((u64)o + acc, len);
@@ -2104,7 +2116,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
       const u64 origin = off - a;                                      // stream offset of lds[0]
       const u32 ev_excl = (u32)(ev_incl - nev);
       u32 extra = 0, shift = 0;                                      // extra bytes of all long events / of those in earlier tiles
-      for_each_long_event(ti, ft, before, long_mask, ev_excl, [&](u32 t, u32, u32 g, u64 len)
+      for_each_long_event(ti, ft, before, long_mask, ev_excl, [&](u32 t, u32 g, u64 len)
       {
         const u32 sz = (u32)long_run_bytes(off + g + extra, len);
         if(lane_id() > t) { shift += sz - 1; }
