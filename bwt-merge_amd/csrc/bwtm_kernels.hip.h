@@ -4,15 +4,23 @@
 
   Kernel map (reference code each one replaces):
     k_block_len        BWT::build scan of the run stream            bwt.cpp:487-502
+    k_build_sup/recs   native blocks -> device records ("transcode at upload", BWT::load)
     k_block_cum        samples[c] at the block starts               bwt.cpp:489-511
-    k_build_sup/recs   native blocks -> device records ("transcode at upload")
     k_sym_*            plain symbols -> device records (input tooling)
-    k_lf_walk          buildRA + BWT::inverse_select + BWT::rank    fmi.cpp:272-334, bwt.cpp:318-341, 445-464
-    k_chunk_popc       RA finalize (replaces the sort / merge-buffer / temp-file hierarchy,
-                       fmi.cpp:139-257, support.h:396-638)
+    k_frontier_*       buildRA + BWT::inverse_select + BWT::rank, level-synchronous form (product)
+                                                                    fmi.cpp:272-334, bwt.cpp:318-341, 445-464
+    k_bound_suffix_min, k_tile_build_frontier
+                       mergeRA / RLArray / RankArray: the sorted emits of every step -> bitvector tiles
+                                                                    fmi.cpp:139-257, support.h:396-638
+    k_lf_walk*, k_part_*, k_tile_build
+                       the same two stages in per-chain form (fallback: long sequences, > 40-bit coordinates)
+    k_chunk_popc       RA finalize (prefix counts of the interleaving bitvector)
     k_interleave_*     mergeBWT                                     bwt.cpp:215-282
-    k_enc_*            RunBuffer + Run::write                       utils.h:121-142, support.h:256-282
+    k_enc_*            RunBuffer + Run::write, block starts of BWT::build
+                                                                    utils.h:121-142, support.h:256-282, bwt.cpp:496
     k_fold_*           byte-offset carry of Run::write across segments (array.size() % 64, support.h:267)
+    k_rank_batch, k_inverse_select_batch, k_extract, k_find_batch
+                       BWT::rank / inverse_select / extract, FMI::find  bwt.cpp:318-464, fmi.h:195-221
 */
 #pragma once
 
