@@ -813,14 +813,12 @@ int partition_level2(DevBuf& l1, DevBuf& gcount, u64 cap, u64 nsub, u32 subs, bw
   return BWTM_OK;
 }
 
-// Product path: walk with partitioned emit, level-2 counting sort, tile build (bwtm_kernels.hip.h).
+// Per-chain walk with partitioned emit, level-2 counting sort, tile build (fallback of the frontier search).
 int search_partitioned(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64 count, bwtm_ra* ra)
 {
   const u64 ntiles = div_up(ra->n_out + 1, 1ull << TILE_SHIFT);
   const u64 nsub = div_up(ntiles, L1_BINS);
   if(nsub > 8192) { return search_atomic(a, b, seq_first, count, ra); }       // LDS tables of level 2 would not fit
-  const u64 ntiles_pad = nsub * L1_BINS;
-  const u64 nwords = ra->nchunks * CHUNK_WORDS;
 
   // Rounds bound the temporary regions: emits of a round <= round_emits (estimated from the
   // average sequence length; the regions have slack and an exact fallback).
