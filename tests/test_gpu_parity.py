@@ -183,6 +183,45 @@ def test_merge_entry_point_and_chaining(gpu, oracle):
     assert np.array_equal(again.data(), direct.data)
 
 
+def mixed_length_text(oracle, seed, nreads):
+    """A read set in which reads j with j % 5 < 3 are 100 bp and the others 150 bp (BASELINE config 5: each
+    length contributes half of the bases), sequences in generation order."""
+    long_reads = oracle.generate_reads(seed, nreads, 150).reshape(nreads, 151)
+    parts = []
+    for j in range(nreads):
+        L = 100 if j % 5 < 3 else 150
+        parts.append(long_reads[j, :L]); parts.append(np.zeros(1, dtype=np.uint8))
+    return np.concatenate(parts)
+
+
+def test_config4_and_config5_shapes(gpu, oracle):
+    """BASELINE config 4 (a small set inserted into a 4x larger one) and config 5 (four sets of mixed
+    100 / 150 bp reads merged in command-line order, bwt_merge.cpp:167-173) at a size the oracle can check:
+    every result equals the oracle's BWT of the concatenated collection."""
+    big = oracle.generate_reads(7001, 2400, 100); small = oracle.generate_reads(7002, 600, 100)
+    fb, fs = oracle.FMI.from_text(big), oracle.FMI.from_text(small)
+    m = gpu.merge(gpu.Index.upload(fb.data, fb.sequences, fb.bases), gpu.Index.upload(fs.data, fs.sequences, fs.bases))
+    direct = oracle.FMI.from_text(np.concatenate([big, small]))
+    assert np.array_equal(m.data(), direct.data) and np.array_equal(m.C, direct.C)
+    be, cum = m.samples(); obe, ocum = direct.samples
+    assert np.array_equal(be, obe) and np.array_equal(cum, ocum)
+
+    texts = [mixed_length_text(oracle, 7100 + k, 500) for k in range(4)]
+    running = None
+    for k, t in enumerate(texts):
+        f = oracle.FMI.from_text(t)
+        ix = gpu.Index.upload(f.data, f.sequences, f.bases)
+        if running is None:
+            running = ix
+        else:
+            nxt = gpu.merge(running, ix)
+            nxt.drop_native() if k < len(texts) - 1 else None       # chained merges keep only the rank structure
+            running = nxt
+    direct = oracle.FMI.from_text(np.concatenate(texts))
+    assert (running.sequences, running.bases) == (direct.sequences, direct.bases)
+    assert np.array_equal(running.data(), direct.data) and np.array_equal(running.C, direct.C)
+
+
 def test_empty_increment_and_empty_base(gpu, oracle):
     a = oracle.FMI.from_text(oracle.generate_reads(7, 50, 20))
     e = oracle.FMI.from_symbols(np.zeros(0, dtype=np.uint8))
