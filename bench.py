@@ -46,6 +46,9 @@ def main():
                     help="iid = the headline distribution; genome = reads from a shared random genome, 30x coverage, 1 %% substitutions (SURVEY 8(d), secondary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-GPU code path (process group, caller-owned bitvector, all-reduce) even with one rank: "
+                         "a smoke test of that path on a 1-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -61,8 +64,11 @@ def main():
     torch.cuda.set_device(local_rank)
     pkg.init(local_rank)
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.force_dist
+    if sharded:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
@@ -102,7 +108,7 @@ def main():
         # BWT::load of both inputs: the resident native bytes are read in place (no second copy in HBM)
         A = pkg.Index.from_device(ptr_a, bytes_a, A0.sequences, n_a, borrow=True)
         B = pkg.Index.from_device(ptr_b, bytes_b, B0.sequences, n_b, borrow=True)
-        if world == 1:
+        if not sharded:
             M = pkg.merge(A, B)
         else:
             nbytes = pkg.ra_buffer_bytes(A, B)
