@@ -55,6 +55,7 @@ struct Tuning
   long long walk_kernel = 0;     // 0 = four lanes per chain (product), 1 = one lane per chain (first version, kept for A/B)
   long long walk_ablate = 0;     // timing-only ablations of the no-emit quad kernel (tools/walk_experiments.py)
   long long search_algo = 0;     // 0 = level-synchronous frontier search (product), 1 = per-chain walk with partitioned emit
+  long long frontier_unfused = 0; // 1 = generic scan + k_frontier_prep per step (the path of segment tables with > 8192 tiles)
   long long l1_cap = 0;          // tests only: entries per level-1 region (0 = sized from the input)
   long long walk_variant = 0;    // 0 = four lanes per chain, four pipelined chains per quad (product); 1 = LDS-transposed one chain per lane
   long long scatter_kernel = 0;  // 0 = LDS counting sort (product), 1 = direct scattered stores (first version)
@@ -387,6 +388,7 @@ extern "C" int bwtm_tune(const char* key, long long value)
   else if(k == "walk_variant") { g_tune.walk_variant = value; }
   else if(k == "l1_cap") { g_tune.l1_cap = value; }
   else if(k == "search_algo") { g_tune.search_algo = value; }
+  else if(k == "frontier_unfused") { g_tune.frontier_unfused = value; }
   else if(k == "round_emits") { g_tune.round_emits = (value > 0 ? value : 1); }
   else { return fail(BWTM_EINVAL, "bwtm_tune: unknown key %s", key); }
   return BWTM_OK;
@@ -902,6 +904,8 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   }
   TRY(seg_prefix.alloc((nseg + 1) * sizeof(u64)));
   DevBuf first_seg; TRY(first_seg.alloc((nb_max + 1) * sizeof(u32)));
+  const u64 scan_tiles = div_up(nseg + 1, (u64)SCAN_TILE);
+  DevBuf scan_partial; TRY(scan_partial.alloc(scan_tiles * sizeof(u64)));
   // An epoch emits at most one value per position of b; a shard of the sequences usually far less.
   // Emits past the capacity take the exact atomicOr fallback.
   const u64 per_seq = b->n / (b->m > 0 ? b->m : 1) + 1;
@@ -920,7 +924,22 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   u64 in_epoch = 0;
   for(u64 t = 0; t <= b->n; t++)
   {
-    TRY(device_scan<0>(seg_len[cur].as<u64>(), seg_prefix.as<u64>(), nseg + 1));
+    if(scan_tiles <= FRONTIER_SCAN_TILES && g_tune.frontier_unfused == 0)
+    {
+      // scan of the segment lengths + per-step bookkeeping in two launches (k_frontier_scan)
+      if(scan_tiles > 1)
+      {
+        LAUNCH("scan_reduce", k_scan_reduce<0>, scan_tiles, BLOCK_THREADS, seg_len[cur].as<const u64>(), scan_partial.as<u64>(), nseg + 1, (u64)0, scan_tiles);
+      }
+      LAUNCH("frontier_scan", k_frontier_scan, scan_tiles, BLOCK_THREADS, seg_len[cur].as<const u64>(), scan_partial.as<const u64>(), nseg,
+        seg_prefix.as<u64>(), first_seg.as<u32>(), emit_base.as<u64>(), in_epoch);
+    }
+    else
+    {
+      TRY(device_scan<0>(seg_len[cur].as<u64>(), seg_prefix.as<u64>(), nseg + 1));
+      LAUNCH("frontier_prep", k_frontier_prep, div_up(nseg, BLOCK_THREADS), BLOCK_THREADS, seg_prefix.as<const u64>(), nseg, first_seg.as<u32>(),
+        emit_base.as<u64>(), in_epoch);
+    }
     if(t % 8 == 0)
     {
       u64 alive = 0;
@@ -928,8 +947,6 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
       HIP_TRY(hipStreamSynchronize(g_ctx.stream));
       if(alive == 0) { break; }
     }
-    LAUNCH("frontier_prep", k_frontier_prep, div_up(nseg, BLOCK_THREADS), BLOCK_THREADS, seg_prefix.as<const u64>(), nseg, first_seg.as<u32>(),
-      emit_base.as<u64>(), in_epoch);
     FrontierView f;
     f.lo = lo[cur].as<const uint2>(); f.hi = hi[cur].as<const unsigned short>();
     f.lo_next = lo[1 - cur].as<uint2>(); f.hi_next = hi[1 - cur].as<unsigned short>();

@@ -1607,6 +1607,49 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_prep(const u64* seg_
   if(b * FR_BLOCK < end) { first_seg[b] = (u32)sgm; }
 }
 
+// The same bookkeeping fused into the scan of the segment lengths (the path used when the segment table has at
+// most FRONTIER_SCAN_TILES tiles): after k_scan_reduce has produced one total per 2048-entry tile, every block
+// sums the totals before its tile itself, scans its tile, and publishes seg_prefix, first_seg and emit_base --
+// two launches per step instead of four.
+constexpr u64 FRONTIER_SCAN_TILES = 8192;
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_scan(const u64* seg_len, const u64* partial, u64 nseg, u64* seg_prefix, u32* first_seg,
+  u64* emit_base, u64 step)
+{
+  __shared__ u64 lds[BLOCK_THREADS / WAVE];
+  const u64 n = nseg + 1;                                            // the entry after the last segment holds 0 and receives N_t
+  u64 c = 0;
+  for(u64 k = threadIdx.x; k < blockIdx.x; k += BLOCK_THREADS) { c += partial[k]; }
+  const u64 carry = block_reduce<0>(c, lds);
+  const u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+  u64 item[SCAN_ITEMS];
+  u64 acc = 0;
+  for(int k = 0; k < SCAN_ITEMS; k++) { item[k] = (base + k < n ? seg_len[base + k] : 0); acc += item[k]; }
+  const u64 incl = wave_incl_sum(acc);
+  const u64 wave_total = shfl_u64(incl, WAVE - 1);
+  u64 excl = shfl_up_u64(incl, 1);
+  if(lane_id() == 0) { excl = 0; }
+  if(lane_id() == 0) { lds[threadIdx.x >> 6] = wave_total; }
+  __syncthreads();
+  u64 run = carry + excl;
+  for(int k = 0; k < (int)(threadIdx.x >> 6); k++) { run += lds[k]; }
+  for(int k = 0; k < SCAN_ITEMS; k++)
+  {
+    const u64 idx = base + k;
+    if(idx < n)
+    {
+      seg_prefix[idx] = run;
+      if(idx < nseg)
+      {
+        const u64 b = (run + FR_BLOCK - 1) / FR_BLOCK;
+        if(b * FR_BLOCK < run + item[k]) { first_seg[b] = (u32)idx; }
+      }
+      else { emit_base[step + 1] = emit_base[step] + run; }
+    }
+    run += item[k];
+  }
+}
+
 // Row t of the boundary table: bound[T] = logical index of the first element of step t whose bit
 // position lies in tile >= T (suffix minimum over the markers; N_t past the last element).
 __global__ void __launch_bounds__(BLOCK_THREADS) k_bound_suffix_min(u32* bound, u64 ntiles, const u64* emit_base, u64 nsteps)

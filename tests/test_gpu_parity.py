@@ -296,12 +296,12 @@ def test_partitioned_emit_rounds_fallbacks_and_variants(gpu, oracle):
             ora = oracle.ra_from_runs(ranks, counts)
             A = gpu.Index.upload(a.data, a.sequences, a.bases)
             B = gpu.Index.upload(b.data, b.sequences, b.bases)
-            settings = [dict(), dict(l1_cap=5000), dict(search_algo=1), dict(search_algo=1, round_emits=20000),
+            settings = [dict(), dict(l1_cap=5000), dict(frontier_unfused=1), dict(search_algo=1), dict(search_algo=1, round_emits=20000),
                         dict(search_algo=1, round_emits=3000, walk_blocks=1), dict(search_algo=1, walk_variant=1),
                         dict(emit_path=1), dict(emit_path=1, walk_kernel=1), dict(search_algo=1, scatter_kernel=1),
                         dict(search_algo=1, l1_cap=256), dict(search_algo=1, l1_cap=1024, walk_variant=1)]
             for st in settings:
-                for k in ("round_emits", "walk_blocks", "walk_variant", "emit_path", "walk_kernel", "scatter_kernel", "l1_cap", "search_algo"):
+                for k in ("round_emits", "walk_blocks", "walk_variant", "emit_path", "walk_kernel", "scatter_kernel", "l1_cap", "search_algo", "frontier_unfused"):
                     gpu.tune(k, {"round_emits": 1 << 33}.get(k, 0))
                 for k, v in st.items():
                     gpu.tune(k, v)
@@ -312,7 +312,7 @@ def test_partitioned_emit_rounds_fallbacks_and_variants(gpu, oracle):
                 assert np.array_equal(ra.download(), ora), st
                 ra.free()
     finally:
-        for k in ("walk_blocks", "walk_variant", "emit_path", "walk_kernel", "scatter_kernel", "l1_cap", "search_algo"):
+        for k in ("walk_blocks", "walk_variant", "emit_path", "walk_kernel", "scatter_kernel", "l1_cap", "search_algo", "frontier_unfused"):
             gpu.tune(k, 0)
         gpu.tune("round_emits", 1 << 33)
 
