@@ -904,6 +904,9 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   }
   TRY(seg_prefix.alloc((nseg + 1) * sizeof(u64)));
   DevBuf first_seg; TRY(first_seg.alloc((nb_max + 1) * sizeof(u32)));
+  // The host looks at the frontier size every few steps: a dead step costs little for a small frontier, a
+  // synchronisation costs little next to a large one.
+  const u64 check_every = (count >= (1ull << 20) ? 8 : 32);
   const u64 scan_tiles = div_up(nseg + 1, (u64)SCAN_TILE);
   DevBuf scan_partial; TRY(scan_partial.alloc(scan_tiles * sizeof(u64)));
   // An epoch emits at most one value per position of b; a shard of the sequences usually far less.
@@ -940,7 +943,7 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
       LAUNCH("frontier_prep", k_frontier_prep, div_up(nseg, BLOCK_THREADS), BLOCK_THREADS, seg_prefix.as<const u64>(), nseg, first_seg.as<u32>(),
         emit_base.as<u64>(), in_epoch);
     }
-    if(t % 8 == 0)
+    if(t % check_every == 0)
     {
       u64 alive = 0;
       HIP_TRY(hipMemcpyAsync(&alive, seg_prefix.as<u64>() + nseg, sizeof(u64), hipMemcpyDeviceToHost, g_ctx.stream));
