@@ -54,7 +54,7 @@ struct Tuning
   long long walk_blocks = 0;     // grid size override for k_lf_walk (0 = default)
   long long walk_kernel = 0;     // 0 = four lanes per chain (product), 1 = one lane per chain (first version, kept for A/B)
   long long walk_ablate = 0;     // timing-only ablations of the no-emit quad kernel (tools/walk_experiments.py)
-  long long search_algo = 0;     // 0 = level-synchronous frontier search (product), 1 = per-chain walk with partitioned emit
+  long long search_algo = 0;     // 0 = by size (frontier search for large shards, per-chain walk for small ones), 1 = walk, 2 = frontier
   long long frontier_unfused = 0; // 1 = generic scan + k_frontier_prep per step (the path of segment tables with > 8192 tiles)
   long long l1_cap = 0;          // tests only: entries per level-1 region (0 = sized from the input)
   long long walk_variant = 0;    // 0 = four lanes per chain, four pipelined chains per quad (product); 1 = LDS-transposed one chain per lane
@@ -887,6 +887,8 @@ int frontier_flush(bwtm_ra* ra, DevBuf& emit16, u64 emit_cap, DevBuf& emit_base,
   return BWTM_OK;
 }
 
+constexpr u64 FRONTIER_MIN_SEQUENCES = 1ull << 21;
+
 int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64 count, bwtm_ra* ra)
 {
   if(a->n >= (1ull << 40) || b->n >= (1ull << 40) || count >= (1ull << 32)) { return search_partitioned(a, b, seq_first, count, ra); }
@@ -985,10 +987,16 @@ extern "C" int bwtm_search(const bwtm_index* a, const bwtm_index* b, uint64_t se
   if(b->m == 0 || seq_first > seq_last) { return BWTM_OK; }       // empty range (utils.h:80-83)
   if(seq_last >= b->m) { return fail(BWTM_EINVAL, "bwtm_search: sequence %llu out of range (%llu sequences)", (unsigned long long)seq_last, (unsigned long long)b->m); }
   u64 count = seq_last - seq_first + 1;
-  // The level-synchronous search costs a few launches per LF step, i.e. per symbol of the LONGEST sequence:
-  // it is the product path for read collections; collections of very long sequences take the per-chain walk.
+  // Two forms of the search.  The level-synchronous frontier search streams the rank structures once per LF step
+  // (43 G steps/s on large read sets) but costs two to three launches per step, i.e. per symbol of the LONGEST
+  // sequence; the per-chain walk does all steps in one launch at random-access speed (21-23 G steps/s).  Measured
+  // crossover on MI355X: ~2-3 million sequences per call, whatever their length (both sides scale with it), so
+  // small shards, small increments and collections of very long sequences take the walk.  search_algo: 0 = choose
+  // by size, 1 = walk, 2 = frontier.
   const u64 avg_len = b->n / (b->m > 0 ? b->m : 1);
-  if(g_tune.search_algo == 0 && g_tune.emit_path == 0 && g_tune.walk_kernel == 0 && avg_len <= 4096) { return search_frontier(a, b, seq_first, count, ra); }
+  const bool frontier_pays = (count >= FRONTIER_MIN_SEQUENCES && avg_len <= 4096);
+  const bool want_frontier = (g_tune.search_algo == 2 || (g_tune.search_algo == 0 && frontier_pays));
+  if(want_frontier && g_tune.emit_path == 0 && g_tune.walk_kernel == 0) { return search_frontier(a, b, seq_first, count, ra); }
   if(g_tune.emit_path == 0 && g_tune.walk_emit == 0 && g_tune.walk_kernel == 0) { return search_partitioned(a, b, seq_first, count, ra); }
   return search_atomic(a, b, seq_first, count, ra);
 }

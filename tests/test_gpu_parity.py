@@ -8,8 +8,13 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def gpu(bwtm):
+    """The library with the frontier search forced: at test sizes the dispatch would pick the per-chain walk
+    (bwtm_search chooses by shard size), and the frontier search is what large inputs run.  The walk and the
+    automatic choice are covered by test_partitioned_emit_rounds_fallbacks_and_variants."""
     bwtm.init(0)
-    return bwtm
+    bwtm.tune("search_algo", 2)
+    yield bwtm
+    bwtm.tune("search_algo", 0)
 
 
 def cum_counts(sym):
@@ -296,7 +301,7 @@ def test_partitioned_emit_rounds_fallbacks_and_variants(gpu, oracle):
             ora = oracle.ra_from_runs(ranks, counts)
             A = gpu.Index.upload(a.data, a.sequences, a.bases)
             B = gpu.Index.upload(b.data, b.sequences, b.bases)
-            settings = [dict(), dict(l1_cap=5000), dict(frontier_unfused=1), dict(search_algo=1), dict(search_algo=1, round_emits=20000),
+            settings = [dict(search_algo=2), dict(search_algo=2, l1_cap=5000), dict(search_algo=2, frontier_unfused=1), dict(search_algo=0), dict(search_algo=1), dict(search_algo=1, round_emits=20000),
                         dict(search_algo=1, round_emits=3000, walk_blocks=1), dict(search_algo=1, walk_variant=1),
                         dict(emit_path=1), dict(emit_path=1, walk_kernel=1), dict(search_algo=1, scatter_kernel=1),
                         dict(search_algo=1, l1_cap=256), dict(search_algo=1, l1_cap=1024, walk_variant=1)]
@@ -312,9 +317,10 @@ def test_partitioned_emit_rounds_fallbacks_and_variants(gpu, oracle):
                 assert np.array_equal(ra.download(), ora), st
                 ra.free()
     finally:
-        for k in ("walk_blocks", "walk_variant", "emit_path", "walk_kernel", "scatter_kernel", "l1_cap", "search_algo", "frontier_unfused"):
+        for k in ("walk_blocks", "walk_variant", "emit_path", "walk_kernel", "scatter_kernel", "l1_cap", "frontier_unfused"):
             gpu.tune(k, 0)
         gpu.tune("round_emits", 1 << 33)
+        gpu.tune("search_algo", 2)
 
 
 def test_find_batch_matches_oracle_backward_search(gpu, oracle):

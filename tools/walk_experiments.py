@@ -51,8 +51,8 @@ def run_product(label, algo=1):
 
 run_product("per-chain walk + partitioned emit", 1)
 if mode == "frontier":
-    run_product("frontier search (product)", 0)
-    pkg.tune("search_algo", 0)
+    run_product("frontier search (product)", 2)
+    pkg.tune("search_algo", 2)
     for mode_emit in (1,):
         pkg.tune("walk_emit", mode_emit)
         pkg.profile_reset()
@@ -61,7 +61,7 @@ if mode == "frontier":
         for k, (ms, n) in pkg.profile_read().items():
             if k.startswith("frontier_step"):
                 print("frontier timing-only variant       %-28s %9.2f ms per search" % (k, ms / 2), flush=True)
-    pkg.tune("walk_emit", 0)
+    pkg.tune("walk_emit", 0); pkg.tune("search_algo", 0)
     sys.exit(0)
 if mode == "ablate":
     pkg.tune("emit_path", 1); pkg.tune("walk_kernel", 0)
