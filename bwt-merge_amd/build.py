@@ -7,7 +7,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbwtm.so")
 SOURCES = ["bwtm_api.hip"]
-DEPS = ["bwtm_api.hip", "bwtm_kernels.hip.h", "bwtm_device.h", os.path.join("..", "..", "include", "bwtm.h")]
+KERNELS = ["common", "transcode", "queries", "search_walk", "search_frontier", "interleave", "encoder"]
+DEPS = (["bwtm_api.hip", "bwtm_kernels.hip.h", "bwtm_device.h", os.path.join("..", "..", "include", "bwtm.h")]
+        + [os.path.join("kernels", k + ".hip.h") for k in KERNELS])
 
 
 def hipcc():

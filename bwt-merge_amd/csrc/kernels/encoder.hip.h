@@ -1,0 +1,382 @@
+/*
+  kernels/encoder.hip.h -- canonical run encoder (RunBuffer + Run::write) with the block starts of BWT::build.
+  Part of bwtm_kernels.hip.h (included there, inside namespace bwtm); gfx950 only.
+*/
+#pragma once
+
+//------------------------------------------------------------------------------
+// K4: canonical run encoder (RunBuffer + Run::write; utils.h:121-142, support.h:256-282).
+//
+// A "head" is a position whose symbol differs from its predecessor (position 0 is a head; a
+// virtual head sits at position n).  Every head h > 0 is an EVENT: the maximal run
+// [previous head, h) with symbol sym(h - 1) ends there and is encoded.  Events are encoded in
+// order; a run shorter than 42 is always one byte, a longer run takes a number of bytes that
+// depends on the byte offset modulo 64 (support.h:267-279).
+//
+//   tile    = 64 positions (one lane)      chunk = 64 tiles (one wave step)
+//   segment = SEG_CHUNKS chunks, processed sequentially by one wave
+//
+//   k_enc_lasthead : last head of every segment (+1; 0 = none)  -> exclusive max-scan
+//   k_enc_size     : for every segment, bytes emitted as a function of the start offset
+//                    mod 64 (lane o evaluates hypothesis o)       -> folded by k_fold_*
+//   k_enc_emit     : writes the bytes of every segment at its now known offset
+
+constexpr int SEG_CHUNKS = 16;
+constexpr u64 SEG_TILES = (u64)SEG_CHUNKS * 64;
+constexpr u64 NONE = 0;   // "position + 1" encoding: 0 means no head
+
+struct TileInfo
+{
+  u64 p0, p1, p2;    // planes of the tile
+  u32 prev;          // symbol at tile_base - 1
+  u64 H;             // heads (including position 0 and the virtual head at n)
+  u64 E;             // events (H without position 0)
+};
+
+// Planes of tile T (64 positions) of the encoded index.
+__device__ inline void load_tile(const uint4* recs, u64 nrecs, u64 T, u64& p0, u64& p1, u64& p2)
+{
+  u64 ch = 2 * T;                                 // 16-byte chunk index: record T >> 1, chunks 2 (T & 1) and + 1
+  if(ch + 1 < 4 * nrecs)
+  {
+    uint4 a = recs[ch], b = recs[ch + 1];
+    p0 = (u64)a.x | ((u64)b.x << 32); p1 = (u64)a.y | ((u64)b.y << 32); p2 = (u64)a.z | ((u64)b.z << 32);
+  }
+  else { p0 = p1 = p2 = 0; }
+}
+
+__device__ inline u32 symbol_at(const uint4* recs, u64 pos)
+{
+  const u32* words = (const u32*)recs;
+  u64 wbase = (pos >> REC_SHIFT) * REC_WORDS + ((pos >> 5) & 3) * 4;
+  u32 t = (u32)(pos & 31);
+  return ((words[wbase] >> t) & 1u) | (((words[wbase + 1] >> t) & 1u) << 1) | (((words[wbase + 2] >> t) & 1u) << 2);
+}
+
+// Heads and events of one tile.  `prev` is the symbol at tile_base - 1 (ignored for tile 0).
+__device__ inline void tile_heads(TileInfo& ti, u64 tile_base, u64 n)
+{
+  u64 q0 = (ti.p0 << 1) | (ti.prev & 1u), q1 = (ti.p1 << 1) | ((ti.prev >> 1) & 1u), q2 = (ti.p2 << 1) | ((ti.prev >> 2) & 1u);
+  u64 D = (ti.p0 ^ q0) | (ti.p1 ^ q1) | (ti.p2 ^ q2);
+  if(tile_base == 0) { D |= 1; }
+  u64 valid = (n >= tile_base + 64 ? ~0ull : (n <= tile_base ? 0ull : ((1ull << (n - tile_base)) - 1)));
+  D &= valid;
+  if(n >= tile_base && n < tile_base + 64) { D |= 1ull << (n - tile_base); }
+  ti.H = D;
+  ti.E = (tile_base == 0 ? D & ~1ull : D);
+}
+
+// Symbol of the run that ends at in-tile bit t (the symbol at position tile_base + t - 1).
+__device__ inline u32 event_symbol(const TileInfo& ti, u32 t)
+{
+  if(t == 0) { return ti.prev; }
+  u32 s = t - 1;
+  return (u32)((ti.p0 >> s) & 1) | ((u32)((ti.p1 >> s) & 1) << 1) | ((u32)((ti.p2 >> s) & 1) << 2);
+}
+
+// Loads the tiles of one chunk (lane = tile) and computes heads; `carry_prev` is the symbol
+// before the chunk (wave-uniform).  Returns the symbol at the end of the chunk for the next one.
+__device__ inline u32 chunk_tiles(const uint4* recs, u64 nrecs, u64 first_tile, u64 n, u32 carry_prev, TileInfo& ti)
+{
+  u64 T = first_tile + lane_id();
+  load_tile(recs, nrecs, T, ti.p0, ti.p1, ti.p2);
+  u32 last = (u32)((ti.p0 >> 63) & 1) | ((u32)((ti.p1 >> 63) & 1) << 1) | ((u32)((ti.p2 >> 63) & 1) << 2);
+  u32 up = (u32)__shfl_up((int)last, 1, WAVE);
+  ti.prev = (lane_id() == 0 ? carry_prev : up);
+  tile_heads(ti, T << 6, n);
+  return (u32)__shfl((int)last, WAVE - 1, WAVE);
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_enc_lasthead(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 nseg, u64* lasthead)
+{
+  u64 seg = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
+  if(seg >= nseg) { return; }
+  u64 first = seg * SEG_TILES;
+  u32 carry = (first == 0 ? 0u : symbol_at(recs, (first << 6) - 1));
+  u64 best = NONE;
+  for(int k = 0; k < SEG_CHUNKS; k++)
+  {
+    u64 ft = first + (u64)k * 64;
+    if(ft >= ntiles) { break; }
+    TileInfo ti;
+    carry = chunk_tiles(recs, nrecs, ft, n, carry, ti);
+    u64 T = ft + lane_id();
+    u64 mine = (ti.H != 0 && T < ntiles ? (T << 6) + (63 - (u64)__builtin_clzll(ti.H)) + 1 : NONE);
+    u64 m = wave_max(mine);
+    if(m > best) { best = m; }
+  }
+  if(lane_id() == 0) { lasthead[seg] = best; }
+}
+
+// Per-lane event statistics of a tile: number of events and the LONG events among them (heads that end a
+// run of >= 42: no other head among the 41 positions before them; at most two per tile).  `before` =
+// (position of the last head before this tile) + 1.
+__device__ inline void tile_event_stats(const TileInfo& ti, u64 tile_base, u64 before, u32& nev, u64& long_mask)
+{
+  nev = (u32)__builtin_popcountll(ti.E); long_mask = 0;
+  const u64 H = ti.H;
+  if(H == 0) { return; }
+  // covered = OR of H << k for k = 1..41: positions that have a head among the 41 positions before them
+  u64 s = H << 1;
+  s |= s << 1; s |= s << 2; s |= s << 4;          // k = 1..8
+  const u64 s9 = s | (H << 9);                     // k = 1..9
+  s |= s << 8; s |= s << 16;                       // k = 1..32
+  const u64 covered = s | (s9 << 32);              // k = 1..41
+  const u64 later = H & (H - 1);                   // heads other than the first one of the tile
+  long_mask = later & ~covered;
+  const u64 pos = tile_base + (u32)__builtin_ctzll(H);   // first head: its run started before the tile
+  if(pos > 0 && pos + 1 - before >= MAX_RUN) { long_mask |= H & (0 - H); }
+}
+
+// The long events of a chunk in position order.  f(t, g, len): tile (lane) t, number of events of the
+// chunk before this one, run length; all arguments are wave-uniform.  Every lane first works out its own
+// (at most two) long events in parallel; the ordered walk then only broadcasts them.
+template<class F>
+__device__ inline void for_each_long_event(const TileInfo& ti, u64 first_tile, u64 before, u64 long_mask, u32 ev_excl, F&& f)
+{
+  u32 g0 = 0, g1 = 0; u64 len0 = 0, len1 = 0;
+  if(long_mask != 0)
+  {
+    const u64 tb = (first_tile + lane_id()) << 6;
+    u64 lm = long_mask;
+#pragma unroll
+    for(int k = 0; k < 2; k++)
+    {
+      if(lm != 0)
+      {
+        const u32 b = (u32)__builtin_ctzll(lm); lm &= lm - 1;
+        const u64 below = (1ull << b) - 1;
+        const u64 hb = ti.H & below;
+        const u64 prev1 = (hb != 0 ? tb + (63 - (u64)__builtin_clzll(hb)) + 1 : before);     // (previous head) + 1
+        const u32 g = ev_excl + (u32)__builtin_popcountll(ti.E & below);
+        const u64 len = tb + b + 1 - prev1;
+        if(k == 0) { g0 = g; len0 = len; } else { g1 = g; len1 = len; }
+      }
+    }
+  }
+  u64 pending = __ballot(long_mask != 0);
+  while(pending)
+  {
+    const int t = (int)__builtin_ctzll(pending); pending &= pending - 1;
+    f((u32)t, (u32)__shfl((int)g0, t, WAVE), shfl_u64(len0, t));
+    const u64 second = shfl_u64(len1, t);
+    if(second != 0) { f((u32)t, (u32)__shfl((int)g1, t, WAVE), second); }
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_enc_size(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 nseg,
+  const u64* prevhead, u32* table)
+{
+  u64 seg = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
+  if(seg >= nseg) { return; }
+  u64 first = seg * SEG_TILES;
+  u32 carry = (first == 0 ? 0u : symbol_at(recs, (first << 6) - 1));
+  u64 last = prevhead[seg];          // (last head before the segment) + 1, wave-uniform
+  u64 acc = 0;                       // bytes emitted so far under hypothesis "start offset = lane"
+  const u32 o = lane_id();
+  for(int k = 0; k < SEG_CHUNKS; k++)
+  {
+    u64 ft = first + (u64)k * 64;
+    if(ft >= ntiles) { break; }
+    TileInfo ti;
+    carry = chunk_tiles(recs, nrecs, ft, n, carry, ti);
+    u64 T = ft + lane_id();
+    if(T >= ntiles) { ti.H = 0; ti.E = 0; }
+    u64 lh = (ti.H != 0 ? (T << 6) + (63 - (u64)__builtin_clzll(ti.H)) + 1 : NONE);
+    u64 incl = wave_incl_max(lh);
+    u64 before = shfl_up_u64(incl, 1);
+    if(lane_id() == 0) { before = NONE; }
+    if(last > before) { before = last; }
+    u32 nev; u64 long_mask;
+    tile_event_stats(ti, T << 6, before, nev, long_mask);
+    const u64 ev_incl = wave_incl_sum(nev);
+    const u32 chunk_events = (u32)shfl_u64(ev_incl, WAVE - 1);
+    // Events shorter than 42 are one byte under every hypothesis; only the long ones are resolved in order.
+    u32 last_g = 0;
+    for_each_long_event(ti, ft, before, long_mask, (u32)(ev_incl - nev), [&](u32, u32 g, u64 len)
+    {
+      acc += g - last_g;
+      acc += long_run_bytes((u64)o + acc, len);
+      last_g = g + 1;
+    });
+    acc += chunk_events - last_g;
+    u64 m = shfl_u64(incl, WAVE - 1);
+    if(m > last) { last = m; }
+  }
+  table[seg * 64 + o] = (u32)acc;
+}
+
+// Fold 1: composition of the segment tables of one group (lane o = start offset hypothesis).
+constexpr int FOLD_GROUP = 256;
+
+__global__ void __launch_bounds__(WAVE) k_fold_group(const u32* table, u64 nseg, u64* group_table)
+{
+  u64 g = blockIdx.x;
+  u64 s0 = g * FOLD_GROUP, s1 = s0 + FOLD_GROUP; if(s1 > nseg) { s1 = nseg; }
+  u64 acc = 0; u32 o = lane_id();
+  for(u64 s = s0; s < s1; s++) { acc += table[s * 64 + ((o + acc) & 63)]; }
+  group_table[g * 64 + o] = acc;
+}
+
+// Fold 2: sequential pass over the groups from offset 0; group_base[ngroups] = total bytes.
+__global__ void __launch_bounds__(WAVE) k_fold_top(const u64* group_table, u64 ngroups, u64* group_base)
+{
+  if(threadIdx.x != 0) { return; }
+  u64 off = 0;
+  for(u64 g = 0; g < ngroups; g++) { group_base[g] = off; off += group_table[g * 64 + (off & 63)]; }
+  group_base[ngroups] = off;
+}
+
+// Fold 3: byte offset of every segment.
+__global__ void __launch_bounds__(WAVE) k_fold_seg(const u32* table, u64 nseg, const u64* group_base, u64* seg_base)
+{
+  if(threadIdx.x != 0) { return; }
+  u64 g = blockIdx.x;
+  u64 s0 = g * FOLD_GROUP, s1 = s0 + FOLD_GROUP; if(s1 > nseg) { s1 = nseg; }
+  u64 off = group_base[g];
+  for(u64 s = s0; s < s1; s++) { seg_base[s] = off; off += table[s * 64 + (off & 63)]; }
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 nseg,
+  const u64* prevhead, const u64* seg_base, u8* out, u64* block_start)
+{
+  __shared__ __attribute__((aligned(16))) u8 stage[BLOCK_THREADS / WAVE][4096 + 32];
+  u64 seg = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
+  if(seg >= nseg) { return; }
+  u64 first = seg * SEG_TILES;
+  u32 carry = (first == 0 ? 0u : symbol_at(recs, (first << 6) - 1));
+  u64 last = prevhead[seg];
+  u64 off = seg_base[seg];           // wave-uniform byte offset
+  for(int k = 0; k < SEG_CHUNKS; k++)
+  {
+    u64 ft = first + (u64)k * 64;
+    if(ft >= ntiles) { break; }
+    TileInfo ti;
+    carry = chunk_tiles(recs, nrecs, ft, n, carry, ti);
+    u64 T = ft + lane_id();
+    if(T >= ntiles) { ti.H = 0; ti.E = 0; }
+    u64 lh = (ti.H != 0 ? (T << 6) + (63 - (u64)__builtin_clzll(ti.H)) + 1 : NONE);
+    u64 incl = wave_incl_max(lh);
+    u64 before = shfl_up_u64(incl, 1);
+    if(lane_id() == 0) { before = NONE; }
+    if(last > before) { before = last; }
+    u32 nev; u64 long_mask;
+    tile_event_stats(ti, T << 6, before, nev, long_mask);
+    u64 ev_incl = wave_incl_sum(nev);
+    u64 chunk_events = shfl_u64(ev_incl, WAVE - 1);
+    bool slow = (__ballot(long_mask != 0) != 0);
+    if(!slow)
+    {
+      // Every event is a run shorter than 42: one byte each, in position order.  The bytes are
+      // staged in LDS at the same 16-byte phase as their destination and leave as 16-byte stores.
+      u8* lds = stage[threadIdx.x >> 6];
+      const u32 a = (u32)(off & 15);
+      u32 idx = a + (u32)(ev_incl - nev);
+      if(ti.H != 0)
+      {
+        // Events of the tile in position order.  The run that ends at head b has the symbol found at the
+        // previous head and the length b - (previous head); only the first head needs the 64-bit state
+        // carried in from the tiles before.  The tile is walked as two 32-bit halves.
+        const u64 tb = T << 6;
+        const u32 phase = (u32)((off - a) & (RLE_BLOCK - 1));            // byte (off - a + idx) opens a block iff ((phase + idx) & 63) == 0
+        const u32 b0 = (u32)__builtin_ctzll(ti.H);
+        u64 h = ti.H;
+        int prev_bit; u32 run_sym;
+        if(tb + b0 == 0) { h &= h - 1; prev_bit = 0; run_sym = (u32)(ti.p0 & 1) | ((u32)(ti.p1 & 1) << 1) | ((u32)(ti.p2 & 1) << 2); }   // position 0 is a head without an event
+        else { prev_bit = (int)b0 - (int)(u32)(tb + b0 + 1 - before); run_sym = event_symbol(ti, b0); }
+#pragma unroll
+        for(int half = 0; half < 2; half++)
+        {
+          u32 hh = (u32)(h >> (32 * half));
+          const u32 q0 = (u32)(ti.p0 >> (32 * half)), q1 = (u32)(ti.p1 >> (32 * half)), q2 = (u32)(ti.p2 >> (32 * half));
+          while(hh)
+          {
+            const u32 bb = (u32)__builtin_ctz(hh); hh &= hh - 1;
+            const int bit = (int)bb + 32 * half;
+            const u32 len = (u32)(bit - prev_bit);
+            if(((phase + idx) & (u32)(RLE_BLOCK - 1)) == 0) { block_start[(off - a + idx) >> 6] = tb + (u64)(long long)prev_bit; }   // this run opens a block
+            lds[idx++] = (u8)(run_sym + 6 * (len - 1));                  // Run::encodeBasic, support.h:231-234
+            run_sym = ((q0 >> bb) & 1u) | (((q1 >> bb) & 1u) << 1) | (((q2 >> bb) & 1u) << 2);
+            prev_bit = bit;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      const u32 total = a + (u32)chunk_events;
+      u8* base = out + (off - a);                                      // 16-byte aligned
+      for(u32 j = lane_id(); j * 16 < total; j += WAVE)
+      {
+        u32 lo = 16 * j, hi = lo + 16;
+        if(lo >= a && hi <= total) { *(uint4*)(base + lo) = *(const uint4*)(lds + lo); }
+        else
+        {
+          u32 from = (lo > a ? lo : a), to = (hi < total ? hi : total);
+          for(u32 t = from; t < to; t++) { base[t] = lds[t]; }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      off += chunk_events;
+    }
+    else
+    {
+      // Some runs of >= 42 end in this chunk.  Their sizes depend on their byte offsets, so they are resolved
+      // in order (a handful per chunk); every other event is one byte at (its event index + the extra bytes
+      // of the long events before it), and all lanes write their tiles in parallel as above.
+      u8* lds = stage[threadIdx.x >> 6];
+      const u32 a = (u32)(off & 15);
+      const u64 origin = off - a;                                      // stream offset of lds[0]
+      const u32 ev_excl = (u32)(ev_incl - nev);
+      u32 extra = 0, shift = 0;                                      // extra bytes of all long events / of those in earlier tiles
+      for_each_long_event(ti, ft, before, long_mask, ev_excl, [&](u32 t, u32 g, u64 len)
+      {
+        const u32 sz = (u32)long_run_bytes(off + g + extra, len);
+        if(lane_id() > t) { shift += sz - 1; }
+        extra += sz - 1;
+      });
+      if(ti.H != 0)
+      {
+        const u64 tb = T << 6;
+        u32 idx = a + ev_excl + shift;
+        u64 h = ti.H;
+        const u32 b0 = (u32)__builtin_ctzll(h);
+        u64 prev1;                                                     // (previous head) + 1
+        u32 run_sym;
+        if(tb + b0 == 0) { h &= h - 1; prev1 = 1; run_sym = (u32)(ti.p0 & 1) | ((u32)(ti.p1 & 1) << 1) | ((u32)(ti.p2 & 1) << 2); }
+        else { prev1 = before; run_sym = event_symbol(ti, b0); }
+        while(h)
+        {
+          const u32 b = (u32)__builtin_ctzll(h); h &= h - 1;
+          const u64 pos = tb + b, len = pos + 1 - prev1;
+          if((long_mask >> b) & 1)
+          {
+            idx += (u32)long_run_write(lds, origin + idx, run_sym, len, block_start, prev1 - 1, origin);
+          }
+          else
+          {
+            if(((origin + idx) & (RLE_BLOCK - 1)) == 0) { block_start[(origin + idx) >> 6] = prev1 - 1; }
+            lds[idx++] = (u8)(run_sym + 6 * (len - 1));
+          }
+          run_sym = (u32)((ti.p0 >> b) & 1) | ((u32)((ti.p1 >> b) & 1) << 1) | ((u32)((ti.p2 >> b) & 1) << 2);
+          prev1 = pos + 1;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      const u32 total = a + (u32)chunk_events + extra;
+      u8* base = out + origin;                                         // 16-byte aligned
+      for(u32 j = lane_id(); j * 16 < total; j += WAVE)
+      {
+        u32 lo = 16 * j, hi = lo + 16;
+        if(lo >= a && hi <= total) { *(uint4*)(base + lo) = *(const uint4*)(lds + lo); }
+        else
+        {
+          u32 from = (lo > a ? lo : a), to = (hi < total ? hi : total);
+          for(u32 t = from; t < to; t++) { base[t] = lds[t]; }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      off += chunk_events + extra;
+    }
+    u64 m = shfl_u64(incl, WAVE - 1);
+    if(m > last) { last = m; }
+  }
+}

@@ -1,0 +1,105 @@
+/*
+  kernels/interleave.hip.h -- rank-array finalize and mergeBWT.
+  Part of bwtm_kernels.hip.h (included there, inside namespace bwtm); gfx950 only.
+*/
+#pragma once
+
+//------------------------------------------------------------------------------
+// K2: rank-array finalize.  A chunk is 64 output records = 8192 bits = 128 words; one wave
+// per chunk counts the set bits.  (An exclusive scan of the counts follows.)
+
+constexpr int CHUNK_WORDS = 128;
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_chunk_popc(const u64* bits, u64 nchunks, u64* cnt)
+{
+  u64 chunk = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
+  if(chunk >= nchunks) { return; }
+  const u64* w = bits + chunk * CHUNK_WORDS + 2 * lane_id();
+  u64 v = (u64)__builtin_popcountll(w[0]) + (u64)__builtin_popcountll(w[1]);
+  v = wave_sum(v);
+  if(lane_id() == 0) { cnt[chunk] = v; }
+}
+
+// RA[i] for every B position (tests / facade): one wave per chunk, one lane per record.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_ra_extract(const u64* bits, const u64* chunk_base, u64 nchunks, u64 nb, u64* ra)
+{
+  u64 chunk = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
+  if(chunk >= nchunks) { return; }
+  u64 q = chunk * 64 + lane_id();
+  u64 m0 = bits[2 * q], m1 = bits[2 * q + 1];
+  u64 mine = (u64)__builtin_popcountll(m0) + (u64)__builtin_popcountll(m1);
+  u64 incl = wave_incl_sum(mine);
+  u64 i = chunk_base[chunk] + incl - mine;
+  u64 base = q << REC_SHIFT;
+  while(m0) { u32 t = (u32)__builtin_ctzll(m0); m0 &= m0 - 1; if(i < nb) { ra[i] = base + t - i; } i++; }
+  while(m1) { u32 t = (u32)__builtin_ctzll(m1); m1 &= m1 - 1; if(i < nb) { ra[i] = base + 64 + t - i; } i++; }
+}
+
+//------------------------------------------------------------------------------
+// K3: interleave (mergeBWT, bwt.cpp:215-282).  Output position p takes the next symbol of B
+// when bit p of the interleaving bitvector is set and the next symbol of A otherwise, so
+// an output record needs b_off = rank1(bits, 128 q) and a_off = 128 q - b_off, and its
+// header is rank_A(a_off) + rank_B(b_off).  One lane per output record.
+
+// Number of set bits before output record q, given the chunk bases.
+__device__ inline u64 bits_before_record(const u64* bits, const u64* chunk_base, u64 q)
+{
+  u64 chunk = q >> 6;
+  u64 b = chunk_base[chunk];
+  for(u64 w = chunk * CHUNK_WORDS; w < 2 * q; w++) { b += (u64)__builtin_popcountll(bits[w]); }
+  return b;
+}
+
+// Super table of the output: absolute counts at the start of every super.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_interleave_sup(IndexView A, IndexView B, const u64* bits, const u64* chunk_base,
+  u64 n_out, u64* sup, u64 nsup)
+{
+  u64 s = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(s >= nsup) { return; }
+  u64 q = s << SUPER_REC_SHIFT;
+  u64 b_off = bits_before_record(bits, chunk_base, q);
+  u64 a_off = (q << REC_SHIFT) - b_off;
+  if(a_off > A.n) { a_off = A.n; }
+  if(b_off > B.n) { b_off = B.n; }
+  u64 ra[6], rb[6];
+  index_ranks(A, a_off, ra); index_ranks(B, b_off, rb);
+  for(int c = 0; c < SUP_STRIDE; c++) { sup[s * SUP_STRIDE + c] = (c >= 1 && c < 6 ? ra[c] + rb[c] : 0); }
+  (void)n_out;
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_interleave(IndexView A, IndexView B, const u64* bits, const u64* chunk_base,
+  u64 nchunks, const u64* sup_out, uint4* recs_out, u64 nrecs_out)
+{
+  u64 chunk = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
+  if(chunk >= nchunks) { return; }
+  u64 q = chunk * 64 + lane_id();
+  u64 m0 = bits[2 * q], m1 = bits[2 * q + 1];
+  u64 mine = (u64)__builtin_popcountll(m0) + (u64)__builtin_popcountll(m1);
+  u64 incl = wave_incl_sum(mine);
+  if(q >= nrecs_out) { return; }
+  u64 b_off = chunk_base[chunk] + incl - mine;
+  u64 a_off = (q << REC_SHIFT) - b_off;
+
+  // Header: counts of symbols 1..5 before output position 128 q.
+  u64 ra[6], rb[6];
+  index_ranks(A, (a_off > A.n ? A.n : a_off), ra);
+  index_ranks(B, (b_off > B.n ? B.n : b_off), rb);
+  const u64* s = sup_out + (q >> SUPER_REC_SHIFT) * SUP_STRIDE;
+  u32 rel[6]; u32 h[4];
+  for(int c = 1; c < 6; c++) { rel[c] = (u32)(ra[c] + rb[c] - s[c]); }
+  pack_header(rel, h);
+
+  // Planes: two halves of 64 positions.
+  u64 a0, a1, a2, b0, b1, b2, lo0, lo1, lo2, hi0, hi1, hi2;
+  load_window(A, a_off, a0, a1, a2); load_window(B, b_off, b0, b1, b2);
+  deposit64(m0, a0, a1, a2, b0, b1, b2, lo0, lo1, lo2);
+  u64 nb0 = (u64)__builtin_popcountll(m0);
+  load_window(A, a_off + 64 - nb0, a0, a1, a2); load_window(B, b_off + nb0, b0, b1, b2);
+  deposit64(m1, a0, a1, a2, b0, b1, b2, hi0, hi1, hi2);
+
+  uint4* dst = recs_out + 4 * q;
+  dst[0] = make_uint4((u32)lo0, (u32)lo1, (u32)lo2, h[0]);
+  dst[1] = make_uint4((u32)(lo0 >> 32), (u32)(lo1 >> 32), (u32)(lo2 >> 32), h[1]);
+  dst[2] = make_uint4((u32)hi0, (u32)hi1, (u32)hi2, h[2]);
+  dst[3] = make_uint4((u32)(hi0 >> 32), (u32)(hi1 >> 32), (u32)(hi2 >> 32), h[3]);
+}

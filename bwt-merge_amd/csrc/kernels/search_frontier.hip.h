@@ -1,0 +1,388 @@
+/*
+  kernels/search_frontier.hip.h -- the search in level-synchronous form (product path for read collections).
+  Part of bwtm_kernels.hip.h (included there, inside namespace bwtm); gfx950 only.
+*/
+#pragma once
+
+//------------------------------------------------------------------------------
+// K1, level-synchronous form ("frontier search").
+//
+// All chains advance together, one LF step per launch, and the frontier F_t (the chains that are
+// t steps from the end of their sequence) is kept SORTED BY SUFFIX.  Then both coordinates are
+// monotone along the frontier -- i (rank among B's suffixes) strictly increasing, r (rank among
+// A's suffixes) non-decreasing -- so the records of both indexes are read as ascending runs of cache lines
+// instead of random gathers, and the emitted bit positions i + r are increasing as well.
+// One LF step keeps the order inside a symbol class (LF is monotone for a fixed symbol) and the
+// classes occupy disjoint, increasing ranges [C[c], C[c+1]), so F_{t+1} = stable 5-way split of
+// F_t by c = BWT_B[i]: the "radix sort + segmented scan" of the north star, one digit per step.
+//
+// No data is moved for the split: a block of FR_BLOCK elements writes its survivors grouped by
+// class into its own slot of the next buffer and records (length, physical start) per (class,
+// block) SEGMENT; the logical order of F_{t+1} is (class, block), and an exclusive scan of the
+// segment lengths (logical order) lets the next step map logical indexes to physical ones.
+// The reference explores the same trie level by level implicitly (fmi.cpp:286-323: ranges of B
+// with equal suffixes); here every sequence keeps its own element, which yields the same multiset
+// of ranks.
+
+constexpr int FR_BLOCK = 256;                  // elements (= threads) per block
+constexpr int FR_SEGS = 31;                    // segment-table entries staged per block
+
+struct FrontierView
+{
+  // Coordinates are 40-bit: the low words of (i, r) share one 8-byte entry, the high bytes one
+  // 2-byte entry (10 bytes per element in two arrays).
+  const uint2* lo; const unsigned short* hi;                             // current frontier (physical layout)
+  uint2* lo_next; unsigned short* hi_next;                               // next frontier
+  const u64* seg_prefix;                       // exclusive scan of seg_len (5 * nb_max + 1 entries); last = N_t
+  const u64* seg_phys;                         // physical start of every segment
+  const u32* first_seg;                        // per block: the segment that holds its first element (k_frontier_prep)
+  u64* seg_len_next; u64* seg_phys_next;       // produced for the next step
+  u64 nb_max;                                  // blocks per class in the segment tables
+  // Dense emit of this step (EMIT == 0): the frontier is sorted, so are its bit positions p = i + r.
+  unsigned short* emit16;                      // in-tile offsets p & 0xFFFF at emit_base[step] + logical index
+  const u64* emit_base;                        // [steps + 1] running number of emits
+  u64 emit_cap;                                // capacity of emit16; emits beyond it fall back to atomicOr
+  u32* bits32;                                 // the bitvector (fallback path only)
+  u32* bound_row;                              // this step's row of tile boundaries: [ntiles + 1], pre-set to ~0
+  u64 step;
+};
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_init(uint2* lo, unsigned short* hi, u64* seg_len, u64* seg_phys, u64 nb_max,
+  u64 seq_first, u64 count, u64 m_a)
+{
+  u64 g = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(g < count)
+  {
+    u64 i = seq_first + g;                                                // fmi.cpp:286: trie root "$"
+    lo[g] = make_uint2((u32)i, (u32)m_a); hi[g] = (unsigned short)(((i >> 32) & 0xFF) | (((m_a >> 32) & 0xFF) << 8));
+  }
+  if(g < 5 * nb_max)
+  {
+    u64 cls = g / nb_max, b = g % nb_max;
+    u64 begin = b * FR_BLOCK;
+    seg_len[g] = (cls == 0 && begin < count ? (count - begin < (u64)FR_BLOCK ? count - begin : (u64)FR_BLOCK) : 0);
+    seg_phys[g] = begin;
+  }
+  if(g == 5 * nb_max) { seg_len[g] = 0; }
+}
+
+// The records of the wave's elements are loaded per lane (four 16-byte loads of the lane's own
+// record, all issued before the first use).  Along the sorted frontier consecutive lanes hit the
+// same or neighbouring records, so the loads of a wave touch a short ascending run of cache lines;
+// records without an element in this step (about a quarter of them at 100 bp) are never fetched.
+// (Measured against fetching the whole spanned window with coalesced loads through LDS: 115 -> 105 ms
+// per search at config 2.)
+struct RecordFetch { uint4 v[4]; };
+
+__device__ inline RecordFetch record_issue(const uint4* recs, u64 nrecs, u64 rec)
+{
+  RecordFetch rf;
+  const uint4* p = recs + 4 * (rec < nrecs ? rec : nrecs - 1);
+  rf.v[0] = p[0]; rf.v[1] = p[1]; rf.v[2] = p[2]; rf.v[3] = p[3];
+  return rf;
+}
+
+__device__ inline void record_words(const RecordFetch& rf, u32 w[16])
+{
+#pragma unroll
+  for(int k = 0; k < 4; k++) { w[4 * k] = rf.v[k].x; w[4 * k + 1] = rf.v[k].y; w[4 * k + 2] = rf.v[k].z; w[4 * k + 3] = rf.v[k].w; }
+}
+
+template<int EMIT>
+__global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, IndexView B, FrontierView f)
+{
+  __shared__ u32 wave_cnt[FR_BLOCK / WAVE][6];
+  __shared__ u64 s_prefix[FR_SEGS + 1], s_phys[FR_SEGS + 1];
+  const u64 nseg = 5 * f.nb_max;
+  const u64 N = f.seg_prefix[nseg];
+  const u64 g0 = (u64)blockIdx.x * FR_BLOCK;
+  const u32 lane = lane_id(), wave = threadIdx.x >> 6;
+
+  // Blocks past the frontier only publish empty segments.
+  if(g0 >= N)
+  {
+    if(threadIdx.x < 5) { f.seg_len_next[(u64)threadIdx.x * f.nb_max + blockIdx.x] = 0; f.seg_phys_next[(u64)threadIdx.x * f.nb_max + blockIdx.x] = g0; }
+    if(blockIdx.x == 0 && threadIdx.x == 5) { f.seg_len_next[nseg] = 0; }
+    return;
+  }
+  // The block's elements live in a handful of segments: stage their table entries in LDS.
+  const u64 first_seg = f.first_seg[blockIdx.x];
+  if(threadIdx.x <= FR_SEGS)
+  {
+    u64 sidx = first_seg + threadIdx.x; if(sidx > nseg) { sidx = nseg; }
+    s_prefix[threadIdx.x] = f.seg_prefix[sidx];
+    s_phys[threadIdx.x] = f.seg_phys[sidx < nseg ? sidx : nseg - 1];
+  }
+  __syncthreads();
+
+  const u64 g = g0 + threadIdx.x;
+  const bool active = (g < N);
+  u64 i = 0, r = 0;
+  if(active)
+  {
+    u64 phys;
+    u32 k = 0;
+    while(k < (u32)FR_SEGS && s_prefix[k + 1] <= g) { k++; }       // skips empty segments
+    if(k < (u32)FR_SEGS) { phys = s_phys[k] + (g - s_prefix[k]); }
+    else
+    {
+      u64 sgm = first_seg + FR_SEGS;                                 // rare: more segments than staged
+      while(f.seg_prefix[sgm + 1] <= g) { sgm++; }
+      phys = f.seg_phys[sgm] + (g - f.seg_prefix[sgm]);
+    }
+    uint2 l = f.lo[phys]; u32 h = f.hi[phys];
+    i = (u64)l.x | ((u64)(h & 0xFF) << 32);
+    r = (u64)l.y | ((u64)(h >> 8) << 32);
+  }
+  const u64 any_active = __ballot(active);
+  u32 c = 0;
+  u64 ni = 0, nr = 0;
+  if(any_active != 0)
+  {
+    // idle lanes (a suffix of the wave) borrow the last active lane's coordinates
+    const u32 last_lane = 63 - (u32)__builtin_clzll(any_active);
+    const u64 li = shfl_u64(i, (int)last_lane), lr = shfl_u64(r, (int)last_lane);
+    if(EMIT == 0)
+    {
+      // Dense emit + tile markers: bound_row[tile] = min(logical index of an element in the tile).
+      // A lane marks when the previous lane lies in another tile; lane 0 of every wave always marks
+      // (the true first element of the tile marks too and wins the minimum).  Tiles without
+      // elements are filled in by k_bound_suffix_min.
+      const u64 p = i + r;
+      const u64 my_tile = p >> TILE_SHIFT;
+      const u64 prev_tile = shfl_up_u64(my_tile, 1);
+      if(active)
+      {
+        u64 slot = f.emit_base[f.step] + g;
+        if(slot < f.emit_cap) { f.emit16[slot] = (unsigned short)(p & TILE_MASK); }
+        else { sink_fallback(f.bits32, p); }                      // exact fallback; k_tile_build_frontier skips these slots
+        if(lane == 0 || my_tile != prev_tile) { atomicMin(&f.bound_row[my_tile], (u32)g); }
+      }
+    }
+    u32 wb[16];
+    const u64 rec_b = (active ? i : li) >> REC_SHIFT, rec_a = (active ? r : lr) >> REC_SHIFT;
+    RecordFetch fb = record_issue(B.recs, B.nrecs, rec_b);
+    RecordFetch fa = record_issue(A.recs, A.nrecs, rec_a);         // in flight while B's record is used
+    const u64 sup_b0 = shfl_u64(i, 0) >> SUPER_SHIFT, sup_a0 = shfl_u64(r, 0) >> SUPER_SHIFT;   // lane 0 is always active here
+    const u64* row_b = B.sup + sup_b0 * SUP_STRIDE;                // wave-uniform addresses
+    const u64* row_a = A.sup + sup_a0 * SUP_STRIDE;
+    record_words(fb, wb);
+    if(active) { c = rec_symbol(wb, (u32)(i & (REC_POS - 1))); }   // BWT_B[i]; 0 ends the chain (fmi.cpp:299)
+    u64 supb = 0, supa = 0;
+    if(active && c != 0)
+    {
+      // Super-table rows: the wave's coordinates are sorted, so nearly every lane needs the row of lane 0,
+      // which was requested with scalar loads (row_b / row_a) together with the records.
+      if((i >> SUPER_SHIFT) == sup_b0) { supb = (c == 1 ? row_b[1] : (c == 2 ? row_b[2] : (c == 3 ? row_b[3] : (c == 4 ? row_b[4] : row_b[5])))); }
+      else { supb = B.sup[(i >> SUPER_SHIFT) * SUP_STRIDE + c]; }
+      if((r >> SUPER_SHIFT) == sup_a0) { supa = (c == 1 ? row_a[1] : (c == 2 ? row_a[2] : (c == 3 ? row_a[3] : (c == 4 ? row_a[4] : row_a[5])))); }
+      else { supa = A.sup[(r >> SUPER_SHIFT) * SUP_STRIDE + c]; }
+      ni = rec_header(wb, c) + rec_count(wb, c, (u32)(i & (REC_POS - 1)));
+    }
+    u32 wa[16];
+    record_words(fa, wa);
+    if(active)
+    {
+      const u32 ja = (u32)(r & (REC_POS - 1));
+      if(c != 0)
+      {
+        ni += supb;
+        nr = supa + rec_header(wa, c) + rec_count(wa, c, ja);
+        // C[c]: kernel arguments cannot be indexed dynamically without scratch, hence the selects
+        u64 cb = (c == 1 ? B.C[1] : (c == 2 ? B.C[2] : (c == 3 ? B.C[3] : (c == 4 ? B.C[4] : B.C[5]))));
+        u64 ca = (c == 1 ? A.C[1] : (c == 2 ? A.C[2] : (c == 3 ? A.C[3] : (c == 4 ? A.C[4] : A.C[5]))));
+        ni += cb; nr += ca;                                     // LF_B(i), LF_A(r, c): utils.h:335-348
+      }
+    }
+  }
+  // Stable split by class inside the block.
+  u32 my_rank = 0;
+  u32 cnt_w[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for(u32 k = 1; k < 6; k++)
+  {
+    u64 m = __ballot(active && c == k);
+    cnt_w[k] = (u32)__builtin_popcountll(m);
+    if(c == k) { my_rank = (u32)__builtin_popcountll(m & ((1ull << lane) - 1)); }
+  }
+  if(lane == 0) { for(u32 k = 1; k < 6; k++) { wave_cnt[wave][k] = cnt_w[k]; } }
+  // Raw barrier with an LDS-only wait: __syncthreads() would also drain vmcnt and expose the latency
+  // of the emit reservation / stores that are still in flight (measured: +35 ms per search).
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  u32 class_base = 0, before_waves = 0;
+#pragma unroll
+  for(u32 k = 1; k < 6; k++)
+  {
+    u32 tot = 0, bw = 0;
+    for(u32 w2 = 0; w2 < FR_BLOCK / WAVE; w2++) { u32 v = wave_cnt[w2][k]; if(w2 < wave) { bw += v; } tot += v; }
+    if(k < c) { class_base += tot; }
+    if(k == c) { before_waves = bw; }
+    if(threadIdx.x == k - 1)
+    {
+      u32 base_k = 0;
+      for(u32 k2 = 1; k2 < k; k2++) { for(u32 w2 = 0; w2 < FR_BLOCK / WAVE; w2++) { base_k += wave_cnt[w2][k2]; } }
+      f.seg_len_next[(u64)(k - 1) * f.nb_max + blockIdx.x] = tot;
+      f.seg_phys_next[(u64)(k - 1) * f.nb_max + blockIdx.x] = g0 + base_k;
+    }
+  }
+  if(blockIdx.x == 0 && threadIdx.x == 5) { f.seg_len_next[nseg] = 0; }
+  if(active && c != 0)
+  {
+    u64 dst = g0 + class_base + before_waves + my_rank;
+    f.lo_next[dst] = make_uint2((u32)ni, (u32)nr);
+    f.hi_next[dst] = (unsigned short)(((ni >> 32) & 0xFF) | (((nr >> 32) & 0xFF) << 8));
+  }
+}
+
+// Per-step bookkeeping.  first_seg[b] = the segment that holds logical element b * FR_BLOCK: a segment
+// has at most FR_BLOCK elements, so it covers at most one block boundary and every non-empty segment
+// can publish "its" block directly (replaces a search of seg_prefix by every block of the step kernel).
+// Dense emit: emit_base[t + 1] = emit_base[t] + N_t.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_prep(const u64* seg_prefix, u64 nseg, u32* first_seg, u64* emit_base, u64 step)
+{
+  u64 sgm = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(sgm == 0) { emit_base[step + 1] = emit_base[step] + seg_prefix[nseg]; }
+  if(sgm >= nseg) { return; }
+  u64 begin = seg_prefix[sgm], end = seg_prefix[sgm + 1];
+  u64 b = (begin + FR_BLOCK - 1) / FR_BLOCK;
+  if(b * FR_BLOCK < end) { first_seg[b] = (u32)sgm; }
+}
+
+// The same bookkeeping fused into the scan of the segment lengths (the path used when the segment table has at
+// most FRONTIER_SCAN_TILES tiles): after k_scan_reduce has produced one total per 2048-entry tile, every block
+// sums the totals before its tile itself, scans its tile, and publishes seg_prefix, first_seg and emit_base --
+// two launches per step instead of four.
+constexpr u64 FRONTIER_SCAN_TILES = 8192;
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_scan(const u64* seg_len, const u64* partial, u64 nseg, u64* seg_prefix, u32* first_seg,
+  u64* emit_base, u64 step)
+{
+  __shared__ u64 lds[BLOCK_THREADS / WAVE];
+  const u64 n = nseg + 1;                                            // the entry after the last segment holds 0 and receives N_t
+  u64 c = 0;
+  for(u64 k = threadIdx.x; k < blockIdx.x; k += BLOCK_THREADS) { c += partial[k]; }
+  const u64 carry = block_reduce<0>(c, lds);
+  const u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+  u64 item[SCAN_ITEMS];
+  u64 acc = 0;
+  for(int k = 0; k < SCAN_ITEMS; k++) { item[k] = (base + k < n ? seg_len[base + k] : 0); acc += item[k]; }
+  const u64 incl = wave_incl_sum(acc);
+  const u64 wave_total = shfl_u64(incl, WAVE - 1);
+  u64 excl = shfl_up_u64(incl, 1);
+  if(lane_id() == 0) { excl = 0; }
+  if(lane_id() == 0) { lds[threadIdx.x >> 6] = wave_total; }
+  __syncthreads();
+  u64 run = carry + excl;
+  for(int k = 0; k < (int)(threadIdx.x >> 6); k++) { run += lds[k]; }
+  for(int k = 0; k < SCAN_ITEMS; k++)
+  {
+    const u64 idx = base + k;
+    if(idx < n)
+    {
+      seg_prefix[idx] = run;
+      if(idx < nseg)
+      {
+        const u64 b = (run + FR_BLOCK - 1) / FR_BLOCK;
+        if(b * FR_BLOCK < run + item[k]) { first_seg[b] = (u32)idx; }
+      }
+      else { emit_base[step + 1] = emit_base[step] + run; }
+    }
+    run += item[k];
+  }
+}
+
+// Row t of the boundary table: bound[T] = logical index of the first element of step t whose bit
+// position lies in tile >= T (suffix minimum over the markers; N_t past the last element).
+__global__ void __launch_bounds__(BLOCK_THREADS) k_bound_suffix_min(u32* bound, u64 ntiles, const u64* emit_base, u64 nsteps)
+{
+  __shared__ u32 lds[BLOCK_THREADS];
+  u64 t = blockIdx.x;
+  if(t >= nsteps) { return; }
+  u32* row = bound + t * (ntiles + 1);
+  u32 running = (u32)(emit_base[t + 1] - emit_base[t]);        // N_t
+  if(threadIdx.x == 0) { row[ntiles] = running; }
+  for(u64 hi = ntiles; hi > 0; )
+  {
+    u64 lo = (hi > (u64)BLOCK_THREADS ? hi - BLOCK_THREADS : 0);
+    u64 idx = lo + threadIdx.x;
+    u32 v = (idx < hi ? row[idx] : 0xFFFFFFFFu);
+    lds[threadIdx.x] = v;
+    __syncthreads();
+    // inclusive suffix min inside the chunk (Hillis-Steele over 256 entries)
+    for(int d = 1; d < BLOCK_THREADS; d <<= 1)
+    {
+      u32 o = ((int)threadIdx.x + d < BLOCK_THREADS ? lds[threadIdx.x + d] : 0xFFFFFFFFu);
+      __syncthreads();
+      if(o < lds[threadIdx.x]) { lds[threadIdx.x] = o; }
+      __syncthreads();
+    }
+    u32 m = lds[threadIdx.x]; if(running < m) { m = running; }
+    if(idx < hi) { row[idx] = m; }
+    u32 chunk_min = lds[0];
+    __syncthreads();
+    if(chunk_min < running) { running = chunk_min; }
+    hi = lo;
+  }
+}
+
+// Tiles from the dense per-step emits: tile T receives, from every step t, the contiguous run
+// [bound[t][T], bound[t][T + 1]) of 16-bit offsets.  One workgroup per tile.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_tile_build_frontier(const unsigned short* emit16, const u64* emit_base, u64 emit_cap, const u32* bound,
+  u64 ntiles, u64 nsteps, u64* bits, u64 nwords)
+{
+  __shared__ u32 tile[1 << (TILE_SHIFT - 5)];
+  __shared__ u32 any;
+  u64 T = blockIdx.x;
+  if(T >= ntiles) { return; }
+  for(u32 k = threadIdx.x; k < (1u << (TILE_SHIFT - 5)); k += BLOCK_THREADS) { tile[k] = 0; }
+  if(threadIdx.x == 0) { any = 0; }
+  __syncthreads();
+  // Wave w takes the steps w, w + 4, ...  The run bounds of 64 of its steps are fetched at once (lane j
+  // holds step w + 4 j) and handed out by shuffles, so that only the loads of the runs themselves are
+  // dependent; four of those are in flight per lane.
+  constexpr u32 NW = BLOCK_THREADS / WAVE;
+  const u32 lane = lane_id(), wv = threadIdx.x >> 6;
+  bool seen = false;
+  for(u64 t0 = wv; t0 < nsteps; t0 += (u64)NW * WAVE)
+  {
+    const u64 tj = t0 + (u64)NW * lane;
+    u32 my_lo = 0, my_hi = 0; u64 my_base = 0;
+    if(tj < nsteps)
+    {
+      const u32* row = bound + tj * (ntiles + 1);
+      my_lo = row[T]; my_hi = row[T + 1]; my_base = emit_base[tj];
+    }
+    const u64 left = (nsteps - t0 + NW - 1) / NW;                  // steps of this wave from t0 on
+    const u32 cnt = (left < (u64)WAVE ? (u32)left : (u32)WAVE);
+    for(u32 j = 0; j < cnt; j++)
+    {
+      const u32 lo = (u32)__shfl((int)my_lo, (int)j, WAVE), hi = (u32)__shfl((int)my_hi, (int)j, WAVE);
+      const u64 base = shfl_u64(my_base, (int)j);
+      seen |= (hi > lo);
+      for(u32 k = lo + lane; k < hi; k += 4 * WAVE)
+      {
+        u32 off[4];
+#pragma unroll
+        for(u32 u = 0; u < 4; u++)
+        {
+          const u32 kk = k + u * WAVE;
+          off[u] = (kk < hi && base + kk < emit_cap ? (u32)emit16[base + kk] : 0xFFFFFFFFu);
+        }
+#pragma unroll
+        for(u32 u = 0; u < 4; u++) { if(off[u] != 0xFFFFFFFFu) { atomicOr(&tile[off[u] >> 5], 1u << (off[u] & 31)); } }
+      }
+    }
+  }
+  if(seen && lane == 0) { any = 1; }
+  __syncthreads();
+  if(any == 0) { return; }
+  u64 w0 = T << (TILE_SHIFT - 6);
+  for(u32 k = threadIdx.x; k < (1u << (TILE_SHIFT - 6)); k += BLOCK_THREADS)
+  {
+    u64 w = w0 + k;
+    u64 v = (u64)tile[2 * k] | ((u64)tile[2 * k + 1] << 32);
+    if(w < nwords && v != 0) { bits[w] |= v; }
+  }
+}

@@ -1,0 +1,419 @@
+/*
+  kernels/transcode.hip.h -- native byte stream / plain symbols -> device rank structure, block samples.
+  Part of bwtm_kernels.hip.h (included there, inside namespace bwtm); gfx950 only.
+*/
+#pragma once
+
+//------------------------------------------------------------------------------
+// K0: native byte stream -> device rank structure (BWT::load + BWT::build, bwt.cpp:132-148, 476-512).
+//
+// The stream is cut into GROUPs of 62 consecutive 64-byte blocks; one wave owns one group and one
+// lane decodes one block, so the byte stream is read exactly once per kernel with coalesced loads.
+//
+//   k_block_len   : positions per block (-> exclusive scan = block_start, the set bits of
+//                   block_boundaries, bwt.cpp:496) and symbol counts per group (-> exclusive scan)
+//   k_build_sup   : absolute counts at the super boundaries
+//   k_build_recs  : the records
+//   k_block_cum   : cumulative symbol counts at the block starts (samples[c], bwt.cpp:489-511),
+//                   read back from the finished rank structure
+//
+// Every full block of a stream written by Run::write encodes at least 64 positions (a run of k bytes
+// is at least k long, support.h:256-282); k_block_len verifies this and the other kernels rely on it.
+
+constexpr int GROUP = 62;                 // blocks owned by one wave; 2 more are staged as lookahead
+constexpr int STAGE_WORDS = 17;           // LDS row stride of a staged block: conflict-free 32-bit reads
+constexpr int STAGE_ROWS = 64;
+
+__device__ inline void wave_sync_lds()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Stages blocks [first, first + count), count <= 64, into rows of STAGE_WORDS words (coalesced 16-byte loads).
+// Bytes past the end of the stream are staged as zeros (= runs of one endmarker, which deposit no bits).
+__device__ inline void stage_blocks(const u8* data, u64 nbytes, u64 first, u32 count, u32* rows)
+{
+  const u32 lane = lane_id();
+  const uint4* src = (const uint4*)(data + first * RLE_BLOCK);
+  const u64 left = nbytes - first * RLE_BLOCK;                        // bytes of the stream from `first` on
+  const u64 chunks_avail = (left + 15) / 16;                          // the buffer is readable up to the next multiple of 16
+#pragma unroll
+  for(int k = 0; k < 4; k++)
+  {
+    u32 g = (u32)k * 64 + lane;
+    if(g < 4 * count)
+    {
+      uint4 v = (g < chunks_avail ? src[g] : make_uint4(0, 0, 0, 0));
+      if((u64)16 * g + 16 > left && g < chunks_avail)                 // the chunk that holds the last byte
+      {
+        u32 keep = (u32)(left - (u64)16 * g);                          // 1..15 bytes
+        u32 m[4];
+#pragma unroll
+        for(u32 j = 0; j < 4; j++) { m[j] = (keep >= 4 * j + 4 ? ~0u : (keep <= 4 * j ? 0u : (1u << (8 * (keep - 4 * j))) - 1u)); }
+        v.x &= m[0]; v.y &= m[1]; v.z &= m[2]; v.w &= m[3];
+      }
+      u32* dst = rows + (g >> 2) * STAGE_WORDS + (g & 3) * 4;
+      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+  }
+}
+
+// Walks the runs of a staged block in order: on_short(sym, len) for runs of 1..41 (one byte, the common
+// case, kept straight-line), on_long(sym, len) for runs with a varint extension (support.h:236-250).
+// A byte-wise state machine without dynamic indexing.  CHECK_VALID: only the first `valid` bytes
+// belong to the stream and a run cut off there is dropped; otherwise all 64 bytes are decoded (bytes
+// staged past the end of the stream are zeros).
+template<bool CHECK_VALID, class FS, class FL>
+__device__ inline void for_each_run(const u32* row, u32 valid, FS&& on_short, FL&& on_long)
+{
+  u32 sym = 0, shift = 0; u64 len = 0; bool cont = false;
+#pragma unroll 1
+  for(int w = 0; w < 16; w++)
+  {
+    const u32 word = row[w];
+    // bytes >= 246 (heads of runs with a varint extension): high bit set and low 7 bits >= 0x76
+    const u32 long_heads = ((word & 0x7F7F7F7Fu) + 0x0A0A0A0Au) & word & 0x80808080u;
+    if(!cont && long_heads == 0 && (!CHECK_VALID || (u32)(4 * w + 3) < valid))
+    {
+      // four one-byte runs: no state, no branches
+#pragma unroll
+      for(int k = 0; k < 4; k++)
+      {
+        const u32 byte = (word >> (8 * k)) & 0xFF;
+        const u32 q = (byte * 171u) >> 10;                           // q = byte / 6, exact for byte < 256
+        on_short(byte - 6 * q, q + 1);
+      }
+      continue;
+    }
+#pragma unroll
+    for(int k = 0; k < 4; k++)
+    {
+      if(!CHECK_VALID || (u32)(4 * w + k) < valid)
+      {
+        u32 byte = (word >> (8 * k)) & 0xFF;
+        if(cont)
+        {
+          len += (u64)(byte & 0x7F) << shift; shift += 7; cont = (byte & 0x80) != 0;
+          if(!cont) { on_long(sym, len); }
+        }
+        else
+        {
+          u32 q = (byte * 171u) >> 10; sym = byte - 6 * q;
+          if(q + 1 >= MAX_RUN) { len = q + 1; shift = 0; cont = true; }
+          else { on_short(sym, q + 1); }
+        }
+      }
+    }
+  }
+}
+
+// blen[b] = positions encoded by block b; gcount[c * gstride + g] = occurrences of c in group g.
+// flags bit 0: a block other than the last one encodes fewer than 64 positions.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_block_len(const u8* data, u64 nbytes, u64 nblocks, u64 ngroups,
+  u64* blen, u64* gcount, u64 gstride, u32* flags)
+{
+  __shared__ u32 stage[BLOCK_THREADS / WAVE][STAGE_ROWS * STAGE_WORDS];
+  const u32 lane = lane_id(), wave = threadIdx.x >> 6;
+  const u64 g = (u64)blockIdx.x * (BLOCK_THREADS / WAVE) + wave;
+  if(g >= ngroups) { return; }
+  const u64 first = g * GROUP;
+  const u32 nb = (nblocks > first ? (nblocks - first > (u64)GROUP ? (u32)GROUP : (u32)(nblocks - first)) : 0u);
+  u32* rows = stage[wave];
+  if(nb > 0) { stage_blocks(data, nbytes, first, nb, rows); }
+  wave_sync_lds();
+  // Short runs (< 42) are counted in packed 16-bit fields (at most 64 * 41 per block), long ones in 64 bits.
+  u64 packed03 = 0; u32 packed45 = 0;
+  u64 l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0, l5 = 0;
+  const u64 b = first + lane;
+  if(lane < nb)
+  {
+    u64 begin = b * RLE_BLOCK;
+    u32 valid = (nbytes - begin >= RLE_BLOCK ? (u32)RLE_BLOCK : (u32)(nbytes - begin));
+    for_each_run<true>(rows + lane * STAGE_WORDS, valid,
+      [&](u32 sym, u32 l)
+      {
+        const u64 add = (u64)l << (16 * (sym & 3));                    // symbols 4 and 5 use fields 0 and 1 of packed45
+        packed03 += (sym < 4 ? add : 0ull); packed45 += (sym < 4 ? 0u : (u32)add);
+      },
+      [&](u32 sym, u64 len)
+      {
+        l0 += (sym == 0 ? len : 0); l1 += (sym == 1 ? len : 0); l2 += (sym == 2 ? len : 0);
+        l3 += (sym == 3 ? len : 0); l4 += (sym == 4 ? len : 0); l5 += (sym == 5 ? len : 0);
+      });
+    l0 += packed03 & 0xFFFF; l1 += (packed03 >> 16) & 0xFFFF; l2 += (packed03 >> 32) & 0xFFFF; l3 += packed03 >> 48;
+    l4 += packed45 & 0xFFFF; l5 += packed45 >> 16;
+    u64 total = l0 + l1 + l2 + l3 + l4 + l5;
+    blen[b] = total;
+    if(total < RLE_BLOCK && b + 1 < nblocks) { atomicOr(flags, 1u); }
+  }
+  u64 t0 = wave_sum(l0), t1 = wave_sum(l1), t2 = wave_sum(l2), t3 = wave_sum(l3), t4 = wave_sum(l4), t5 = wave_sum(l5);
+  if(lane == 0)
+  {
+    gcount[0 * gstride + g] = t0; gcount[1 * gstride + g] = t1; gcount[2 * gstride + g] = t2;
+    gcount[3 * gstride + g] = t3; gcount[4 * gstride + g] = t4; gcount[5 * gstride + g] = t5;
+  }
+}
+
+// block_end[b] = block_start[b + 1] - 1 (the set bits of block_boundaries, bwt.cpp:496).
+__global__ void __launch_bounds__(BLOCK_THREADS) k_block_end(const u64* block_start, u64 nblocks, u64* block_end)
+{
+  u64 b = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(b < nblocks) { block_end[b] = block_start[b + 1] - 1; }
+}
+
+// Largest b in [0, nblocks) with block_start[b] <= p (p < n).
+__device__ inline u64 find_block(const u64* block_start, u64 nblocks, u64 p)
+{
+  u64 lo = 0, hi = nblocks;           // invariant: block_start[lo] <= p < block_start[hi]
+  while(hi - lo > 1)
+  {
+    u64 mid = (lo + hi) >> 1;
+    if(block_start[mid] <= p) { lo = mid; } else { hi = mid; }
+  }
+  return lo;
+}
+
+// Super table from the native stream: one wave per super.  The counts at position p are the counts at
+// the start of p's group plus the runs of the group's blocks before p (one lane per block).
+__global__ void __launch_bounds__(BLOCK_THREADS) k_build_sup(const u8* data, u64 nbytes, const u64* block_start,
+  const u64* gcum, u64 gstride, u64 nblocks, u64 ngroups, u64 n, u64* sup, u64 nsup)
+{
+  const u32 lane = lane_id();
+  const u64 s = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
+  if(s >= nsup) { return; }
+  const u64 p = s << SUPER_SHIFT;
+  u64 g = ngroups;                                  // column of the totals
+  u64 c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+  if(p < n)
+  {
+    const u64 b = find_block(block_start, nblocks, p);   // wave-uniform
+    g = b / GROUP;
+    const u64 blk = g * GROUP + lane;
+    if(lane < (u32)GROUP && blk <= b)
+    {
+      u64 pos = block_start[blk], rle = blk * RLE_BLOCK;
+      const u64 end = (nbytes - rle >= RLE_BLOCK ? rle + RLE_BLOCK : nbytes);
+      while(rle < end && pos < p)
+      {
+        u32 sym; u64 len; run_decode(data, rle, sym, len);
+        u64 take = (p - pos < len ? p - pos : len);
+        c1 += (sym == 1 ? take : 0); c2 += (sym == 2 ? take : 0); c3 += (sym == 3 ? take : 0);
+        c4 += (sym == 4 ? take : 0); c5 += (sym == 5 ? take : 0);
+        pos += len;
+      }
+    }
+  }
+  c1 = wave_sum(c1); c2 = wave_sum(c2); c3 = wave_sum(c3); c4 = wave_sum(c4); c5 = wave_sum(c5);
+  if(lane == 0)
+  {
+    u64* out = sup + s * SUP_STRIDE;
+    out[0] = 0; out[6] = 0; out[7] = 0;
+    out[1] = gcum[1 * gstride + g] + c1; out[2] = gcum[2 * gstride + g] + c2; out[3] = gcum[3 * gstride + g] + c3;
+    out[4] = gcum[4 * gstride + g] + c4; out[5] = gcum[5 * gstride + g] + c5;
+  }
+}
+
+// Records from the native stream.  The wave of group g owns the records that START inside the group's
+// position range [S, E) (the last group also owns the rest); they may extend up to 127 positions into
+// the next group, which the two lookahead blocks cover.  Positions are processed in windows of
+// BR_WINDOW: every lane deposits the runs of its block into three LDS bit-planes (word-wise OR,
+// accumulated in registers while consecutive runs stay inside one word), then lane r assembles record
+// r of the window: planes from LDS, header = counts before the group + carried counts of the earlier
+// windows + wave prefix of the records' own counts.  One window is the common case (a group of
+// random-read BWT covers ~5300 positions); compressible streams take more windows over fewer bytes.
+// The window is a template parameter: 8192 positions for streams around the iid density, larger windows
+// (fewer waves per workgroup) for compressible streams whose groups cover more positions.
+template<u32 BR_WINDOW, int WAVES>
+__global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64 nbytes, const u64* block_start,
+  const u64* gcum, u64 gstride, u64 nblocks, u64 ngroups, u64 n, const u64* sup, uint4* recs, u64 nrecs)
+{
+  constexpr u32 PW = BR_WINDOW / 32;                             // words per plane
+  __shared__ u32 stage[WAVES][STAGE_ROWS * STAGE_WORDS];
+  __shared__ uint4 planes[WAVES][3][BR_WINDOW / 128];
+  const u32 lane = lane_id(), wave = threadIdx.x >> 6;
+  const u64 g = (u64)blockIdx.x * WAVES + wave;
+  if(g >= ngroups) { return; }
+  const u64 first = g * GROUP;
+  const bool last_group = (g + 1 == ngroups);
+  const u32 nb = (nblocks > first ? (nblocks - first > (u64)STAGE_ROWS ? (u32)STAGE_ROWS : (u32)(nblocks - first)) : 0u);
+  const u64 S = (nb > 0 ? block_start[first] : 0);
+  const u64 q_lo = (S + REC_POS - 1) >> REC_SHIFT;
+  const u64 q_hi = (last_group ? nrecs : (block_start[first + GROUP] + REC_POS - 1) >> REC_SHIFT);
+  if(q_lo >= q_hi) { return; }                                  // wave-uniform: no record starts in this group
+  u32* rows = stage[wave];
+  if(nb > 0) { stage_blocks(data, nbytes, first, nb, rows); }
+  const bool have = (lane < nb);
+  const u64 b = first + lane;
+  const u64 bstart = (have ? block_start[b] : 0), bend = (have ? block_start[b + 1] : 0);
+  const u32 valid = (have ? (nbytes - b * RLE_BLOCK >= RLE_BLOCK ? (u32)RLE_BLOCK : (u32)(nbytes - b * RLE_BLOCK)) : 0u);
+  u64 a1 = gcum[1 * gstride + g], a2 = gcum[2 * gstride + g], a3 = gcum[3 * gstride + g],
+      a4 = gcum[4 * gstride + g], a5 = gcum[5 * gstride + g];   // counts before the first record of the window
+  const u64 pos_end = ((q_hi << REC_SHIFT) < n ? (q_hi << REC_SHIFT) : n);
+  u32* pl = (u32*)planes[wave];                                 // plane k: words [PW k, PW k + PW)
+  for(u64 ws = S & ~(u64)(REC_POS - 1); (ws >> REC_SHIFT) < q_hi; ws += BR_WINDOW)
+  {
+#pragma unroll
+    for(u32 k = 0; k < 3 * PW / WAVE; k++) { pl[k * 64 + lane] = 0; }
+    wave_sync_lds();
+    const u64 we = (ws + BR_WINDOW < pos_end ? ws + BR_WINDOW : pos_end);
+    const bool inside = (have && bstart >= ws && bend <= ws + BR_WINDOW);
+    if(inside)
+    {
+      // The block lies inside the LDS window (the common case): its runs are appended to three bit
+      // streams, one per plane, through 64-bit shift accumulators that release a word whenever 32 bits
+      // are complete.  No clipping: bits past the last owned record are never read.
+      u64 acc0 = 0, acc1 = 0, acc2 = 0;
+      u32 fill = (u32)(bstart - ws) & 31u, wi = (u32)(bstart - ws) >> 5;
+      auto append = [&](u32 sym, u32 take)                      // 1 <= take <= 32, fill < 32
+      {
+        const u64 v = ((1ull << take) - 1ull) << fill;
+        acc0 |= (sym & 1 ? v : 0ull); acc1 |= (sym & 2 ? v : 0ull); acc2 |= (sym & 4 ? v : 0ull);
+        fill += take;
+        if(fill >= 32)
+        {
+          atomicOr(&pl[wi], (u32)acc0); atomicOr(&pl[PW + wi], (u32)acc1); atomicOr(&pl[2 * PW + wi], (u32)acc2);   // edge words are shared with the neighbours
+          acc0 >>= 32; acc1 >>= 32; acc2 >>= 32; fill -= 32; wi++;
+        }
+      };
+      for_each_run<false>(rows + lane * STAGE_WORDS, valid,
+        [&](u32 sym, u32 l) { append(sym, (l < 32 ? l : 32u)); if(l > 32) { append(sym, l - 32); } },
+        [&](u32 sym, u64 len) { u32 l = (u32)len; while(l > 0) { u32 take = (l < 32 ? l : 32u); append(sym, take); l -= take; } });
+      if(fill > 0 && wi < BR_WINDOW / 32) { atomicOr(&pl[wi], (u32)acc0); atomicOr(&pl[PW + wi], (u32)acc1); atomicOr(&pl[2 * PW + wi], (u32)acc2); }
+    }
+    else if(have && bstart < we && bend > ws)
+    {
+      // The block straddles a window edge: general path with clipping, word-wise OR.
+      u32 cur = 0, acc0 = 0, acc1 = 0, acc2 = 0;
+      auto deposit = [&](u32 sym, u32 a, u32 e)                 // window-relative positions [a, e)
+      {
+        while(a < e)
+        {
+          const u32 w = a >> 5;
+          if(w != cur)
+          {
+            if(acc0) { atomicOr(&pl[cur], acc0); } if(acc1) { atomicOr(&pl[PW + cur], acc1); } if(acc2) { atomicOr(&pl[2 * PW + cur], acc2); }
+            cur = w; acc0 = 0; acc1 = 0; acc2 = 0;
+          }
+          const u32 stop = (e < ((w + 1) << 5) ? e : ((w + 1) << 5));
+          const u32 count = stop - a;
+          const u32 mask = (count == 32 ? ~0u : ((1u << count) - 1u) << (a & 31));
+          acc0 |= (sym & 1 ? mask : 0u); acc1 |= (sym & 2 ? mask : 0u); acc2 |= (sym & 4 ? mask : 0u);
+          a = stop;
+        }
+      };
+      u64 pos = bstart;
+      auto run = [&](u32 sym, u64 len)
+      {
+        const u64 from = pos, to = pos + len;
+        pos = to;
+        if(sym != 0 && to > ws && from < we) { deposit(sym, (from > ws ? (u32)(from - ws) : 0u), (to < we ? (u32)(to - ws) : (u32)(we - ws))); }
+      };
+      for_each_run<false>(rows + lane * STAGE_WORDS, valid, [&](u32 sym, u32 l) { run(sym, (u64)l); }, run);
+      if(acc0) { atomicOr(&pl[cur], acc0); } if(acc1) { atomicOr(&pl[PW + cur], acc1); } if(acc2) { atomicOr(&pl[2 * PW + cur], acc2); }
+    }
+    wave_sync_lds();
+    // records rr * 64 + lane of the window
+    for(u32 rr = 0; rr < BR_WINDOW / 8192; rr++)
+    {
+    const uint4 P0 = planes[wave][0][rr * 64 + lane], P1 = planes[wave][1][rr * 64 + lane], P2 = planes[wave][2][rr * 64 + lane];
+    u32 n1 = 0, n2 = 0, n3 = 0, n4 = 0, n5 = 0;
+#define BWTM_COUNT_WORD(f) \
+    n1 += (u32)__builtin_popcount(plane_match(P0.f, P1.f, P2.f, 1)); n2 += (u32)__builtin_popcount(plane_match(P0.f, P1.f, P2.f, 2)); \
+    n3 += (u32)__builtin_popcount(plane_match(P0.f, P1.f, P2.f, 3)); n4 += (u32)__builtin_popcount(plane_match(P0.f, P1.f, P2.f, 4)); \
+    n5 += (u32)__builtin_popcount(plane_match(P0.f, P1.f, P2.f, 5));
+    BWTM_COUNT_WORD(x) BWTM_COUNT_WORD(y) BWTM_COUNT_WORD(z) BWTM_COUNT_WORD(w)
+#undef BWTM_COUNT_WORD
+    const u64 own14 = (u64)n1 | ((u64)n2 << 16) | ((u64)n3 << 32) | ((u64)n4 << 48);   // wave totals <= 8192 per field
+    const u64 incl14 = wave_incl_sum(own14), incl5 = wave_incl_sum((u64)n5);
+    const u64 before14 = incl14 - own14, before5 = incl5 - n5;
+    const u64 q = (ws >> REC_SHIFT) + rr * 64 + lane;
+    if(q >= q_lo && q < q_hi)
+    {
+      const u64 p = q << REC_SHIFT;
+      const u64* sp = sup + (p >> SUPER_SHIFT) * SUP_STRIDE;
+      u32 rel[6]; u32 h[4];
+      rel[0] = 0;
+      rel[1] = (u32)(a1 + (before14 & 0xFFFF) - sp[1]); rel[2] = (u32)(a2 + ((before14 >> 16) & 0xFFFF) - sp[2]);
+      rel[3] = (u32)(a3 + ((before14 >> 32) & 0xFFFF) - sp[3]); rel[4] = (u32)(a4 + (before14 >> 48) - sp[4]);
+      rel[5] = (u32)(a5 + before5 - sp[5]);
+      pack_header(rel, h);
+      uint4* dst = recs + 4 * q;
+      dst[0] = make_uint4(P0.x, P1.x, P2.x, h[0]);
+      dst[1] = make_uint4(P0.y, P1.y, P2.y, h[1]);
+      dst[2] = make_uint4(P0.z, P1.z, P2.z, h[2]);
+      dst[3] = make_uint4(P0.w, P1.w, P2.w, h[3]);
+    }
+    const u64 tot14 = shfl_u64(incl14, WAVE - 1), tot5 = shfl_u64(incl5, WAVE - 1);
+    a1 += tot14 & 0xFFFF; a2 += (tot14 >> 16) & 0xFFFF; a3 += (tot14 >> 32) & 0xFFFF; a4 += tot14 >> 48; a5 += tot5;
+    }
+    wave_sync_lds();                                             // the planes are cleared again by the next window
+  }
+}
+
+// cum[c * stride + b] = occurrences of c before the start of block b, b in [0, nblocks]
+// (CumulativeArray::sum(b) of samples[c], support.h:338-343), from the rank structure.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_block_cum(IndexView x, const u64* block_start, u64 count, u64* cum, u64 stride)
+{
+  u64 b = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(b >= count) { return; }
+  u64 p = block_start[b];
+  u64 r[6]; index_ranks(x, p, r);
+  cum[0 * stride + b] = p - (r[1] + r[2] + r[3] + r[4] + r[5]);
+  cum[1 * stride + b] = r[1]; cum[2 * stride + b] = r[2]; cum[3 * stride + b] = r[3]; cum[4 * stride + b] = r[4]; cum[5 * stride + b] = r[5];
+}
+
+//------------------------------------------------------------------------------
+// Plain symbols (one byte each) -> records.  k_sym_counts: per-record symbol counts
+// (cnt[c * stride + q], c = 1..5 used); after an exclusive scan k_sym_recs writes the records.
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_sym_counts(const u8* sym, u64 n, u64 nrecs, u64* cnt, u64 stride)
+{
+  u64 q = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(q >= nrecs) { return; }
+  u64 p = q << REC_SHIFT;
+  u32 c[6] = {0, 0, 0, 0, 0, 0};
+  for(u32 t = 0; t < REC_POS && p + t < n; t++)
+  {
+    u32 s = sym[p + t];
+    c[0] += (s == 0); c[1] += (s == 1); c[2] += (s == 2); c[3] += (s == 3); c[4] += (s == 4); c[5] += (s == 5);
+  }
+  for(int k = 0; k < 6; k++) { cnt[k * stride + q] = c[k]; }
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_sym_sup(const u64* cum, u64 stride, u64 nrecs, u64* sup, u64 nsup)
+{
+  u64 s = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(s >= nsup) { return; }
+  u64 q = s << SUPER_REC_SHIFT; if(q > nrecs) { q = nrecs; }
+  for(int c = 0; c < SUP_STRIDE; c++) { sup[s * SUP_STRIDE + c] = (c >= 1 && c < 6 ? cum[c * stride + q] : 0); }
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_sym_recs(const u8* sym, u64 n, const u64* cum, u64 stride,
+  const u64* sup, uint4* recs, u64 nrecs)
+{
+  u64 q = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(q >= nrecs) { return; }
+  u64 p = q << REC_SHIFT;
+  u32 plane[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+  for(u32 k = 0; k < 4; k++)
+  {
+    u32 a = 0, b = 0, c = 0;
+    for(u32 t = 0; t < 32; t++)
+    {
+      u64 pos = p + 32 * k + t;
+      u32 s = (pos < n ? sym[pos] : 0);
+      a |= (s & 1u) << t; b |= ((s >> 1) & 1u) << t; c |= ((s >> 2) & 1u) << t;
+    }
+    plane[0][k] = a; plane[1][k] = b; plane[2][k] = c;
+  }
+  const u64* s = sup + (p >> SUPER_SHIFT) * SUP_STRIDE;
+  u32 rel[6]; u32 h[4];
+  for(int c = 1; c < 6; c++) { rel[c] = (u32)(cum[c * stride + q] - s[c]); }
+  pack_header(rel, h);
+  uint4* dst = recs + 4 * q;
+#pragma unroll
+  for(u32 k = 0; k < 4; k++) { dst[k] = make_uint4(plane[0][k], plane[1][k], plane[2][k], h[k]); }
+}
