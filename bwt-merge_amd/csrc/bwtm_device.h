@@ -212,6 +212,13 @@ BWTM_HD u32 varint_bytes(u64 x) { return (bit_length64(x) + 6) / 7; }           
 
 BWTM_HD u64 long_run_bytes(u64 offset, u64 length)
 {
+  // Closed form of the loop below for the runs that dominate in practice, 42 <= length < 42 + 128: head byte + one
+  // extension byte, unless the head is the last byte of its block (basic length 41, the rest opens the next block).
+  if(length >= MAX_RUN && length < MAX_RUN + 128)
+  {
+    if((offset % RLE_BLOCK) != RLE_BLOCK - 1) { return 2; }
+    return (length - (MAX_RUN - 1) < MAX_RUN ? 2 : 3);
+  }
   u64 bytes = 0;
   while(length > 0)
   {
