@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="reads per set for the CPU baseline sample (0 = auto)")
     ap.add_argument("--workload", choices=("iid", "genome"), default="iid",
                     help="iid = the headline distribution; genome = reads from a shared random genome, 30x coverage, 1 %% substitutions (SURVEY 8(d), secondary)")
+    ap.add_argument("--coverage", type=int, default=30, help="genome workload: coverage (a smaller genome = a more repetitive BWT)")
+    ap.add_argument("--error-percent", type=int, default=1, help="genome workload: substitution rate in percent")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
@@ -80,13 +82,14 @@ def main():
 
     # ---------------------------------------------------------------- inputs (untimed)
     t_gen = time.time()
+    wargs = ({"coverage": args.coverage, "error_percent": args.error_percent} if args.workload == "genome" else {})
     sets = []
     for k, seed in enumerate((1001, 1002)):
         def progress(done, total, k=k):
             if rank == 0 and (done == total or (done // args.leaf_reads) % 16 == 0):
                 log("input%d: %d / %d reads (%.0f s)" % (k + 1, done, total, time.time() - t_gen))
         ix = synth.build_index(pkg, seed, args.reads, args.readlen, leaf_reads=args.leaf_reads, device=dev, progress=progress,
-                               workload=args.workload)
+                               workload=args.workload, **wargs)
         ix.encode()
         sets.append(ix)
     torch.cuda.empty_cache()
@@ -192,7 +195,7 @@ def main():
         got = synth.extract_sequences(pkg, last, ids, max_len=args.readlen + 8)
         for j, seq in zip(ids, got):
             seed, idx = (1001, int(j)) if j < A0.sequences else (1002, int(j - A0.sequences))
-            ref = synth.make_reads(args.workload, seed, idx, 1, args.readlen, args.reads)[0].tolist()
+            ref = synth.make_reads(args.workload, seed, idx, 1, args.readlen, args.reads, **wargs)[0].tolist()
             verified = verified and (seq == ref)
         # the emitted native stream must decode back to the merged index (header check in upload)
         p, nb = last.device_data()

@@ -73,13 +73,14 @@ def generate_genome_reads(seed, first_read, nreads, readlen, genome_len, device=
     return (1 + torch.where(is_sub, other, g)).to(torch.uint8)
 
 
-def make_reads(workload, seed, first_read, nreads, readlen, total_reads, device="cpu"):
+def make_reads(workload, seed, first_read, nreads, readlen, total_reads, device="cpu", coverage=30, error_percent=1):
     """Reads first_read .. first_read + nreads - 1 of set `seed` for a named workload: "iid" (the headline
     distribution) or "genome" (30x coverage of a shared random genome, 1 % substitutions)."""
     if workload == "iid":
         return generate_reads(seed, first_read, nreads, readlen, device=device)
     if workload == "genome":
-        return generate_genome_reads(seed, first_read, nreads, readlen, max(readlen, total_reads * readlen // 30), device=device)
+        return generate_genome_reads(seed, first_read, nreads, readlen, max(readlen, total_reads * readlen // coverage), device=device,
+                                     error_percent=error_percent)
     raise ValueError("unknown workload %r" % workload)
 
 
@@ -129,12 +130,12 @@ def merge_indexes(pkg, a, b, free_inputs=True):
     return out
 
 
-def build_index(pkg, seed, nreads, readlen=100, leaf_reads=1 << 19, device="cuda", progress=None, workload="iid"):
+def build_index(pkg, seed, nreads, readlen=100, leaf_reads=1 << 19, device="cuda", progress=None, workload="iid", **workload_args):
     """Index of the synthetic set `seed` (reads 0 .. nreads-1 in generation order)."""
     stack = []                               # (level, index); adjacent entries are adjacent read ranges
     for first in range(0, nreads, leaf_reads):
         count = min(leaf_reads, nreads - first)
-        reads = make_reads(workload, seed, first, count, readlen, nreads, device=device)
+        reads = make_reads(workload, seed, first, count, readlen, nreads, device=device, **workload_args)
         sym = leaf_bwt(reads).contiguous()
         if sym.is_cuda:
             torch.cuda.synchronize()
