@@ -315,12 +315,14 @@ int transcode(bwtm_index* x)
     x->sup.as<u64>(), x->nsup);
   // one wave per group; LDS window sized to the positions a group covers on average (iid reads: ~5300)
   const u64 per_group = x->n / x->ngroups;
-#define BUILD_RECS(W, WAVES) LAUNCH("build_recs", (k_build_recs<W, WAVES>), div_up(x->ngroups, WAVES), WAVES * WAVE, \
+  const bool long_runs = (x->nblocks > 0 && x->n / x->nblocks > 400);        // > ~6 positions per byte: cooperative fill of long runs pays
+#define BUILD_RECS(W, WAVES, FILL) LAUNCH("build_recs", (k_build_recs<W, WAVES, FILL>), div_up(x->ngroups, WAVES), WAVES * WAVE, \
     x->native_bytes(), x->nbytes, x->block_start.as<const u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, x->n, \
     x->sup.as<const u64>(), x->recs.as<uint4>(), x->nrecs)
-  if(per_group <= 6500) { BUILD_RECS(8192, 4); }
-  else if(per_group <= 14000) { BUILD_RECS(16384, 4); }
-  else { BUILD_RECS(32768, 2); }
+  if(per_group <= 6500) { BUILD_RECS(8192, 4, false); }
+  else if(per_group <= 14000) { BUILD_RECS(16384, 4, false); }
+  else if(!long_runs) { BUILD_RECS(32768, 2, false); }
+  else { BUILD_RECS(32768, 2, true); }
 #undef BUILD_RECS
   return BWTM_OK;
 }

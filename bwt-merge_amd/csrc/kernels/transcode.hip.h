@@ -225,13 +225,20 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_build_sup(const u8* data, u64
 // random-read BWT covers ~5300 positions); compressible streams take more windows over fewer bytes.
 // The window is a template parameter: 8192 positions for streams around the iid density, larger windows
 // (fewer waves per workgroup) for compressible streams whose groups cover more positions.
-template<u32 BR_WINDOW, int WAVES>
+// FILL (for streams of long runs): the whole plane words in the middle of a long run are not deposited by the lane
+// that decodes the run -- a serial loop of length / 32 steps on a mostly idle wave -- but queued in LDS and written
+// by all 64 lanes after the decode pass.  It costs ~1 ms on read-like streams, hence a template flag.
+constexpr u32 BR_FILLS = 256;
+
+template<u32 BR_WINDOW, int WAVES, bool FILL>
 __global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64 nbytes, const u64* block_start,
   const u64* gcum, u64 gstride, u64 nblocks, u64 ngroups, u64 n, const u64* sup, uint4* recs, u64 nrecs)
 {
   constexpr u32 PW = BR_WINDOW / 32;                             // words per plane
   __shared__ u32 stage[WAVES][STAGE_ROWS * STAGE_WORDS];
   __shared__ uint4 planes[WAVES][3][BR_WINDOW / 128];
+  __shared__ u32 fill_list[WAVES][FILL ? BR_FILLS : 1];
+  __shared__ u32 fill_count[WAVES];
   const u32 lane = lane_id(), wave = threadIdx.x >> 6;
   const u64 g = (u64)blockIdx.x * WAVES + wave;
   if(g >= ngroups) { return; }
@@ -256,9 +263,19 @@ __global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64
   {
 #pragma unroll
     for(u32 k = 0; k < 3 * PW / WAVE; k++) { pl[k * 64 + lane] = 0; }
+    if(FILL && lane == 0) { fill_count[wave] = 0; }
     wave_sync_lds();
     const u64 we = (ws + BR_WINDOW < pos_end ? ws + BR_WINDOW : pos_end);
     const bool inside = (have && bstart >= ws && bend <= ws + BR_WINDOW);
+    // Queues `nwords` whole words from `word` on for the cooperative fill; returns the number of words taken over
+    // (0 if the queue is full: the caller then deposits them itself).
+    auto queue_fill = [&](u32 sym, u32 word, u32 nwords) -> u32
+    {
+      const u32 slot = atomicAdd(&fill_count[wave], 1u);
+      if(slot >= BR_FILLS) { return 0; }
+      fill_list[wave][slot] = word | ((nwords - 1) << 10) | (sym << 20);      // word < 1024, nwords <= 1024
+      return nwords;
+    };
     if(inside)
     {
       // The block lies inside the LDS window (the common case): its runs are appended to three bit
@@ -279,7 +296,21 @@ __global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64
       };
       for_each_run<false>(rows + lane * STAGE_WORDS, valid,
         [&](u32 sym, u32 l) { append(sym, (l < 32 ? l : 32u)); if(l > 32) { append(sym, l - 32); } },
-        [&](u32 sym, u64 len) { u32 l = (u32)len; while(l > 0) { u32 take = (l < 32 ? l : 32u); append(sym, take); l -= take; } });
+        [&](u32 sym, u64 len)
+        {
+          u32 l = (u32)len;
+          if(FILL)
+          {
+            if(fill != 0) { const u32 take = (l < 32 - fill ? l : 32 - fill); append(sym, take); l -= take; }   // completes the current word
+            if(l >= 128)                                          // fill == 0 here: whole words follow
+            {
+              const u32 nfull = l >> 5;
+              const u32 taken = (sym == 0 ? nfull : queue_fill(sym, wi, nfull));                     // endmarker runs leave the planes zero
+              wi += taken; l -= 32 * taken;
+            }
+          }
+          while(l > 0) { const u32 take = (l < 32 ? l : 32u); append(sym, take); l -= take; }
+        });
       if(fill > 0 && wi < BR_WINDOW / 32) { atomicOr(&pl[wi], (u32)acc0); atomicOr(&pl[PW + wi], (u32)acc1); atomicOr(&pl[2 * PW + wi], (u32)acc2); }
     }
     else if(have && bstart < we && bend > ws)
@@ -291,6 +322,11 @@ __global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64
         while(a < e)
         {
           const u32 w = a >> 5;
+          if(FILL && (a & 31) == 0 && e - a >= 128)
+          {
+            const u32 taken = queue_fill(sym, w, (e - a) >> 5);
+            if(taken != 0) { a += 32 * taken; continue; }
+          }
           if(w != cur)
           {
             if(acc0) { atomicOr(&pl[cur], acc0); } if(acc1) { atomicOr(&pl[PW + cur], acc1); } if(acc2) { atomicOr(&pl[2 * PW + cur], acc2); }
@@ -314,6 +350,20 @@ __global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64
       if(acc0) { atomicOr(&pl[cur], acc0); } if(acc1) { atomicOr(&pl[PW + cur], acc1); } if(acc2) { atomicOr(&pl[2 * PW + cur], acc2); }
     }
     wave_sync_lds();
+    if(FILL)
+    {
+      const u32 nfills = (fill_count[wave] < BR_FILLS ? fill_count[wave] : BR_FILLS);
+      for(u32 k = 0; k < nfills; k++)
+      {
+        const u32 entry = fill_list[wave][k];
+        const u32 word = entry & 0x3FF, nwords = ((entry >> 10) & 0x3FF) + 1, sym = entry >> 20;
+        for(u32 j = lane; j < nwords; j += WAVE)
+        {
+          if(sym & 1) { pl[word + j] = ~0u; } if(sym & 2) { pl[PW + word + j] = ~0u; } if(sym & 4) { pl[2 * PW + word + j] = ~0u; }
+        }
+      }
+      if(nfills != 0) { wave_sync_lds(); }
+    }
     // records rr * 64 + lane of the window
     for(u32 rr = 0; rr < BR_WINDOW / 8192; rr++)
     {
