@@ -10,8 +10,8 @@ all-reduce (sum == or: set bits are disjoint); the rest is replicated ("strong" 
 the job is fixed as N grows).
 
 Prints ONE JSON line on rank 0 (see the contract in the task description), including
-  roofline      HBM roofline of the dominant kernel (k_lf_walk), duration measured with HIP
-                events on the library's stream
+  roofline      HBM roofline of the dominant kernel (k_frontier_step; k_lf_walk_binned for small inputs), duration
+                measured with HIP events on the library's stream
   cpu_baseline  the CPU oracle (port of the reference algorithm) timed on this host's cores
                 on a bounded sample of the same workload (N == 1, rank 0 only)
 """

@@ -50,16 +50,16 @@ Context g_ctx;
 // Diagnostic knobs (bwtm_tune): never change results unless documented as timing-only.
 struct Tuning
 {
-  long long walk_emit = 0;       // 0 product path; 1 / 2 timing-only variants of the emit (see k_lf_walk)
+  long long walk_emit = 0;       // 0 = real emit; 1 / 2 timing-only variants of the emit (see k_lf_walk)
   long long walk_blocks = 0;     // grid size override for k_lf_walk (0 = default)
-  long long walk_kernel = 0;     // 0 = four lanes per chain (product), 1 = one lane per chain (first version, kept for A/B)
+  long long walk_kernel = 0;     // 0 = four lanes per chain (default), 1 = one lane per chain (first version, kept for A/B)
   long long walk_ablate = 0;     // timing-only ablations of the no-emit quad kernel (tools/walk_experiments.py)
   long long search_algo = 0;     // 0 = by size (frontier search for large shards, per-chain walk for small ones), 1 = walk, 2 = frontier
   long long frontier_unfused = 0; // 1 = generic scan + k_frontier_prep per step (the path of segment tables with > 8192 tiles)
   long long l1_cap = 0;          // tests only: entries per level-1 region (0 = sized from the input)
-  long long walk_variant = 0;    // 0 = four lanes per chain, four pipelined chains per quad (product); 1 = LDS-transposed one chain per lane
-  long long scatter_kernel = 0;  // 0 = LDS counting sort (product), 1 = direct scattered stores (first version)
-  long long emit_path = 0;       // 0 = partitioned emit (product), 1 = atomicOr on the bitvector (first version, also the fallback)
+  long long walk_variant = 0;    // 0 = four lanes per chain, four pipelined chains per quad (default); 1 = LDS-transposed one chain per lane
+  long long scatter_kernel = 0;  // 0 = LDS counting sort (default), 1 = direct scattered stores (first version)
+  long long emit_path = 0;       // 0 = partitioned emit (default), 1 = atomicOr on the bitvector (first version, also the fallback)
   long long round_emits = 1ll << 33;   // upper bound of emits partitioned per round (bounds the temporary regions)
 };
 Tuning g_tune;

@@ -1,5 +1,5 @@
 /*
-  kernels/search_frontier.hip.h -- the search in level-synchronous form (product path for read collections).
+  kernels/search_frontier.hip.h -- the search in level-synchronous form (what bwtm_search runs for shards of >= 2^21 sequences of a read collection).
   Part of bwtm_kernels.hip.h (included there, inside namespace bwtm); gfx950 only.
 */
 #pragma once

@@ -15,7 +15,7 @@
 // Per step one 64-byte record of B and one of A are fetched (both addresses are known at the
 // top of the iteration, so the two HBM accesses overlap), plus two L2-resident super rows.
 
-// EMIT: 0 = atomicOr into the bitvector (the product path); 1 = nothing, 2 = plain 8-byte store
+// EMIT: 0 = atomicOr into the bitvector (first version; exact fallback of the partitioned emit); 1 = nothing, 2 = plain 8-byte store
 // of r at scratch[i] (diagnostic builds for pricing the emit traffic; results are not a rank array).
 template<int EMIT>
 __device__ inline void walk_emit(u32* bits, u64 i, u64 r)
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_lf_walk(IndexView A, IndexVie
 }
 
 //------------------------------------------------------------------------------
-// K1, product form: FOUR lanes per chain.  A 64-byte record is four 16-byte chunks
+// K1, walk form used by bwtm_search: FOUR lanes per chain.  A 64-byte record is four 16-byte chunks
 // {plane0, plane1, plane2, header word} of 32 positions each, so lane q of a quad loads chunk q
 // with ONE dwordx4: the quad's four loads fall into one 64-byte line and cost a single request in
 // the vector memory pipeline (measured: 95 G records/s against 23 G records/s when one lane issues
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_lf_walk_quad(IndexView A, Ind
 }
 
 //------------------------------------------------------------------------------
-// K1 + K2, product form: search with a PARTITIONED EMIT.
+// K1 + K2, walk form used by bwtm_search (shards below 2^21 sequences, long sequences): search with a PARTITIONED EMIT.
 //
 // Scattered memory-side atomics cap at ~24 G/s on MI355X and queue behind the next step's loads
 // (DESIGN.md 3.1), so the walk does not touch the bitvector.  Every emit p = i + r becomes a 32-bit
@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(WB_THREADS, 4) k_lf_walk_binned(IndexView A, I
   }
 }
 
-// K1, product form 3: COALESCED LOADS, ONE CHAIN PER LANE.
+// K1, experimental variant (walk_variant = 1, slower): COALESCED LOADS, ONE CHAIN PER LANE.
 // The quad kernel above makes every lane of a quad repeat the chain arithmetic (9.6 wave
 // instructions per LF step against 2.8 for one lane per chain), and the ablation shows ~106 ms of
 // pure issue time at config 2.  Here a lane owns one chain again, but the records still arrive
@@ -579,7 +579,7 @@ __global__ void __launch_bounds__(PART_THREADS) k_part_scatter(const u32* l1, u6
   }
 }
 
-// Level 2, pass c, product form: LDS counting sort of 16 384-entry chunks, so that entries of
+// Level 2, pass c: LDS counting sort of 16 384-entry chunks, so that entries of
 // the same tile leave the workgroup as contiguous runs (a wave store touches ~3 lines instead
 // of 64).  Dynamic LDS: sorted[SORT_CHUNK] u32, hist[nsub] u32, offs[nsub] u32, cursor[nsub] u64.
 constexpr int SORT_CHUNK = 16384;

@@ -48,7 +48,7 @@ typedef struct bwtm_ra    bwtm_ra;      /* device-resident rank array: replaces 
 /* Selects the HIP device for the calling process and creates the library's stream. */
 int bwtm_init(int device);
 const char* bwtm_last_error(void);
-/* Diagnostic knobs for measurements (see DESIGN.md "Experiments"); defaults are the product path. */
+/* Diagnostic knobs for measurements and tests; the defaults are what a caller wants. */
 int bwtm_tune(const char* key, long long value);
 /* Returns the library's cached device memory to the driver (device buffers released by
    handles are kept in a pool for reuse). */
