@@ -135,6 +135,7 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
     r = (u64)l.y | ((u64)(h >> 8) << 32);
   }
   const u64 any_active = __ballot(active);
+  u32 tile_first = 0xFFFFFFFFu, tile_last = 0xFFFFFFFFu;           // tiles of the wave's first / last element (EMIT == 0)
   u32 c = 0;
   u64 ni = 0, nr = 0;
   if(any_active != 0)
@@ -145,9 +146,10 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
     if(EMIT == 0)
     {
       // Dense emit + tile markers: bound_row[tile] = min(logical index of an element in the tile).
-      // A lane marks when the previous lane lies in another tile; lane 0 of every wave always marks
-      // (the true first element of the tile marks too and wins the minimum).  Tiles without
-      // elements are filled in by k_bound_suffix_min.
+      // A lane marks when the previous lane lies in another tile.  Lane 0 does not know its predecessor: it
+      // marks after the partition barrier below, unless the previous wave of the block ended in the same tile
+      // (the first wave of a block always marks; the true first element of the tile marks too and wins the
+      // minimum).  Tiles without elements are filled in by k_bound_suffix_min.
       const u64 p = i + r;
       const u64 my_tile = p >> TILE_SHIFT;
       const u64 prev_tile = shfl_up_u64(my_tile, 1);
@@ -156,8 +158,10 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
         u64 slot = f.emit_base[f.step] + g;
         if(slot < f.emit_cap) { f.emit16[slot] = (unsigned short)(p & TILE_MASK); }
         else { sink_fallback(f.bits32, p); }                      // exact fallback; k_tile_build_frontier skips these slots
-        if(lane == 0 || my_tile != prev_tile) { atomicMin(&f.bound_row[my_tile], (u32)g); }
+        if(lane != 0 && my_tile != prev_tile) { atomicMin(&f.bound_row[my_tile], (u32)g); }
       }
+      tile_first = (u32)my_tile;                                  // meaningful in lane 0
+      tile_last = (u32)shfl_u64(my_tile, (int)last_lane);
     }
     u32 wb[16];
     const u64 rec_b = (active ? i : li) >> REC_SHIFT, rec_a = (active ? r : lr) >> REC_SHIFT;
@@ -205,12 +209,13 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
     cnt_w[k] = (u32)__builtin_popcountll(m);
     if(c == k) { my_rank = (u32)__builtin_popcountll(m & ((1ull << lane) - 1)); }
   }
-  if(lane == 0) { for(u32 k = 1; k < 6; k++) { wave_cnt[wave][k] = cnt_w[k]; } }
+  if(lane == 0) { wave_cnt[wave][0] = tile_last; for(u32 k = 1; k < 6; k++) { wave_cnt[wave][k] = cnt_w[k]; } }
   // Raw barrier with an LDS-only wait: __syncthreads() would also drain vmcnt and expose the latency
   // of the emit reservation / stores that are still in flight (measured: +35 ms per search).
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  if(EMIT == 0 && lane == 0 && active && (wave == 0 || wave_cnt[wave - 1][0] != tile_first)) { atomicMin(&f.bound_row[tile_first], (u32)g); }
   u32 class_base = 0, before_waves = 0;
 #pragma unroll
   for(u32 k = 1; k < 6; k++)
