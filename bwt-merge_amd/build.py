@@ -7,9 +7,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbwtm.so")
 SOURCES = ["bwtm_api.hip"]
-KERNELS = ["common", "transcode", "queries", "search_walk", "search_frontier", "interleave", "encoder"]
+KERNELS = ["common", "transcode", "queries", "search_walk", "search_frontier", "interleave", "encoder", "diagnostics"]
+API = ["context", "index", "search", "merge"]
 DEPS = (["bwtm_api.hip", "bwtm_kernels.hip.h", "bwtm_device.h", os.path.join("..", "..", "include", "bwtm.h")]
-        + [os.path.join("kernels", k + ".hip.h") for k in KERNELS])
+        + [os.path.join("kernels", k + ".hip.h") for k in KERNELS] + [os.path.join("api", k + ".hip.h") for k in API])
 
 
 def hipcc():
@@ -26,12 +27,14 @@ def stale():
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
-def build(force=False, verbose=False):
-    """Compile for gfx950 only (no other targets, no fallbacks)."""
-    if not force and not stale():
+def build(force=False, verbose=False, diagnostics=False, out=None):
+    """Compile for gfx950 only (no other targets, no fallbacks).  diagnostics=True adds the timing-only
+    kernel variants and their bwtm_tune keys (-DBWTM_DIAGNOSTICS; never the product build)."""
+    out = out or LIB
+    if not force and out == LIB and not stale():
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread"] + \
+          (["-DBWTM_DIAGNOSTICS"] if diagnostics else []) + ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -16,9 +16,36 @@ p_u8 = C.POINTER(C.c_uint8)
 p_u64 = C.POINTER(C.c_uint64)
 vp = C.c_void_p
 
+
+
+class HostInput(C.Structure):
+    """bwtm_host_input"""
+    _fields_ = [("data", C.c_void_p), ("nbytes", u64), ("sequences", u64), ("bases", u64), ("C", p_u64)]
+
+
+class HostOutput(C.Structure):
+    """bwtm_host_output"""
+    _fields_ = [("data", C.c_void_p), ("nbytes", u64), ("blocks", u64), ("sequences", u64), ("bases", u64),
+                ("C", u64 * (SIGMA + 1)), ("block_end", C.c_void_p), ("cum", C.c_void_p),
+                ("ms_upload", C.c_double), ("ms_search", C.c_double), ("ms_interleave", C.c_double),
+                ("ms_encode_download", C.c_double), ("ms_samples", C.c_double), ("ms_total", C.c_double)]
+
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, u64)
+
 # Every symbol include/bwtm.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("bwtm_init", C.c_int, [C.c_int]),
+    ("bwtm_context_create", C.c_int, [C.c_int, C.POINTER(vp)]),
+    ("bwtm_context_make_current", C.c_int, [vp]),
+    ("bwtm_context_destroy", None, [vp]),
+    ("bwtm_device_bytes_peak", u64, [C.c_int]),
+    ("bwtm_host_alloc", C.c_int, [u64, C.POINTER(vp)]),
+    ("bwtm_host_free", None, [vp]),
+    ("bwtm_ra_download_runs", C.c_int, [vp, p_u64, p_u64, u64, p_u64]),
+    ("bwtm_merge_consume", C.c_int, [vp, vp, C.POINTER(vp)]),
+    ("bwtm_merge_host", C.c_int, [C.POINTER(HostInput), C.POINTER(HostInput), ALLOC_FN, vp, C.c_int, C.POINTER(HostOutput), C.POINTER(vp)]),
+    ("bwtm_merge_host_chained", C.c_int, [vp, C.POINTER(HostInput), ALLOC_FN, vp, C.c_int, C.POINTER(HostOutput), C.POINTER(vp)]),
     ("bwtm_last_error", C.c_char_p, []),
     ("bwtm_synchronize", C.c_int, []),
     ("bwtm_trim", C.c_int, []),
@@ -109,6 +136,114 @@ def tune(key, value):
 
 def trim():
     check(lib().bwtm_trim())
+
+
+def device_bytes_peak(reset=False):
+    """Peak bytes of device memory the library's context has held since the last reset."""
+    return int(lib().bwtm_device_bytes_peak(1 if reset else 0))
+
+
+class Context:
+    """An additional library context (device + streams + memory pool); make_current() binds the calling thread."""
+
+    def __init__(self, device=0):
+        out = vp()
+        check(lib().bwtm_context_create(device, C.byref(out)))
+        self.h = out
+
+    def make_current(self):
+        check(lib().bwtm_context_make_current(self.h))
+
+    def destroy(self):
+        if self.h:
+            lib().bwtm_context_destroy(self.h)
+            self.h = None
+
+
+def make_default_current():
+    check(lib().bwtm_context_make_current(None))
+
+
+class HostBuffer:
+    """Page-locked host memory (bwtm_host_alloc) viewed as a numpy array."""
+
+    def __init__(self, nbytes, dtype=np.uint8, ptr=None):
+        self.nbytes = int(nbytes)
+        if ptr is None:
+            out = vp()
+            check(lib().bwtm_host_alloc(self.nbytes, C.byref(out)))
+            ptr = out.value
+        self.ptr = ptr
+        raw = (C.c_uint8 * max(self.nbytes, 1)).from_address(self.ptr)
+        self.array = np.frombuffer(raw, dtype=np.uint8)[: self.nbytes].view(dtype)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib().bwtm_host_free(vp(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class HostMerge:
+    """Result of merge_host: page-locked data / block_end / cum arrays + the phase times of the call."""
+
+    def __init__(self):
+        self.buffers = {}
+        self.out = HostOutput()
+        self.keep = None
+
+    def free(self):
+        for b in self.buffers.values():
+            b.free()
+        self.buffers = {}
+        if self.keep is not None:
+            self.keep.free()
+            self.keep = None
+
+    data = property(lambda s: s.buffers[0].array[: s.out.nbytes])
+    block_end = property(lambda s: s.buffers[1].array.view(np.uint64)[: s.out.blocks])
+    cum = property(lambda s: s.buffers[2].array.view(np.uint64)[: SIGMA * (s.out.blocks + 1)].reshape(SIGMA, s.out.blocks + 1))
+    C = property(lambda s: np.array(list(s.out.C), dtype=np.uint64))
+    times = property(lambda s: {k: getattr(s.out, k) for k in ("ms_upload", "ms_search", "ms_interleave", "ms_encode_download", "ms_samples", "ms_total")})
+
+
+def _host_input(data, sequences, bases):
+    """data: numpy uint8 array (ideally the .array of a HostBuffer)."""
+    assert data.dtype == np.uint8 and data.flags["C_CONTIGUOUS"]
+    return HostInput(data.ctypes.data, data.size, sequences, bases, None)
+
+
+def merge_host(a, b, samples=True, keep=False, chained=None):
+    """FMI::FMI(a, b) from host-resident inputs to a host-resident result (bwtm_merge_host).
+    a, b: (data uint8 array, sequences, bases); chained: a device Index (consumed) instead of a."""
+    res = HostMerge()
+
+    def alloc(user, what, nbytes):
+        buf = HostBuffer(nbytes)
+        res.buffers[what] = buf
+        return buf.ptr
+
+    cb = ALLOC_FN(alloc)
+    hb = _host_input(*b)
+    kp = vp()
+    if chained is not None:
+        h, chained.h = chained.h, None                     # consumed by the call
+        rc = lib().bwtm_merge_host_chained(h, C.byref(hb), cb, None, 1 if samples else 0, C.byref(res.out), C.byref(kp) if keep else None)
+    else:
+        ha = _host_input(*a)
+        rc = lib().bwtm_merge_host(C.byref(ha), C.byref(hb), cb, None, 1 if samples else 0, C.byref(res.out), C.byref(kp) if keep else None)
+    if rc != 0:
+        res.free()
+        check(rc)
+    if keep:
+        res.keep = Index(kp)
+    return res
 
 
 def _u8(a):
@@ -279,6 +414,15 @@ class RankArray:
         check(lib().bwtm_ra_download(self.h, out.ctypes.data_as(p_u64), out.size))
         return out
 
+    def runs(self):
+        """The rank array as maximal (rank, count) runs (the reference's own form)."""
+        n = u64(0)
+        check(lib().bwtm_ra_download_runs(self.h, None, None, 0, C.byref(n)))
+        ranks = np.zeros(n.value, dtype=np.uint64)
+        counts = np.zeros(n.value, dtype=np.uint64)
+        check(lib().bwtm_ra_download_runs(self.h, ranks.ctypes.data_as(p_u64), counts.ctypes.data_as(p_u64), n.value, C.byref(n)))
+        return ranks, counts
+
     def bits(self):
         words = (self.n_out + 63) // 64
         out = np.zeros(words, dtype=np.uint64)
@@ -300,6 +444,15 @@ def merge(a, b):
     """FMI::FMI(a, b): search + finalize + interleave + encode + samples on the device."""
     out = vp()
     check(lib().bwtm_merge(a.h, b.h, C.byref(out)))
+    return Index(out)
+
+
+def merge_consume(a, b):
+    """The same with the reference's ownership: a and b are destroyed, their memory released progressively."""
+    out = vp()
+    ha, hb = a.h, b.h
+    a.h = None; b.h = None
+    check(lib().bwtm_merge_consume(ha, hb, C.byref(out)))
     return Index(out)
 
 

@@ -1,0 +1,474 @@
+/*
+  api/context.hip.h -- contexts (device + streams + memory pool), errors, launch macros, device buffers,
+  per-kernel profiling, generic scans.  Part of bwtm_api.hip.
+*/
+#pragma once
+
+//------------------------------------------------------------------------------
+// Errors.
+
+namespace
+{
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...)
+{
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+inline u64 div_up(u64 a, u64 b) { return (a + b - 1) / b; }
+
+} // namespace
+
+//------------------------------------------------------------------------------
+// Context.  One HIP device, a compute stream (all kernels), a copy stream (chunked H2D / D2H that
+// overlaps with kernels) and a memory pool.  All work that touches pooled buffers is ordered on the
+// compute stream, so a block released by a handle may be handed to the next allocation immediately
+// (stream order protects it); work on the copy stream is always joined back into the compute stream
+// (or the host) before the buffers it touches are released.  Blocks return to the driver only in
+// bwtm_trim() or when hipMalloc runs out of memory: a repeated merge of the same shape performs no
+// hipMalloc / hipFree at all (both cost milliseconds per GB and serialise with the device).
+
+struct bwtm_context
+{
+  int device = -1;
+  hipStream_t stream = nullptr;            // compute
+  hipStream_t copy_stream = nullptr;       // H2D / D2H
+  std::recursive_mutex mu;                 // calls on one context are serialized
+  bool is_default = false;
+
+  // per-kernel profiling (bwtm_profile_*)
+  bool profiling = false;
+  struct Pending { const char* name; hipEvent_t start, stop; };
+  std::vector<Pending> pending;
+  std::map<std::string, std::pair<double, uint64_t>> totals;
+  std::vector<const char*> order;
+
+  // memory pool
+  std::multimap<u64, void*> free_blocks;
+  u64 cached_bytes = 0, held_bytes = 0, peak_bytes = 0;     // held = obtained from hipMalloc and not yet hipFree'd
+
+  // small page-locked scratch for results read back by the host (a pageable destination would make
+  // hipMemcpyAsync stage and block)
+  u64* host_scratch = nullptr;             // 64 u64
+};
+
+namespace
+{
+
+// Knobs (bwtm_tune): process-wide, read at the start of a call.  None of the product knobs changes results.
+struct Tuning
+{
+  long long search_algo = 0;      // 0 = by size (frontier search for large shards, per-chain walk for small ones), 1 = walk, 2 = frontier
+  long long frontier_unfused = 0; // 1 = generic scan + k_frontier_prep per step (the path of segment tables with > 8192 tiles)
+  long long l1_cap = 0;           // tests: entries per level-1 region / emit capacity (0 = sized from the input): forces the exact fallbacks
+  long long emit_path = 0;        // 0 = partitioned emit (default), 1 = atomicOr on the bitvector (the exact fallback, first version)
+  long long round_emits = 1ll << 33;      // upper bound of emits partitioned per round of the walk (bounds the temporary regions)
+  long long emit_budget = 16ll << 30;     // bytes of dense emits the frontier search keeps before it builds tiles (one epoch)
+  long long frontier_epoch = 512;         // upper bound of steps per epoch (tests use small values)
+  long long eager_cum_budget = 16ll << 30; // bwtm_index_encode materializes the samples' cumulative counts when they take at most this many bytes
+  long long upload_chunk = 64ll << 20;    // bytes per H2D chunk of the pipelined upload
+  long long download_chunk = 128ll << 20; // approximate bytes per D2H chunk of the pipelined download
+#ifdef BWTM_DIAGNOSTICS
+  long long walk_emit = 0;       // 0 = real emit; 1 / 2 timing-only variants of the emit (see diagnostics.hip.h)
+  long long walk_blocks = 0;     // grid size override for the walk kernels (0 = default)
+  long long walk_kernel = 0;     // 0 = four lanes per chain (default), 1 = one lane per chain (first version)
+  long long walk_ablate = 0;     // timing-only ablations of the no-emit quad kernel (tools/walk_experiments.py)
+  long long walk_variant = 0;    // 1 = LDS-transposed one chain per lane
+  long long scatter_kernel = 0;  // 1 = direct scattered stores in level 2 of the partition (first version)
+#endif
+};
+Tuning g_tune;
+
+std::mutex g_registry_mu;
+std::map<int, bwtm_context*> g_default_ctx;          // device -> default context
+thread_local bwtm_context* t_bound = nullptr;        // the calling thread's context (bwtm_init / make_current)
+thread_local bwtm_context* t_ctx = nullptr;          // the context of the API call in progress
+
+#define CTX (*t_ctx)
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if(e_ != hipSuccess) { \
+  return fail(e_ == hipErrorOutOfMemory ? BWTM_ENOMEM : BWTM_ENODEV, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } } while(0)
+
+#define TRY(expr) do { int rc_ = (expr); if(rc_ != BWTM_OK) { return rc_; } } while(0)
+
+int context_setup(bwtm_context* c, int device)
+{
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if(e != hipSuccess || count <= 0) { return fail(BWTM_ENODEV, "no HIP device available (%s)", hipGetErrorString(e)); }
+  if(device < 0 || device >= count) { return fail(BWTM_EINVAL, "device %d out of range (%d devices)", device, count); }
+  HIP_TRY(hipSetDevice(device));
+  c->device = device;
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  HIP_TRY(hipHostMalloc((void**)&c->host_scratch, 64 * sizeof(u64), hipHostMallocDefault));
+  // Kernels that take more than the default 64 KiB of dynamic LDS (a per-device attribute).
+  HIP_TRY(hipFuncSetAttribute((const void*)k_part_scatter_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_lf_walk_binned<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024));
+#ifdef BWTM_DIAGNOSTICS
+  HIP_TRY(hipFuncSetAttribute((const void*)k_lf_walk_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 122 * 1024));
+  HIP_TRY(hipFuncSetAttribute((const void*)k_lf_walk_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 82 * 1024));
+#endif
+  return BWTM_OK;
+}
+
+void context_teardown(bwtm_context* c)
+{
+  if(c->device < 0) { return; }
+  (void)hipSetDevice(c->device);
+  if(c->stream) { (void)hipStreamSynchronize(c->stream); }
+  if(c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); }
+  for(auto& p : c->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
+  c->pending.clear();
+  for(auto& kv : c->free_blocks) { (void)hipFree(kv.second); }
+  c->free_blocks.clear();
+  if(c->host_scratch) { (void)hipHostFree(c->host_scratch); }
+  if(c->stream) { (void)hipStreamDestroy(c->stream); }
+  if(c->copy_stream) { (void)hipStreamDestroy(c->copy_stream); }
+}
+
+// The default context of a device (created on first use).
+int default_context(int device, bwtm_context** out)
+{
+  std::lock_guard<std::mutex> lock(g_registry_mu);
+  auto it = g_default_ctx.find(device);
+  if(it != g_default_ctx.end()) { *out = it->second; return BWTM_OK; }
+  bwtm_context* c = new bwtm_context();
+  c->is_default = true;
+  int rc = context_setup(c, device);
+  if(rc != BWTM_OK) { context_teardown(c); delete c; return rc; }
+  g_default_ctx[device] = c;
+  *out = c;
+  return BWTM_OK;
+}
+
+// Every entry point runs inside a Scope: it resolves the context (the handle's, or the thread's), takes its
+// lock, makes its device current for the calling thread and publishes it as t_ctx for the helpers below.
+struct Scope
+{
+  bwtm_context* prev;
+  bwtm_context* ctx = nullptr;
+  int rc = BWTM_OK;
+  explicit Scope(bwtm_context* wanted)
+  {
+    prev = t_ctx;
+    if(!wanted) { wanted = t_bound; }
+    if(!wanted) { rc = default_context(0, &wanted); if(rc != BWTM_OK) { return; } }
+    ctx = wanted;
+    ctx->mu.lock();
+    hipError_t e = hipSetDevice(ctx->device);
+    if(e != hipSuccess) { rc = fail(BWTM_ENODEV, "hipSetDevice(%d) failed: %s", ctx->device, hipGetErrorString(e)); }
+    t_ctx = ctx;
+  }
+  ~Scope()
+  {
+    if(ctx) { t_ctx = prev; ctx->mu.unlock(); }
+  }
+  Scope(const Scope&) = delete; Scope& operator=(const Scope&) = delete;
+};
+
+#define ENTER(wanted) Scope scope_(wanted); if(scope_.rc != BWTM_OK) { return scope_.rc; }
+
+//------------------------------------------------------------------------------
+// Profiling: every launch bracketed by events on the compute stream (only when enabled).
+
+void profile_begin(const char* name)
+{
+  if(!CTX.profiling) { return; }
+  bwtm_context::Pending p; p.name = name;
+  (void)hipEventCreate(&p.start); (void)hipEventCreate(&p.stop);
+  (void)hipEventRecord(p.start, CTX.stream);
+  CTX.pending.push_back(p);
+}
+
+void profile_end()
+{
+  if(!CTX.profiling) { return; }
+  (void)hipEventRecord(CTX.pending.back().stop, CTX.stream);
+}
+
+void profile_collect()
+{
+  if(CTX.pending.empty()) { return; }
+  (void)hipStreamSynchronize(CTX.stream);
+  for(auto& p : CTX.pending)
+  {
+    float ms = 0; (void)hipEventElapsedTime(&ms, p.start, p.stop);
+    auto it = CTX.totals.find(p.name);
+    if(it == CTX.totals.end()) { CTX.totals[p.name] = std::make_pair((double)ms, (uint64_t)1); CTX.order.push_back(p.name); }
+    else { it->second.first += ms; it->second.second += 1; }
+    (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop);
+  }
+  CTX.pending.clear();
+}
+
+#define LAUNCH_CFG(name, kernel, grid, block, lds, ...) do { \
+  profile_begin(name); \
+  hipLaunchKernelGGL(kernel, grid, dim3((unsigned)(block)), (unsigned)(lds), CTX.stream, __VA_ARGS__); \
+  profile_end(); \
+  hipError_t le_ = hipGetLastError(); \
+  if(le_ != hipSuccess) { return fail(BWTM_ENODEV, "launch of %s failed: %s", name, hipGetErrorString(le_)); } } while(0)
+
+#define LAUNCH(name, kernel, grid, block, ...) LAUNCH_CFG(name, kernel, dim3((unsigned)(grid)), block, 0, __VA_ARGS__)
+#define LAUNCH_LDS(name, kernel, grid, block, lds, ...) LAUNCH_CFG(name, kernel, dim3((unsigned)(grid)), block, lds, __VA_ARGS__)
+#define LAUNCH2D(name, kernel, gridx, gridy, block, ...) LAUNCH_CFG(name, kernel, dim3((unsigned)(gridx), (unsigned)(gridy)), block, 0, __VA_ARGS__)
+
+//------------------------------------------------------------------------------
+// Pool.
+
+u64 pool_round(u64 n)
+{
+  if(n < 256) { n = 256; }
+  u64 g = (n >= (64ull << 20) ? (2ull << 20) : (n >= (1ull << 20) ? (64ull << 10) : 256ull));
+  return (n + g - 1) / g * g;
+}
+
+void pool_trim(bwtm_context* c)
+{
+  if(c->stream) { (void)hipStreamSynchronize(c->stream); }
+  for(auto& kv : c->free_blocks) { (void)hipFree(kv.second); c->held_bytes -= kv.first; }
+  c->free_blocks.clear(); c->cached_bytes = 0;
+}
+
+hipError_t pool_get(bwtm_context* c, u64 n, void** p, u64* actual)
+{
+  n = pool_round(n);
+  auto it = c->free_blocks.lower_bound(n);
+  if(it != c->free_blocks.end() && it->first <= n + n / 8)
+  {
+    *p = it->second; *actual = it->first; c->cached_bytes -= it->first; c->free_blocks.erase(it);
+    return hipSuccess;
+  }
+  hipError_t e = hipMalloc(p, n);
+  if(e != hipSuccess) { (void)hipGetLastError(); pool_trim(c); e = hipMalloc(p, n); }
+  if(e == hipSuccess) { c->held_bytes += n; if(c->held_bytes > c->peak_bytes) { c->peak_bytes = c->held_bytes; } }
+  *actual = n;
+  return e;
+}
+
+void pool_put(bwtm_context* c, void* p, u64 n) { c->free_blocks.insert(std::make_pair(n, p)); c->cached_bytes += n; }
+
+// RAII device buffer (pooled).  Released into the pool of the context it came from; the release must happen
+// inside a Scope of that context (handles enter their own context before they are destroyed).
+struct DevBuf
+{
+  void* p = nullptr; u64 bytes = 0; bwtm_context* owner = nullptr;
+  DevBuf() {}
+  DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() { if(p) { pool_put(owner, p, bytes); p = nullptr; bytes = 0; owner = nullptr; } }
+  int alloc(u64 n, bool zero = false)
+  {
+    release();
+    if(n == 0) { n = 8; }
+    hipError_t e = pool_get(t_ctx, n, &p, &bytes);
+    if(e != hipSuccess) { p = nullptr; bytes = 0; return fail(BWTM_ENOMEM, "hipMalloc(%llu bytes) failed: %s", (unsigned long long)n, hipGetErrorString(e)); }
+    owner = t_ctx;
+    if(zero) { e = hipMemsetAsync(p, 0, n, CTX.stream); if(e != hipSuccess) { return fail(BWTM_ENODEV, "hipMemsetAsync failed: %s", hipGetErrorString(e)); } }
+    return BWTM_OK;
+  }
+  template<class T> T* as() const { return (T*)p; }
+  void swap(DevBuf& o) { std::swap(p, o.p); std::swap(bytes, o.bytes); std::swap(owner, o.owner); }
+};
+
+// Small results the host needs: copied into the context's page-locked scratch (slot..slot+count-1), valid after the next
+// synchronisation of the compute stream.
+int fetch_u64(const u64* device_src, u32 slot, u32 count = 1)
+{
+  HIP_TRY(hipMemcpyAsync(CTX.host_scratch + slot, device_src, count * sizeof(u64), hipMemcpyDeviceToHost, CTX.stream));
+  return BWTM_OK;
+}
+
+// Joins the copy stream into the compute stream (work queued later on the compute stream, including the reuse of
+// pooled buffers, waits for the copies queued so far).
+int join_copy_stream()
+{
+  hipEvent_t ev;
+  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, CTX.copy_stream);
+  if(e == hipSuccess) { e = hipStreamWaitEvent(CTX.stream, ev, 0); }
+  (void)hipEventDestroy(ev);
+  if(e != hipSuccess) { return fail(BWTM_ENODEV, "joining the copy stream failed: %s", hipGetErrorString(e)); }
+  return BWTM_OK;
+}
+
+// The copy stream waits for everything queued so far on the compute stream.
+int fork_copy_stream()
+{
+  hipEvent_t ev;
+  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, CTX.stream);
+  if(e == hipSuccess) { e = hipStreamWaitEvent(CTX.copy_stream, ev, 0); }
+  (void)hipEventDestroy(ev);
+  if(e != hipSuccess) { return fail(BWTM_ENODEV, "forking the copy stream failed: %s", hipGetErrorString(e)); }
+  return BWTM_OK;
+}
+
+//------------------------------------------------------------------------------
+// Exclusive scan of `narrays` arrays of n u64 items each, `stride` items apart (in place allowed).
+// OP 0 = sum, 1 = max.
+
+template<int OP>
+int device_scan_multi(const u64* in, u64* out, u64 n, u64 narrays, u64 stride)
+{
+  if(n == 0 || narrays == 0) { return BWTM_OK; }
+  u64 tiles = div_up(n, SCAN_TILE);
+  if(tiles == 1)
+  {
+    LAUNCH2D("scan_apply", k_scan_apply<OP>, 1, narrays, BLOCK_THREADS, in, out, (const u64*)nullptr, n, stride, (u64)0);
+    return BWTM_OK;
+  }
+  DevBuf partial; TRY(partial.alloc(tiles * narrays * sizeof(u64)));
+  LAUNCH2D("scan_reduce", k_scan_reduce<OP>, tiles, narrays, BLOCK_THREADS, in, partial.as<u64>(), n, stride, tiles);
+  TRY(device_scan_multi<OP>(partial.as<u64>(), partial.as<u64>(), tiles, narrays, tiles));
+  LAUNCH2D("scan_apply", k_scan_apply<OP>, tiles, narrays, BLOCK_THREADS, in, out, (const u64*)partial.as<u64>(), n, stride, tiles);
+  return BWTM_OK;                                   // `partial` returns to the pool (stream ordered)
+}
+
+template<int OP>
+int device_scan(const u64* in, u64* out, u64 n) { return device_scan_multi<OP>(in, out, n, 1, 0); }
+
+} // namespace
+
+//------------------------------------------------------------------------------
+// Library entry points.
+
+extern "C" int bwtm_init(int device)
+{
+  bwtm_context* c = nullptr;
+  TRY(default_context(device, &c));
+  t_bound = c;
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_context_create(int device, bwtm_context** out)
+{
+  if(!out) { return fail(BWTM_EINVAL, "bwtm_context_create: null argument"); }
+  bwtm_context* c = new bwtm_context();
+  int rc = context_setup(c, device);
+  if(rc != BWTM_OK) { context_teardown(c); delete c; return rc; }
+  *out = c;
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_context_make_current(bwtm_context* context)
+{
+  t_bound = context;
+  return BWTM_OK;
+}
+
+extern "C" void bwtm_context_destroy(bwtm_context* context)
+{
+  if(!context || context->is_default) { return; }
+  if(t_bound == context) { t_bound = nullptr; }
+  context_teardown(context);
+  delete context;
+}
+
+extern "C" const char* bwtm_last_error(void) { return g_error.c_str(); }
+
+extern "C" int bwtm_tune(const char* key, long long value)
+{
+  if(!key) { return fail(BWTM_EINVAL, "bwtm_tune: null key"); }
+  std::string k(key);
+  if(k == "search_algo") { g_tune.search_algo = value; }
+  else if(k == "frontier_unfused") { g_tune.frontier_unfused = value; }
+  else if(k == "l1_cap") { g_tune.l1_cap = value; }
+  else if(k == "emit_path") { g_tune.emit_path = value; }
+  else if(k == "round_emits") { g_tune.round_emits = (value > 0 ? value : 1); }
+  else if(k == "emit_budget") { g_tune.emit_budget = (value > 0 ? value : (16ll << 30)); }
+  else if(k == "frontier_epoch") { g_tune.frontier_epoch = (value > 0 ? value : 512); }
+  else if(k == "eager_cum_budget") { g_tune.eager_cum_budget = (value > 0 ? value : (16ll << 30)); }
+  else if(k == "upload_chunk") { g_tune.upload_chunk = (value > 0 ? value : (64ll << 20)); }
+  else if(k == "download_chunk") { g_tune.download_chunk = (value > 0 ? value : (128ll << 20)); }
+#ifdef BWTM_DIAGNOSTICS
+  else if(k == "walk_emit") { g_tune.walk_emit = value; }
+  else if(k == "walk_blocks") { g_tune.walk_blocks = value; }
+  else if(k == "walk_kernel") { g_tune.walk_kernel = value; }
+  else if(k == "walk_ablate") { g_tune.walk_ablate = value; }
+  else if(k == "walk_variant") { g_tune.walk_variant = value; }
+  else if(k == "scatter_kernel") { g_tune.scatter_kernel = value; }
+#endif
+  else { return fail(BWTM_EINVAL, "bwtm_tune: unknown key %s", key); }
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_trim(void)
+{
+  ENTER(nullptr);
+  pool_trim(t_ctx);
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_synchronize(void)
+{
+  ENTER(nullptr);
+  HIP_TRY(hipStreamSynchronize(CTX.copy_stream));
+  HIP_TRY(hipStreamSynchronize(CTX.stream));
+  return BWTM_OK;
+}
+
+extern "C" uint64_t bwtm_device_bytes_peak(int reset)
+{
+  Scope scope_(nullptr);
+  if(scope_.rc != BWTM_OK) { return 0; }
+  u64 peak = CTX.peak_bytes;
+  if(reset) { CTX.peak_bytes = CTX.held_bytes; }
+  return peak;
+}
+
+extern "C" int bwtm_host_alloc(uint64_t nbytes, void** out)
+{
+  ENTER(nullptr);
+  if(!out) { return fail(BWTM_EINVAL, "bwtm_host_alloc: null argument"); }
+  hipError_t e = hipHostMalloc(out, nbytes > 0 ? nbytes : 8, hipHostMallocDefault);
+  if(e != hipSuccess) { (void)hipGetLastError(); return fail(BWTM_ENOMEM, "hipHostMalloc(%llu bytes) failed: %s", (unsigned long long)nbytes, hipGetErrorString(e)); }
+  return BWTM_OK;
+}
+
+extern "C" void bwtm_host_free(void* p)
+{
+  if(p) { (void)hipHostFree(p); }
+}
+
+//------------------------------------------------------------------------------
+// Measurement.
+
+extern "C" int bwtm_profile_enable(int on)
+{
+  ENTER(nullptr);
+  profile_collect();
+  CTX.profiling = (on != 0);
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_profile_reset(void)
+{
+  ENTER(nullptr);
+  profile_collect();
+  CTX.totals.clear(); CTX.order.clear();
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_profile_read(const char** names, double* total_ms, uint64_t* launches, int capacity)
+{
+  Scope scope_(nullptr);
+  if(scope_.rc != BWTM_OK) { return 0; }
+  profile_collect();
+  int k = 0;
+  for(const char* name : CTX.order)
+  {
+    if(k < capacity)
+    {
+      auto& t = CTX.totals[name];
+      names[k] = name; total_ms[k] = t.first; launches[k] = t.second;
+    }
+    k++;
+  }
+  return k;
+}

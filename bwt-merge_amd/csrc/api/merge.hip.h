@@ -1,0 +1,229 @@
+/*
+  api/merge.hip.h -- interleave (BWT::BWT(a, b, ra), bwt.cpp:286-314) and the whole path
+  (FMI::FMI(a, b, parameters), fmi.cpp:336-369): device-resident, consuming, and host-to-host forms.
+  Part of bwtm_api.hip.
+*/
+#pragma once
+
+namespace
+{
+
+int interleave_impl(const bwtm_index* a, const bwtm_index* b, bwtm_ra* ra, bwtm_index* x)
+{
+  x->n = ra->n_out; x->m = a->m + b->m;                           // bwt.cpp:305-306
+  for(int c = 0; c < 8; c++) { x->C[c] = a->C[c] + b->C[c]; }     // fmi.cpp:367-368
+  x->nrecs = ra->nrecs_out; x->nsup = num_supers(x->n);
+  TRY(x->recs.alloc(x->nrecs * 64));
+  TRY(x->sup.alloc(x->nsup * SUP_STRIDE * sizeof(u64)));
+  LAUNCH("interleave_sup", k_interleave_sup, div_up(x->nsup, BLOCK_THREADS), BLOCK_THREADS, a->view(), b->view(),
+    ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), x->n, x->sup.as<u64>(), x->nsup);
+  LAUNCH("interleave", k_interleave, div_up(ra->nchunks * WAVE, BLOCK_THREADS), BLOCK_THREADS, a->view(), b->view(),
+    ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), ra->nchunks, x->sup.as<const u64>(), x->recs.as<uint4>(), x->nrecs);
+  return BWTM_OK;
+}
+
+int check_interleave_args(const bwtm_index* a, const bwtm_index* b, const bwtm_ra* ra)
+{
+  if(!ra->finalized) { return fail(BWTM_EINVAL, "bwtm_interleave: rank array not finalized"); }
+  if(ra->na != a->n || ra->nb != b->n) { return fail(BWTM_EINVAL, "bwtm_interleave: rank array was created for other inputs"); }
+  if(ra->values != b->n) { return fail(BWTM_EINVAL, "bwtm_interleave: rank array holds %llu values, expected %llu", (unsigned long long)ra->values, (unsigned long long)b->n); }
+  return BWTM_OK;
+}
+
+// A rank array for a and b inside the current scope (no nested entry point).
+int ra_make(const bwtm_index* a, const bwtm_index* b, bwtm_ra** out)
+{
+  bwtm_ra* ra = new bwtm_ra();
+  ra->ctx = t_ctx;
+  ra->na = a->n; ra->nb = b->n; ra->n_out = a->n + b->n;
+  ra->nrecs_out = num_records(ra->n_out);
+  ra->nchunks = div_up(ra->nrecs_out, 64);
+  int rc = ra->owned_bits.alloc(ra->nchunks * CHUNK_WORDS * sizeof(u64), true);
+  ra->bits_ptr = ra->owned_bits.p;
+  if(rc == BWTM_OK) { rc = ra->chunk_base.alloc((ra->nchunks + 1) * sizeof(u64), true); }
+  if(rc != BWTM_OK) { delete ra; return rc; }
+  *out = ra;
+  return BWTM_OK;
+}
+
+// search + finalize + interleave; with `consume` the inputs are deleted as soon as the interleave is queued (their
+// buffers return to the pool in stream order, so the encoder that follows can reuse the memory).
+int merge_records(bwtm_index*& a, bwtm_index*& b, bool consume, bwtm_index** out)
+{
+  bwtm_ra* ra = nullptr;
+  TRY(ra_make(a, b, &ra));
+  int rc = BWTM_OK;
+  if(b->m > 0) { rc = bwtm_search(a, b, 0, b->m - 1, ra); }
+  if(rc == BWTM_OK) { rc = ra_finalize(ra); }
+  if(rc == BWTM_OK) { rc = check_interleave_args(a, b, ra); }
+  bwtm_index* x = nullptr;
+  if(rc == BWTM_OK)
+  {
+    x = new bwtm_index(); x->ctx = t_ctx;
+    rc = interleave_impl(a, b, ra, x);
+  }
+  delete ra;
+  if(consume) { delete a; delete b; a = nullptr; b = nullptr; }
+  if(rc != BWTM_OK) { delete x; return rc; }
+  *out = x;
+  return BWTM_OK;
+}
+
+double now_ms()
+{
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Native bytes of a host input -> device index without its native form, queued without a synchronisation:
+// chunked H2D + first decode pass, scans, transcode.  The header is validated later (upload_validate).
+int host_input_queue(const bwtm_host_input* in, u32 slot, bwtm_index* x)
+{
+  x->ctx = t_ctx; x->nbytes = in->nbytes; x->n = in->bases; x->m = in->sequences;
+  TRY(alloc_native(x->data, in->nbytes));
+  TRY(upload_queue(x, (in->nbytes > 0 ? in->data : nullptr)));
+  TRY(upload_scan(x, slot));
+  return BWTM_OK;
+}
+
+int merge_host_impl(bwtm_index* a_dev, const bwtm_host_input* a_host, const bwtm_host_input* b_host, bwtm_alloc_fn alloc, void* user,
+  int want_samples, bwtm_host_output* out, bwtm_index** keep)
+{
+  const double t0 = now_ms();
+  bwtm_index* a = a_dev;
+  bwtm_index* b = new bwtm_index();
+  bwtm_index* x = nullptr;
+  auto body = [&]() -> int
+  {
+    // b first: its scans and transcode run on the compute stream while a's bytes are still arriving on the copy stream.
+    TRY(host_input_queue(b_host, 8, b));
+    TRY(transcode(b));
+    if(a_host)
+    {
+      a = new bwtm_index();
+      TRY(host_input_queue(a_host, 16, a));
+    }
+    HIP_TRY(hipStreamSynchronize(CTX.copy_stream));
+    HIP_TRY(hipStreamSynchronize(CTX.stream));
+    TRY(upload_validate(b, b_host->sequences, b_host->bases, b_host->C, 8));
+    if(a_host)
+    {
+      TRY(upload_validate(a, a_host->sequences, a_host->bases, a_host->C, 16));
+      TRY(transcode(a));
+    }
+    if(a->ctx != t_ctx) { return fail(BWTM_EINVAL, "bwtm_merge_host_chained: the index lives in another context"); }
+    // the native bytes of the inputs are not needed any more (BlockArray::clearUntil, bwt.cpp:224-225)
+    TRY(bwtm_index_drop_native(a)); TRY(bwtm_index_drop_native(b));
+    const double t1 = now_ms();
+    out->ms_upload = t1 - t0;
+
+    TRY(merge_records(a, b, true, &x));                           // a and b are gone after this
+    const double t2 = now_ms();
+    out->ms_search = t2 - t1;
+
+    out->sequences = x->m; out->bases = x->n;
+    for(int c = 0; c <= 6; c++) { out->C[c] = x->C[c]; }
+    out->data = nullptr; out->nbytes = 0; out->blocks = 0; out->block_end = nullptr; out->cum = nullptr;
+    std::unique_ptr<EncodePlan> plan_holder(new EncodePlan());
+    EncodePlan& plan = *plan_holder;
+    if(x->n > 0) { TRY(encode_size(x, plan)); }
+    const double t3 = now_ms();
+    out->ms_interleave = t3 - t2;
+    const u64 total = plan.total;
+    out->nbytes = total; out->blocks = div_up(total, RLE_BLOCK);
+    out->data = (u8*)alloc(user, BWTM_BUF_DATA, total);
+    if(!out->data && total > 0) { return fail(BWTM_ENOMEM, "bwtm_merge_host: the caller's allocator returned no buffer for %llu bytes", (unsigned long long)total); }
+    if(x->n > 0) { TRY(encode_emit(x, plan, out->data)); }
+    else { TRY(encode_blocking(x)); }
+    plan_holder.reset();                                           // the size tables return to the pool
+    if(want_samples)
+    {
+      out->block_end = (u64*)alloc(user, BWTM_BUF_BLOCK_END, out->blocks * sizeof(u64));
+      out->cum = (u64*)alloc(user, BWTM_BUF_CUM, 6 * (out->blocks + 1) * sizeof(u64));
+      if((!out->block_end && out->blocks > 0) || !out->cum) { return fail(BWTM_ENOMEM, "bwtm_merge_host: the caller's allocator returned no buffer for the samples"); }
+    }
+    HIP_TRY(hipStreamSynchronize(CTX.copy_stream));
+    HIP_TRY(hipStreamSynchronize(CTX.stream));
+    const double t4 = now_ms();
+    out->ms_encode_download = t4 - t3;
+    if(want_samples) { TRY(download_samples(x, out->block_end, out->cum)); }
+    const double t5 = now_ms();
+    out->ms_samples = t5 - t4;
+    out->ms_total = t5 - t0;
+    return BWTM_OK;
+  };
+  int rc = body();
+  if(rc != BWTM_OK)
+  {
+    (void)hipStreamSynchronize(CTX.copy_stream); (void)hipStreamSynchronize(CTX.stream);   // nothing may touch the caller's buffers after the return
+    delete a; delete b; delete x;
+    return rc;
+  }
+  if(keep) { rc = bwtm_index_drop_native(x); *keep = x; }
+  else { delete x; }
+  return rc;
+}
+
+} // namespace
+
+//------------------------------------------------------------------------------
+// C ABI.
+
+extern "C" int bwtm_interleave(const bwtm_index* a, const bwtm_index* b, bwtm_ra* ra, bwtm_index** out)
+{
+  if(!a || !b || !ra || !out) { return fail(BWTM_EINVAL, "bwtm_interleave: null argument"); }
+  if(a->ctx != ra->ctx || b->ctx != ra->ctx) { return fail(BWTM_EINVAL, "bwtm_interleave: handles of different contexts"); }
+  ENTER(ra->ctx);
+  TRY(check_interleave_args(a, b, ra));
+  bwtm_index* x = new bwtm_index();
+  x->ctx = t_ctx;
+  int rc = interleave_impl(a, b, ra, x);
+  if(rc != BWTM_OK) { delete x; return rc; }
+  *out = x;
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_merge(const bwtm_index* a, const bwtm_index* b, bwtm_index** out)
+{
+  if(!a || !b || !out) { return fail(BWTM_EINVAL, "bwtm_merge: null argument"); }
+  if(a->ctx != b->ctx) { return fail(BWTM_EINVAL, "bwtm_merge: the two indexes live in different contexts"); }
+  ENTER(a->ctx);
+  bwtm_index* aa = const_cast<bwtm_index*>(a); bwtm_index* bb = const_cast<bwtm_index*>(b);
+  bwtm_index* x = nullptr;
+  TRY(merge_records(aa, bb, false, &x));
+  int rc = encode_blocking(x);
+  if(rc != BWTM_OK) { delete x; return rc; }
+  *out = x;
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_merge_consume(bwtm_index* a, bwtm_index* b, bwtm_index** out)
+{
+  if(!a || !b || !out) { bwtm_index_free(a); bwtm_index_free(b); return fail(BWTM_EINVAL, "bwtm_merge_consume: null argument"); }
+  if(a->ctx != b->ctx) { bwtm_index_free(a); bwtm_index_free(b); return fail(BWTM_EINVAL, "bwtm_merge_consume: the two indexes live in different contexts"); }
+  ENTER(a->ctx);
+  int rc = bwtm_index_drop_native(a);
+  if(rc == BWTM_OK) { rc = bwtm_index_drop_native(b); }
+  bwtm_index* x = nullptr;
+  if(rc == BWTM_OK) { rc = merge_records(a, b, true, &x); }
+  delete a; delete b;                                              // no-ops when merge_records consumed them
+  if(rc == BWTM_OK) { rc = encode_blocking(x); }
+  if(rc != BWTM_OK) { delete x; return rc; }
+  *out = x;
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_merge_host(const bwtm_host_input* a, const bwtm_host_input* b, bwtm_alloc_fn alloc, void* user,
+  int want_samples, bwtm_host_output* out, bwtm_index** keep)
+{
+  if(!a || !b || !alloc || !out || (a->nbytes > 0 && !a->data) || (b->nbytes > 0 && !b->data)) { return fail(BWTM_EINVAL, "bwtm_merge_host: null argument"); }
+  ENTER(nullptr);
+  return merge_host_impl(nullptr, a, b, alloc, user, want_samples, out, keep);
+}
+
+extern "C" int bwtm_merge_host_chained(bwtm_index* a, const bwtm_host_input* b, bwtm_alloc_fn alloc, void* user,
+  int want_samples, bwtm_host_output* out, bwtm_index** keep)
+{
+  if(!a || !b || !alloc || !out || (b->nbytes > 0 && !b->data)) { bwtm_index_free(a); return fail(BWTM_EINVAL, "bwtm_merge_host_chained: null argument"); }
+  ENTER(a->ctx);
+  return merge_host_impl(a, nullptr, b, alloc, user, want_samples, out, keep);
+}

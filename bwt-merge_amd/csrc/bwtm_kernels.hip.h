@@ -12,8 +12,9 @@
     k_bound_suffix_min, k_tile_build_frontier
                        mergeRA / RLArray / RankArray: the sorted emits of every step -> bitvector tiles
                                                                     fmi.cpp:139-257, support.h:396-638
-    k_lf_walk*, k_part_*, k_tile_build
-                       the same two stages in per-chain form (fallback: long sequences, > 40-bit coordinates)
+    k_lf_walk_binned, k_lf_walk_quad, k_part_*, k_tile_build
+                       the same two stages in per-chain form (small shards, long sequences, > 40-bit coordinates)
+    kernels/diagnostics.hip.h (only with -DBWTM_DIAGNOSTICS): timing-only and A/B variants, not in the product
     k_chunk_popc       RA finalize (prefix counts of the interleaving bitvector)
     k_interleave_*     mergeBWT                                     bwt.cpp:215-282
     k_enc_*            RunBuffer + Run::write, block starts of BWT::build
@@ -48,6 +49,9 @@ struct IndexView
 #include "kernels/transcode.hip.h"
 #include "kernels/queries.hip.h"
 #include "kernels/search_walk.hip.h"
+#ifdef BWTM_DIAGNOSTICS
+#include "kernels/diagnostics.hip.h"
+#endif
 #include "kernels/search_frontier.hip.h"
 #include "kernels/interleave.hip.h"
 #include "kernels/encoder.hip.h"

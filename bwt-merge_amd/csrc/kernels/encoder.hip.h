@@ -237,12 +237,14 @@ __global__ void __launch_bounds__(WAVE) k_fold_seg(const u32* table, u64 nseg, c
   for(u64 s = s0; s < s1; s++) { seg_base[s] = off; off += table[s * 64 + (off & 63)]; }
 }
 
-__global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 nseg,
+// The launch covers the segments [seg_first, seg_end): the pipelined download copies the bytes of one range to the
+// host while the next range is written.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 seg_first, u64 seg_end,
   const u64* prevhead, const u64* seg_base, u8* out, u64* block_start)
 {
   __shared__ __attribute__((aligned(16))) u8 stage[BLOCK_THREADS / WAVE][4096 + 32];
-  u64 seg = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
-  if(seg >= nseg) { return; }
+  u64 seg = seg_first + (((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6);
+  if(seg >= seg_end) { return; }
   u64 first = seg * SEG_TILES;
   u32 carry = (first == 0 ? 0u : symbol_at(recs, (first << 6) - 1));
   u64 last = prevhead[seg];

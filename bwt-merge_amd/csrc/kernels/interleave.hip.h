@@ -35,6 +35,52 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_ra_extract(const u64* bits, c
   while(m1) { u32 t = (u32)__builtin_ctzll(m1); m1 &= m1 - 1; if(i < nb) { ra[i] = base + 64 + t - i; } i++; }
 }
 
+// The rank array as maximal (rank, count) runs, the form RankArray hands to mergeBWT (support.h:576-638,
+// bwt.cpp:194-213): equal ranks are consecutive 1 bits of the interleaving bitvector, so a run is a maximal
+// block of ones; its rank is the number of zeros before it and its count the number of ones up to the next run.
+// Pass 1 counts the run starts per chunk; after a scan pass 2 writes (rank, B offset) per run; counts = differences.
+__device__ inline u64 run_starts(const u64* bits, u64 w, u64 word)
+{
+  const u64 carry = (w == 0 ? 0ull : bits[w - 1] >> 63);
+  return word & ~((word << 1) | carry);
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_ra_run_count(const u64* bits, u64 nchunks, u64* cnt)
+{
+  u64 chunk = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
+  if(chunk >= nchunks) { return; }
+  const u64 w = chunk * CHUNK_WORDS + 2 * lane_id();
+  u64 v = (u64)__builtin_popcountll(run_starts(bits, w, bits[w])) + (u64)__builtin_popcountll(run_starts(bits, w + 1, bits[w + 1]));
+  v = wave_sum(v);
+  if(lane_id() == 0) { cnt[chunk] = v; }
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_ra_run_write(const u64* bits, const u64* chunk_base, const u64* run_base, u64 nchunks,
+  u64* ranks, u64* boff, u64 capacity)
+{
+  u64 chunk = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
+  if(chunk >= nchunks) { return; }
+  const u64 w = chunk * CHUNK_WORDS + 2 * lane_id();
+  const u64 m0 = bits[w], m1 = bits[w + 1];
+  u64 s0 = run_starts(bits, w, m0), s1 = run_starts(bits, w + 1, m1);
+  const u64 ones = (u64)__builtin_popcountll(m0) + (u64)__builtin_popcountll(m1);
+  const u64 starts = (u64)__builtin_popcountll(s0) + (u64)__builtin_popcountll(s1);
+  const u64 ones_incl = wave_incl_sum(ones), starts_incl = wave_incl_sum(starts);
+  u64 b = chunk_base[chunk] + ones_incl - ones;            // ones before word w
+  u64 k = run_base[chunk] + starts_incl - starts;          // runs before word w
+  while(s0) { u32 t = (u32)__builtin_ctzll(s0); s0 &= s0 - 1; u64 before = b + (u64)__builtin_popcountll(m0 & ((1ull << t) - 1)); if(k < capacity) { ranks[k] = (w << 6) + t - before; boff[k] = before; } k++; }
+  b += (u64)__builtin_popcountll(m0);
+  while(s1) { u32 t = (u32)__builtin_ctzll(s1); s1 &= s1 - 1; u64 before = b + (u64)__builtin_popcountll(m1 & ((1ull << t) - 1)); if(k < capacity) { ranks[k] = ((w + 1) << 6) + t - before; boff[k] = before; } k++; }
+}
+
+// counts[k] = boff[k + 1] - boff[k] for k < count (boff has nboff entries; the run after the last one starts at nb).
+__global__ void __launch_bounds__(BLOCK_THREADS) k_ra_run_diff(const u64* boff, u64 nboff, u64 count, u64 nb, u64* counts)
+{
+  u64 k = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(k >= count) { return; }
+  counts[k] = (k + 1 < nboff ? boff[k + 1] : nb) - boff[k];
+}
+
 //------------------------------------------------------------------------------
 // K3: interleave (mergeBWT, bwt.cpp:215-282).  Output position p takes the next symbol of B
 // when bit p of the interleaving bitvector is set and the next symbol of A otherwise, so

@@ -111,13 +111,14 @@ __device__ inline void for_each_run(const u32* row, u32 valid, FS&& on_short, FL
 
 // blen[b] = positions encoded by block b; gcount[c * gstride + g] = occurrences of c in group g.
 // flags bit 0: a block other than the last one encodes fewer than 64 positions.
-__global__ void __launch_bounds__(BLOCK_THREADS) k_block_len(const u8* data, u64 nbytes, u64 nblocks, u64 ngroups,
+// The launch covers the groups [group_first, group_end): the pipelined upload runs one launch per H2D chunk.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_block_len(const u8* data, u64 nbytes, u64 nblocks, u64 group_first, u64 group_end,
   u64* blen, u64* gcount, u64 gstride, u32* flags)
 {
   __shared__ u32 stage[BLOCK_THREADS / WAVE][STAGE_ROWS * STAGE_WORDS];
   const u32 lane = lane_id(), wave = threadIdx.x >> 6;
-  const u64 g = (u64)blockIdx.x * (BLOCK_THREADS / WAVE) + wave;
-  if(g >= ngroups) { return; }
+  const u64 g = group_first + (u64)blockIdx.x * (BLOCK_THREADS / WAVE) + wave;
+  if(g >= group_end) { return; }
   const u64 first = g * GROUP;
   const u32 nb = (nblocks > first ? (nblocks - first > (u64)GROUP ? (u32)GROUP : (u32)(nblocks - first)) : 0u);
   u32* rows = stage[wave];
@@ -157,10 +158,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_block_len(const u8* data, u64
 }
 
 // block_end[b] = block_start[b + 1] - 1 (the set bits of block_boundaries, bwt.cpp:496).
-__global__ void __launch_bounds__(BLOCK_THREADS) k_block_end(const u64* block_start, u64 nblocks, u64* block_end)
+__global__ void __launch_bounds__(BLOCK_THREADS) k_block_end(const u64* block_start, u64 first, u64 count, u64* block_end)
 {
   u64 b = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
-  if(b < nblocks) { block_end[b] = block_start[b + 1] - 1; }
+  if(b < count) { block_end[b] = block_start[first + b + 1] - 1; }
 }
 
 // Largest b in [0, nblocks) with block_start[b] <= p (p < n).
@@ -402,13 +403,13 @@ __global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64
   }
 }
 
-// cum[c * stride + b] = occurrences of c before the start of block b, b in [0, nblocks]
-// (CumulativeArray::sum(b) of samples[c], support.h:338-343), from the rank structure.
-__global__ void __launch_bounds__(BLOCK_THREADS) k_block_cum(IndexView x, const u64* block_start, u64 count, u64* cum, u64 stride)
+// cum[c * stride + b] = occurrences of c before the start of block first + b, b in [0, count)
+// (CumulativeArray::sum(first + b) of samples[c], support.h:338-343), from the rank structure.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_block_cum(IndexView x, const u64* block_start, u64 first, u64 count, u64* cum, u64 stride)
 {
   u64 b = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
   if(b >= count) { return; }
-  u64 p = block_start[b];
+  u64 p = block_start[first + b];
   u64 r[6]; index_ranks(x, p, r);
   cum[0 * stride + b] = p - (r[1] + r[2] + r[3] + r[4] + r[5]);
   cum[1 * stride + b] = r[1]; cum[2 * stride + b] = r[2]; cum[3 * stride + b] = r[3]; cum[4 * stride + b] = r[4]; cum[5 * stride + b] = r[5];

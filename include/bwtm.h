@@ -14,7 +14,11 @@
       bwtm_last_error() returns a message for the calling thread's last failure.
       (The reference prints to std::cerr and calls std::exit(EXIT_FAILURE); the facade and
       the CLI convert the status codes back into that behaviour.)
-    * Calls are blocking and not re-entrant per handle; one host thread per GPU.
+    * Calls are blocking and not re-entrant per handle.  All device state lives in a CONTEXT (one HIP
+      device, the library's streams, its memory pool); a host thread per GPU binds its own context
+      (bwtm_init / bwtm_context_make_current) and handles remember the context they were created in, so
+      a C++ host can drive several GPUs from several threads of one process (ParallelLoop's workers,
+      fmi.cpp:351-358, become one thread per GPU).  Calls on the same context are serialized.
     * Device buffers are owned by the library behind opaque handles; host output buffers
       are owned by the caller (sizes are queried first).
     * All integers are unsigned 64-bit like the reference's size_type (utils.h:44).
@@ -40,21 +44,36 @@ enum
   BWTM_EALPHABET = 4            /* fmi.cpp:338-342: cannot merge BWTs with different alphabets */
 };
 
+typedef struct bwtm_context bwtm_context; /* one HIP device + the library's streams and memory pool */
 typedef struct bwtm_index bwtm_index;   /* device-resident FM-index: replaces a loaded FMI (fmi.h:225-226) */
 typedef struct bwtm_ra    bwtm_ra;      /* device-resident rank array: replaces RankArray (support.h:576-638) */
 
 /* --- library ------------------------------------------------------------------------ */
 
-/* Selects the HIP device for the calling process and creates the library's stream. */
+/* Binds the calling thread to the process-wide default context of HIP device `device` (created on
+   first use).  Threads that never call it use device 0. */
 int bwtm_init(int device);
+/* Additional contexts (e.g. two independent pipelines on one GPU, or explicit per-thread ownership).
+   A context may be current in one thread at a time; destroying it requires that its handles are gone. */
+int bwtm_context_create(int device, bwtm_context** out);
+int bwtm_context_make_current(bwtm_context* context);      /* NULL: back to the default context of device 0 */
+void bwtm_context_destroy(bwtm_context* context);
 const char* bwtm_last_error(void);
-/* Diagnostic knobs for measurements and tests; the defaults are what a caller wants. */
+/* Knobs for tests and measurements; the defaults are what a caller wants.
+   Keys that select timing-only kernel variants exist only in builds with -DBWTM_DIAGNOSTICS. */
 int bwtm_tune(const char* key, long long value);
-/* Returns the library's cached device memory to the driver (device buffers released by
-   handles are kept in a pool for reuse). */
+/* Returns the cached device memory of the calling thread's context to the driver (device buffers
+   released by handles are kept in a pool for reuse). */
 int bwtm_trim(void);
-/* Blocks until all work queued by the library has finished. */
+/* Blocks until all work queued in the calling thread's context has finished. */
 int bwtm_synchronize(void);
+/* Peak number of bytes of device memory the context has held from the driver since the last call with reset != 0. */
+uint64_t bwtm_device_bytes_peak(int reset);
+
+/* Page-locked host memory: transfers from / to it run at PCIe speed and overlap with kernels
+   (the BlockArray of the facade, support.h:90-150, allocates its bytes here). */
+int bwtm_host_alloc(uint64_t nbytes, void** out);
+void bwtm_host_free(void* p);
 
 /* --- index: BWT::load + BWT::build (bwt.cpp:132-148, 476-512) on the device ------------ */
 
@@ -64,6 +83,9 @@ int bwtm_synchronize(void);
    support.cpp:84-91). */
 int bwtm_index_upload(const uint8_t* data, uint64_t nbytes, uint64_t sequences, uint64_t bases,
                       const uint64_t C[BWTM_SIGMA + 1], bwtm_index** out);
+/* The upload is chunked: the H2D copy of chunk k + 1 runs on the context's copy stream while the first
+   decode pass of chunk k runs on its compute stream.  `C`, when given, must agree with the symbol
+   counts of the stream (BWTM_EINVAL otherwise). */
 /* Same, from a device buffer that already holds the native bytes (the bytes are copied). */
 int bwtm_index_from_device(const void* device_data, uint64_t nbytes, uint64_t sequences, uint64_t bases,
                            const uint64_t C[BWTM_SIGMA + 1], bwtm_index** out);
@@ -141,6 +163,10 @@ uint64_t bwtm_ra_values(const bwtm_ra* ra);   /* number of set bits after finali
 int bwtm_ra_download(bwtm_ra* ra, uint64_t* out, uint64_t capacity);
 /* The raw bitvector words. */
 int bwtm_ra_download_bits(bwtm_ra* ra, uint64_t* out_words, uint64_t capacity_words);
+/* The rank array in the reference's own form: maximal (rank, count) runs in rank order, what RankArray
+   iterates over (support.h:576-638, bwt.cpp:194-213).  *nruns receives the number of runs; up to
+   `capacity` of them are written (call with capacity 0 to size the buffers). */
+int bwtm_ra_download_runs(bwtm_ra* ra, uint64_t* ranks, uint64_t* counts, uint64_t capacity, uint64_t* nruns);
 
 /* --- interleave: BWT::BWT(a, b, ra) (bwt.cpp:286-314) ------------------------------------ */
 
@@ -153,10 +179,44 @@ int bwtm_interleave(const bwtm_index* a, const bwtm_index* b, bwtm_ra* ra, bwtm_
 
 /* search over all sequences of b + finalize + interleave + encode + samples. */
 int bwtm_merge(const bwtm_index* a, const bwtm_index* b, bwtm_index** out);
+/* The same with the reference's ownership: "merges a and b, destroying them" (fmi.h:107-109).  Both
+   handles are freed by the call (also when it fails); their device memory is released as soon as the
+   stage that last needs it has run (native bytes after the transcode, records after the interleave:
+   the counterpart of BlockArray::clearUntil in mergeBWT, bwt.cpp:224-225). */
+int bwtm_merge_consume(bwtm_index* a, bwtm_index* b, bwtm_index** out);
+
+/* Host-resident inputs -> host-resident result in one call: what merge() in bwt_merge.cpp:287-299 times.
+   The two uploads, the device work and the download are pipelined on the context's copy and compute
+   streams (H2D of chunk k + 1 under the decode of chunk k, transcode of b under the H2D of a, D2H of
+   encoded ranges under the encoder).  Pass page-locked buffers (bwtm_host_alloc) for full PCIe speed. */
+typedef struct
+{
+  const uint8_t* data; uint64_t nbytes;      /* native run-length bytes (BWT::data) */
+  uint64_t sequences, bases;                 /* NativeHeader fields */
+  const uint64_t* C;                         /* Alphabet::C or NULL */
+} bwtm_host_input;
+/* The library asks the caller for the output buffers once their sizes are known. */
+enum { BWTM_BUF_DATA = 0, BWTM_BUF_BLOCK_END = 1, BWTM_BUF_CUM = 2 };
+typedef void* (*bwtm_alloc_fn)(void* user, int what, uint64_t nbytes);
+typedef struct
+{
+  uint8_t* data; uint64_t nbytes;            /* native bytes of the merged BWT */
+  uint64_t blocks, sequences, bases;
+  uint64_t C[BWTM_SIGMA + 1];
+  uint64_t* block_end;                       /* [blocks]            (NULL unless samples were requested) */
+  uint64_t* cum;                             /* [6][blocks + 1]     (NULL unless samples were requested) */
+  double ms_upload, ms_search, ms_interleave, ms_encode_download, ms_samples, ms_total;
+} bwtm_host_output;
+/* `keep` (optional) receives the merged device index (rank structure only) for a chained merge. */
+int bwtm_merge_host(const bwtm_host_input* a, const bwtm_host_input* b, bwtm_alloc_fn alloc, void* user,
+                    int want_samples, bwtm_host_output* out, bwtm_index** keep);
+/* Chained form: `a` is a device index kept from the previous merge (consumed), `b` comes from the host. */
+int bwtm_merge_host_chained(bwtm_index* a, const bwtm_host_input* b, bwtm_alloc_fn alloc, void* user,
+                            int want_samples, bwtm_host_output* out, bwtm_index** keep);
 
 /* --- measurement ----------------------------------------------------------------------------- */
 
-/* When enabled, every kernel launch is bracketed by HIP events on the library's stream. */
+/* When enabled, every kernel launch is bracketed by HIP events on the context's compute stream. */
 int bwtm_profile_enable(int on);
 int bwtm_profile_reset(void);
 /* Per-kernel totals since the last reset: returns the number of distinct kernels; fills up to

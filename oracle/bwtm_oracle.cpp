@@ -843,6 +843,27 @@ static void encode_symbols(const u8* symbols, u64 n, BWT& out)
   out.build();
 }
 
+// The same from (symbol, length) pairs: adjacent pairs of one symbol coalesce in the RunBuffer exactly like repeated
+// symbols do (utils.h:121-142), so strings of billions of positions can be stated in a few megabytes.
+static void encode_runs(const u64* symbols, const u64* lengths, u64 nruns, BWT& out)
+{
+  out.data.clear();
+  RunBuffer rb;
+  u64 counts[SIGMA] = {};
+  u64 n = 0;
+  for(u64 k = 0; k < nruns; k++)
+  {
+    if(lengths[k] == 0) { continue; }
+    n += lengths[k];
+    if(rb.add(symbols[k], lengths[k])) { run_write(out.data, rb.run.first, rb.run.second); counts[rb.run.first] += rb.run.second; }
+  }
+  rb.flush();
+  if(rb.run.second > 0) { run_write(out.data, rb.run.first, rb.run.second); counts[rb.run.first] += rb.run.second; }
+  out.sequences = counts[0];
+  out.bases = n;
+  out.build();
+}
+
 static void decode_symbols(const BWT& bwt, u8* symbols)
 {
   u64 rle_pos = 0, k = 0;
@@ -1015,6 +1036,14 @@ void* orc_fmi_from_symbols(const u8* symbols, u64 n)
 {
   FMI* f = new FMI();
   encode_symbols(symbols, n, f->bwt);
+  f->set_C_from_counts();
+  return f;
+}
+
+void* orc_fmi_from_runs(const u64* symbols, const u64* lengths, u64 nruns)
+{
+  FMI* f = new FMI();
+  encode_runs(symbols, lengths, nruns, f->bwt);
   f->set_C_from_counts();
   return f;
 }

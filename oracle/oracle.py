@@ -53,6 +53,7 @@ def lib():
         sig("orc_fmi_from_text", C.c_void_p, p_u8, u64)
         sig("orc_fmi_from_symbols", C.c_void_p, p_u8, u64)
         sig("orc_fmi_from_native", C.c_void_p, p_u8, u64, u64, u64)
+        sig("orc_fmi_from_runs", C.c_void_p, p_u64, p_u64, u64)
         sig("orc_fmi_clone", C.c_void_p, C.c_void_p)
         sig("orc_fmi_free", None, C.c_void_p)
         for n in ("bases", "sequences", "bytes", "blocks", "hash"):
@@ -181,6 +182,12 @@ class FMI:
         return FMI(lib().orc_fmi_from_symbols(sp, symbols.size))
 
     @staticmethod
+    def from_runs(symbols, lengths):
+        """From (symbol, length) pairs; adjacent pairs of one symbol coalesce (RunBuffer)."""
+        symbols, sp = _u64(symbols); lengths, lp = _u64(lengths)
+        return FMI(lib().orc_fmi_from_runs(sp, lp, symbols.size))
+
+    @staticmethod
     def from_native(data, sequences, bases):
         data, dp = _u8(data)
         return FMI(lib().orc_fmi_from_native(dp, data.size, sequences, bases))
@@ -263,14 +270,16 @@ def _params(threads=1, sequence_blocks=0, run_buffer_size=0, thread_buffer_size=
     return OrcParams(run_buffer_size, thread_buffer_size, merge_buffers, threads, sequence_blocks)
 
 
-def search(a, b, **kw):
-    """Rank array of inserting b into a, as maximal (rank, count) runs; also branch stats."""
-    cap = b.bases + 1
+def search(a, b, capacity=None, **kw):
+    """Rank array of inserting b into a, as maximal (rank, count) runs; also branch stats.
+    capacity: upper bound of the number of runs (default: one per position of b)."""
+    cap = (b.bases + 1 if capacity is None else capacity)
     r = np.zeros(cap, dtype=np.uint64); c = np.zeros(cap, dtype=np.uint64)
     stats = np.zeros(3, dtype=np.uint64)
     p = _params(**kw)
     n = lib().orc_search(a.h, b.h, C.byref(p), r.ctypes.data_as(p_u64), c.ctypes.data_as(p_u64), cap,
                          stats.ctypes.data_as(p_u64))
+    assert n <= cap, "orc_search: %d runs, capacity %d" % (n, cap)
     return r[:n].copy(), c[:n].copy(), stats
 
 
