@@ -6,16 +6,20 @@ the reference's native byte format: transcode of both inputs to the device rank 
 LF-walk search, rank-array finalize, interleave, canonical run encoder, sample build
 (the work between the timers of merge(), bwt_merge.cpp:287-299).  At N > 1 the sequences of
 input2 are sharded over the ranks and the rank-array bitvectors are combined with one RCCL
-all-reduce (sum == or: set bits are disjoint); the rest is replicated ("strong" scaling:
-the job is fixed as N grows).
+all-reduce (sum == or: set bits are disjoint); every rank then interleaves and encodes only its
+own range of the output (bwtm_slice_*), so the result is left sharded by byte range.
 
 Prints ONE JSON line on rank 0 (see the contract in the task description), including
+  value         the HBM-resident rate (inputs and result stay on the device)
+  host_to_host  the rate SURVEY.md 8(d) defines: page-locked host inputs -> page-locked host result incl. samples
+                (bwtm_merge_host: pipelined H2D / device work / D2H), with a PCIe calibration next to it
   roofline      HBM roofline of the dominant kernel (k_frontier_step; k_lf_walk_binned for small inputs), duration
                 measured with HIP events on the library's stream
   cpu_baseline  the CPU oracle (port of the reference algorithm) timed on this host's cores
                 on a bounded sample of the same workload (N == 1, rank 0 only)
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -26,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8.0 TB/s spec
+PCIE_SPEC_GBS = 63.0                       # PCIe Gen5 x16 per direction
 SEARCH_BYTES_PER_BASE = 160                # one 64-byte block + 8 + 8 bytes on each side
 
 
@@ -39,17 +44,22 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=50_000_000, help="reads per input set (config 2: 5e7 x 100 bp = 5.05 Gbase)")
+    ap.add_argument("--reads-a", type=int, default=0, help="reads of input1 when it differs from input2 (BASELINE config 4: asymmetric insert)")
     ap.add_argument("--readlen", type=int, default=100)
     ap.add_argument("--leaf-reads", type=int, default=1 << 19)
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="reads per set for the CPU baseline sample (0 = auto)")
-    ap.add_argument("--workload", choices=("iid", "genome"), default="iid",
-                    help="iid = the headline distribution; genome = reads from a shared random genome, 30x coverage, 1 %% substitutions (SURVEY 8(d), secondary)")
+    ap.add_argument("--workload", choices=("iid", "genome", "mixed"), default="iid",
+                    help="iid = the headline distribution; genome = reads from a shared random genome, 30x coverage, 1 %% substitutions "
+                         "(SURVEY 8(d), secondary); mixed = iid reads of 100 and 150 bp, half of the bases each (BASELINE config 5)")
     ap.add_argument("--coverage", type=int, default=30, help="genome workload: coverage (a smaller genome = a more repetitive BWT)")
     ap.add_argument("--error-percent", type=int, default=1, help="genome workload: substitution rate in percent")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-to-host measurement")
+    ap.add_argument("--host-steps", type=int, default=3)
+    ap.add_argument("--verify-reads", type=int, default=10000, help="reads extracted from the merged index and compared with the generator")
     ap.add_argument("--force-dist", action="store_true",
-                    help="take the multi-GPU code path (process group, caller-owned bitvector, all-reduce) even with one rank: "
+                    help="take the multi-GPU code path (process group, caller-owned bitvector, all-reduce, output slices) even with one rank: "
                          "a smoke test of that path on a 1-GPU box")
     args = ap.parse_args()
 
@@ -81,55 +91,59 @@ def main():
             dist.barrier()
 
     # ---------------------------------------------------------------- inputs (untimed)
+    # Built on the device by the merge tree, encoded to the native format, parked in page-locked host memory (the
+    # host-to-host leg starts from there) and copied back into plain device buffers for the HBM-resident leg, so that the
+    # library holds nothing of the inputs when a step starts.
     t_gen = time.time()
     wargs = ({"coverage": args.coverage, "error_percent": args.error_percent} if args.workload == "genome" else {})
-    sets = []
+    reads_per_set = (args.reads_a or args.reads, args.reads)
+    host_in, dev_in, meta = [], [], []
     for k, seed in enumerate((1001, 1002)):
         def progress(done, total, k=k):
-            if rank == 0 and (done == total or (done // args.leaf_reads) % 16 == 0):
+            if rank == 0 and (done == total or (done // args.leaf_reads) % 64 == 0):
                 log("input%d: %d / %d reads (%.0f s)" % (k + 1, done, total, time.time() - t_gen))
-        ix = synth.build_index(pkg, seed, args.reads, args.readlen, leaf_reads=args.leaf_reads, device=dev, progress=progress,
+        ix = synth.build_index(pkg, seed, reads_per_set[k], args.readlen, leaf_reads=args.leaf_reads, device=dev, progress=progress,
                                workload=args.workload, **wargs)
         ix.encode()
-        sets.append(ix)
+        hb = pkg.HostBuffer(ix.nbytes)
+        ix.download_into(hb.array)
+        meta.append({"sequences": ix.sequences, "bases": ix.bases, "nbytes": ix.nbytes, "C": ix.C})
+        ix.free()
+        host_in.append(hb)
     torch.cuda.empty_cache()
     pkg.trim()
-    A0, B0 = sets
-    n_a, n_b = A0.bases, B0.bases
-    ptr_a, bytes_a = A0.device_data()
-    ptr_b, bytes_b = B0.device_data()
+    for hb in host_in:
+        t = torch.empty(hb.nbytes + 16, dtype=torch.uint8, device=dev)       # 16 readable bytes after the stream (borrowed form)
+        t[: hb.nbytes].copy_(torch.from_numpy(hb.array))
+        t[hb.nbytes:].zero_()
+        dev_in.append(t)
+    torch.cuda.synchronize()
+    n_a, n_b = meta[0]["bases"], meta[1]["bases"]
+    m_a, m_b = meta[0]["sequences"], meta[1]["sequences"]
+    bytes_a, bytes_b = meta[0]["nbytes"], meta[1]["nbytes"]
     if rank == 0:
         log("inputs ready in %.0f s: %d + %d bases, %.3f + %.3f GB native (%.3f bytes/base)" %
             (time.time() - t_gen, n_a, n_b, bytes_a / 1e9, bytes_b / 1e9, (bytes_a + bytes_b) / (n_a + n_b)))
 
     # shard of input2's sequences for this rank (getBounds, utils.cpp:169-187)
-    from bwt_merge_amd.dist import shard_range
-    seq_first, seq_last = shard_range(B0.sequences, rank, world)
+    from bwt_merge_amd.dist import shard_range, merge_sharded
+    seq_first, seq_last = shard_range(m_b, rank, world)
+
+    def load_inputs():
+        # BWT::load of both inputs: the resident native bytes are read in place (no second copy in HBM)
+        A = pkg.Index.from_device(dev_in[0].data_ptr(), bytes_a, m_a, n_a, borrow=True)
+        B = pkg.Index.from_device(dev_in[1].data_ptr(), bytes_b, m_b, n_b, borrow=True)
+        return A, B
 
     # ---------------------------------------------------------------- one step
     def step(keep=False):
-        # BWT::load of both inputs: the resident native bytes are read in place (no second copy in HBM)
-        A = pkg.Index.from_device(ptr_a, bytes_a, A0.sequences, n_a, borrow=True)
-        B = pkg.Index.from_device(ptr_b, bytes_b, B0.sequences, n_b, borrow=True)
+        A, B = load_inputs()
         if not sharded:
-            M = pkg.merge(A, B)
+            M = pkg.merge_consume(A, B)          # "merges a and b, destroying them": their records are released after the interleave
         else:
-            nbytes = pkg.ra_buffer_bytes(A, B)
-            buf = torch.zeros(nbytes // 8, dtype=torch.int64, device=dev)
-            torch.cuda.synchronize()
-            ra = pkg.RankArray(A, B, buf.data_ptr(), nbytes)
-            if seq_first <= seq_last:
-                ra.search(A, B, seq_first, seq_last)
-            pkg.synchronize()
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)      # RCCL over xGMI; disjoint bits: sum == or
-            torch.cuda.synchronize()
-            ra.finalize()
-            M = pkg.interleave(A, B, ra)
-            M.encode()
-            ra.free()
-            del buf
+            M = merge_sharded(pkg, A, B, rank, world, dist, torch, dev)      # this rank's slice of the result
+            A.free(); B.free()
         pkg.synchronize()
-        A.free(); B.free()
         if keep:
             return M
         M.free()
@@ -137,6 +151,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    pkg.device_bytes_peak(reset=True)
     pkg.profile_enable(True)
     pkg.profile_reset()
     barrier()
@@ -148,6 +163,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = pkg.profile_read()
     pkg.profile_enable(False)
+    peak_device = pkg.device_bytes_peak() + sum(t.numel() for t in dev_in)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -162,75 +178,182 @@ def main():
     dom = "frontier_step" if "frontier_step" in prof else "lf_walk"
     dom_ms, dom_launches = prof.get(dom, (0.0, 0))
     searches = max(1, args.steps)
-    units_per_search = (seq_last - seq_first + 1) / max(1, B0.sequences) * n_b if seq_first <= seq_last else 0
+    units_per_search = (seq_last - seq_first + 1) / max(1, m_b) * n_b if seq_first <= seq_last else 0
     launches_per_search = dom_launches / searches if dom_launches else 0
     avg_launch_s = (dom_ms / 1e3 / dom_launches) if dom_launches else float("nan")
     units_per_launch = units_per_search / launches_per_search if launches_per_search else 0
     achieved = SEARCH_BYTES_PER_BASE * units_per_launch / avg_launch_s / 1e9 if dom_launches else 0.0
-    traffic, traffic_source = None, None
+    traffic, traffic_source, traffic_gbs = None, None, None
     try:
         with open(os.path.join(ROOT, "profiles", "search_kernel_traffic.json")) as f:
             t = json.load(f)
-        if (t["kernel"] == dom and t["config"]["reads_per_set"] == args.reads and t["config"]["read_length"] == args.readlen and world == 1):
+        if (t["kernel"] == dom and t["config"]["reads_per_set"] == args.reads and not args.reads_a and t["config"]["read_length"] == args.readlen
+                and args.workload == "iid" and world == 1):
             traffic, traffic_source = t["hbm_bytes_per_launch"], t["source"]
+            traffic_gbs = traffic / avg_launch_s / 1e9
     except (OSError, KeyError, ValueError):
         pass
+    # `achieved` / `frac` follow the contract: ALGORITHMIC bytes per launch / measured duration.  The frontier search shares cache
+    # lines between neighbouring elements, so the HBM bytes really moved (`traffic`, PMC counters) are fewer: `traffic_GBs` /
+    # `traffic_frac` say how busy the memory system actually is.
     roofline = {"bound": "hbm", "kernel": "k_" + dom + ("_binned" if dom == "lf_walk" else ""), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_basis": "algorithmic bytes (SURVEY 8(d): 160 B per LF step)",
+                "traffic": traffic, "traffic_source": traffic_source,
+                "traffic_GBs": (round(traffic_gbs, 1) if traffic_gbs else None), "traffic_frac": (round(traffic_gbs / HBM_PEAK_GBS, 4) if traffic_gbs else None),
                 "launches_per_step": round(launches_per_search, 2), "avg_launch_ms": round(avg_launch_s * 1e3, 4),
                 "kernel_ms_per_step": round(dom_ms / searches, 3),
                 "algorithmic_bytes_per_launch": SEARCH_BYTES_PER_BASE * units_per_launch}
     kernel_ms = {name: round(ms / max(1, args.steps), 3) for name, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0])}
     # whole-job algorithmic bytes W = 176 n_B + |A| + |B| + 2 |Out|
-    out_bytes = last.nbytes if last is not None else 0
+    out_bytes = last.total_nbytes if last is not None else 0
     W = 176 * n_b + bytes_a + bytes_b + 2 * out_bytes
     job = {"algorithmic_bytes": W, "achieved_GBs": round(W / sec_per_step / 1e9, 1), "frac": round(W / sec_per_step / 1e9 / HBM_PEAK_GBS, 4)}
 
     # ---------------------------------------------------------------- verification at full size
-    verified = None
-    if rank == 0 and last is not None and not args.no_verify:
-        verified = bool(np.array_equal(last.C, A0.C + B0.C) and last.bases == n_a + n_b and last.sequences == A0.sequences + B0.sequences)
-        rng = np.random.default_rng(12345)
-        ids = np.sort(rng.integers(0, last.sequences, 48))
-        got = synth.extract_sequences(pkg, last, ids, max_len=args.readlen + 8)
-        for j, seq in zip(ids, got):
-            seed, idx = (1001, int(j)) if j < A0.sequences else (1002, int(j - A0.sequences))
-            ref = synth.make_reads(args.workload, seed, idx, 1, args.readlen, args.reads, **wargs)[0].tolist()
-            verified = verified and (seq == ref)
-        # the emitted native stream must decode back to the merged index (header check in upload)
-        p, nb = last.device_data()
-        R = pkg.Index.from_device(p, nb, last.sequences, last.bases)
-        w0 = int(rng.integers(0, max(1, last.bases - 4096)))
-        verified = verified and bool(np.array_equal(R.extract(w0, min(4096, last.bases)), last.extract(w0, min(4096, last.bases))))
-        R.free()
-        log("full-size verification: %s" % verified)
+    verified, checks = None, {}
+    if rank == 0 and last is not None and not args.no_verify and not sharded:
+        verified, checks = verify_full_size(pkg, synth, np, last, meta, args, wargs, load_inputs)
+        log("full-size verification: %s %s" % (verified, checks))
     if last is not None:
         last.free()
+
+    # ---------------------------------------------------------------- host to host (SURVEY 8(d)'s T), rank 0 at N == 1
+    host = None
+    if rank == 0 and world == 1 and not args.no_host:
+        host = host_to_host(pkg, np, torch, dev, host_in, meta, args)
+    for t in dev_in:
+        del t
+    dev_in = []
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N == 1)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        torch.cuda.empty_cache(); pkg.trim()
         cpu = cpu_baseline(pkg, synth, torch, np, dev, args)
 
     if rank == 0:
+        wname = {"iid": "sigma=6", "genome": "reads from a shared random genome, %dx coverage, %d%% substitutions" % (args.coverage, args.error_percent),
+                 "mixed": "sigma=6, 100 / 150 bp mixed"}[args.workload]
         out = {
             "metric": "merged Gbases/sec (input1+input2), bit-exact native BWT",
             "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(sec_per_step * 1e3, 2), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "two %.3g Gbase synthetic %d bp read sets (%s), native format, inputs resident in HBM" %
-                       (n_a / 1e9, args.readlen, "sigma=6" if args.workload == "iid" else "reads from a shared random genome, 30x coverage, 1% substitutions"),
-                       "reads_per_set": args.reads, "read_length": args.readlen,
+            "config": {"workload": "%.3g + %.3g Gbase synthetic %d bp read sets (%s), native format, inputs resident in HBM" %
+                       (n_a / 1e9, n_b / 1e9, args.readlen, wname),
+                       "reads_per_set": args.reads, "reads_input1": reads_per_set[0], "read_length": args.readlen,
                        "bases": [n_a, n_b], "native_bytes": [bytes_a, bytes_b, out_bytes],
                        "parallelism": "sequence blocks of input2 sharded over %d GPU(s)%s" %
-                       (world, ", RCCL all-reduce of the rank-array bitvector" if world > 1 else "")},
+                       (world, ", RCCL all-reduce of the rank-array bitvector, result sharded by output range" if sharded else "")},
             "roofline": roofline, "job_roofline": job, "kernel_ms_per_step": kernel_ms,
-            "cpu_baseline": cpu, "verified": verified,
+            "host_to_host": host, "peak_device_bytes": peak_device,
+            "cpu_baseline": cpu, "verified": verified, "verification": checks,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def verify_full_size(pkg, synth, np, last, meta, args, wargs, load_inputs):
+    """Size-independent checks of the full-size result: C additivity and header, `verify_reads` reads extracted from the merged
+    index by LF walk == the generator's, the emitted stream decodes back to the same index, and -- two implementations of the
+    search against each other -- the rank array of the level-synchronous frontier search == that of the per-chain walk."""
+    checks = {}
+    C = meta[0]["C"] + meta[1]["C"]
+    m_a = meta[0]["sequences"]
+    checks["header_and_C"] = bool(np.array_equal(last.C, C) and last.bases == meta[0]["bases"] + meta[1]["bases"]
+                                  and last.sequences == m_a + meta[1]["sequences"])
+    rng = np.random.default_rng(12345)
+    ids = np.sort(rng.integers(0, last.sequences, args.verify_reads))
+    maxlen = (150 if args.workload == "mixed" else args.readlen)
+    got = synth.extract_sequences_matrix(last, ids, max_len=maxlen + 2)
+    ok = True
+    reads_per_set = (args.reads_a or args.reads, args.reads)
+    for which, seed in ((0, 1001), (1, 1002)):
+        sel = (ids < m_a) if which == 0 else (ids >= m_a)
+        idx = ids[sel] - (0 if which == 0 else m_a)
+        ref = synth.reads_matrix(args.workload, seed, idx, args.readlen, reads_per_set[which], maxlen + 2, **wargs)
+        ok = ok and bool(np.array_equal(got[sel], ref))
+    checks["extracted_reads"] = ok
+    checks["extracted_reads_count"] = int(ids.size)
+    # the emitted native stream must decode back to the merged index (header check in upload)
+    p, nb = last.device_data()
+    R = pkg.Index.from_device(p, nb, last.sequences, last.bases, borrow=True)
+    w0 = int(rng.integers(0, max(1, last.bases - (1 << 20))))
+    cnt = min(1 << 20, last.bases)
+    checks["stream_decodes_back"] = bool(np.array_equal(R.extract(w0, cnt), last.extract(w0, cnt)))
+    R.free()
+    if meta[1]["bases"] <= 2e10:
+        A, B = load_inputs()
+        bits = []
+        for algo in (2, 1):
+            pkg.tune("search_algo", algo)
+            ra = pkg.RankArray(A, B)
+            ra.search(A, B, 0, meta[1]["sequences"] - 1)
+            ra.finalize()
+            bits.append(ra.bits())
+            ra.free()
+        pkg.tune("search_algo", 0)
+        A.free(); B.free()
+        checks["frontier_equals_walk"] = bool(np.array_equal(bits[0], bits[1]))
+        del bits
+    return all(v for k, v in checks.items() if isinstance(v, bool)), checks
+
+
+def host_to_host(pkg, np, torch, dev, host_in, meta, args):
+    """T of SURVEY.md 8(d): page-locked native inputs -> page-locked native result + samples, through bwtm_merge_host."""
+    a = (host_in[0].array, meta[0]["sequences"], meta[0]["bases"])
+    b = (host_in[1].array, meta[1]["sequences"], meta[1]["bases"])
+    torch.cuda.empty_cache(); pkg.trim()
+    buffers = {}
+    res = pkg.merge_host(a, b, samples=True, buffers=buffers)           # warmup: allocates the page-locked output buffers once
+    out_bytes, blocks = res.out.nbytes, res.out.blocks
+    times, best = [], None
+    for _ in range(max(1, args.host_steps)):
+        t0 = time.perf_counter()
+        res = pkg.merge_host(a, b, samples=True, buffers=buffers)
+        dt = time.perf_counter() - t0
+        times.append(dt)
+        if best is None or dt <= min(times):
+            best = dict(res.times)
+    t_data = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        r2 = pkg.merge_host(a, b, samples=False, buffers=buffers)
+        t_data.append(time.perf_counter() - t0)
+    # PCIe calibration: plain page-locked copies of the same buffers
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    n = host_in[0].nbytes
+    scratch = torch.empty(n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    cal = {}
+    for name, dst, src, kind in (("h2d_GBs", scratch.data_ptr(), host_in[0].ptr, 1), ("d2h_GBs", buffers[0].ptr, scratch.data_ptr(), 2)):
+        best_t = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            hip.hipMemcpy(dst, src, min(n, buffers[0].nbytes), kind)
+            best_t = min(best_t, time.perf_counter() - t0)
+        cal[name] = round(min(n, buffers[0].nbytes) / best_t / 1e9, 1)
+    del scratch
+    merged = meta[0]["bases"] + meta[1]["bases"]
+    sec = sum(times) / len(times)
+    in_bytes = meta[0]["nbytes"] + meta[1]["nbytes"]
+    sample_bytes = 8 * blocks + 48 * (blocks + 1)
+    floor_ms = (in_bytes / (cal["h2d_GBs"] * 1e9) + (out_bytes + sample_bytes) / (cal["d2h_GBs"] * 1e9)) * 1e3
+    host = {"value": round(merged / 1e9 / sec, 4), "unit": "Gbases/s", "ms_per_step": round(sec * 1e3, 2), "steps": len(times),
+            "includes": "H2D of both native inputs, transcode, search, interleave, encode, D2H of the native result and of its samples "
+                        "(block_end + 6 cumulative arrays, 56 bytes per 64-byte block)",
+            "phases_ms": {k: round(v, 2) for k, v in best.items()},
+            "data_only": {"value": round(merged / 1e9 / min(t_data), 4), "ms_per_step": round(min(t_data) * 1e3, 2),
+                          "note": "without the D2H of the samples"},
+            "bytes": {"h2d": in_bytes, "d2h_data": out_bytes, "d2h_samples": sample_bytes},
+            "pcie": dict(cal, spec_GBs=PCIE_SPEC_GBS, transfer_floor_ms=round(floor_ms, 2))}
+    log("host to host: %.1f ms per merge (%.2f Gbases/s); phases %s; pcie %s" % (sec * 1e3, host["value"], host["phases_ms"], host["pcie"]))
+    for bfr in buffers.values():
+        bfr.free()
+    return host
 
 
 def cpu_baseline(pkg, synth, torch, np, dev, args):
@@ -246,7 +369,7 @@ def cpu_baseline(pkg, synth, torch, np, dev, args):
     t0 = time.time()
     fm = []
     for seed in (1001, 1002):
-        sym = synth.leaf_bwt(synth.make_reads(args.workload, seed, 0, n, args.readlen, n, device=dev)).cpu().numpy()
+        sym = synth.leaf_symbols(args.workload, seed, 0, n, args.readlen, n, dev).cpu().numpy()
         fm.append(orc.FMI.from_symbols(sym))
     a, b = fm
     A = pkg.Index.upload(a.data, a.sequences, a.bases)
@@ -255,14 +378,14 @@ def cpu_baseline(pkg, synth, torch, np, dev, args):
     gpu_bytes = M.data()
     log("cpu baseline sample: 2 x %d reads prepared in %.1f s; running the oracle on %d threads" % (n, time.time() - t0, cores))
     t0 = time.perf_counter()
+    merged = a.bases + b.bases
     m, secs = orc.merge(a, b, threads=cores)
     dt = time.perf_counter() - t0
     ok = bool(np.array_equal(gpu_bytes, m.data))
-    merged = 2 * n * (args.readlen + 1)
     log("cpu baseline: %.2f s (search %.2f s, interleave %.2f s), parity with GPU on the sample: %s" % (dt, secs[0], secs[1], ok))
     return {"value": round(merged / 1e9 / dt, 6), "unit": "Gbases/s", "cores": cores, "kind": "port",
-            "sample": "two sets of %d synthetic %d bp reads (%.3g Gbase merged), oracle merge with %d threads, reference default buffers" %
-                      (n, args.readlen, merged / 1e9, cores),
+            "sample": "two sets of %d synthetic reads of the same workload (%.3g Gbase merged), oracle merge with %d threads, reference default buffers" %
+                      (n, merged / 1e9, cores),
             "seconds": round(dt, 3), "gpu_parity_on_sample": ok}
 
 

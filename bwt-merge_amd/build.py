@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbwtm.so")
 SOURCES = ["bwtm_api.hip"]
 KERNELS = ["common", "transcode", "queries", "search_walk", "search_frontier", "interleave", "encoder", "diagnostics"]
-API = ["context", "index", "search", "merge"]
+API = ["context", "index", "search", "merge", "slices"]
 DEPS = (["bwtm_api.hip", "bwtm_kernels.hip.h", "bwtm_device.h", os.path.join("..", "..", "include", "bwtm.h")]
         + [os.path.join("kernels", k + ".hip.h") for k in KERNELS] + [os.path.join("api", k + ".hip.h") for k in API])
 

@@ -44,6 +44,22 @@ SYMBOLS = [
     ("bwtm_host_free", None, [vp]),
     ("bwtm_ra_download_runs", C.c_int, [vp, p_u64, p_u64, u64, p_u64]),
     ("bwtm_merge_consume", C.c_int, [vp, vp, C.POINTER(vp)]),
+    ("bwtm_merged_records", u64, [vp, vp]),
+    ("bwtm_slice_bounds", C.c_int, [u64, C.c_int, C.c_int, p_u64, p_u64]),
+    ("bwtm_interleave_range", C.c_int, [vp, vp, vp, u64, u64, C.POINTER(vp)]),
+    ("bwtm_slice_free", None, [vp]),
+    ("bwtm_slice_lasthead", C.c_int, [vp, p_u64]),
+    ("bwtm_slice_size_table", C.c_int, [vp, u64, p_u64]),
+    ("bwtm_fold_offsets", C.c_int, [p_u64, C.c_int, p_u64]),
+    ("bwtm_slice_encode", C.c_int, [vp, u64]),
+    ("bwtm_slice_byte_first", u64, [vp]),
+    ("bwtm_slice_bytes", u64, [vp]),
+    ("bwtm_slice_block_first", u64, [vp]),
+    ("bwtm_slice_blocks", u64, [vp]),
+    ("bwtm_slice_first_block_start", C.c_int, [vp, p_u64]),
+    ("bwtm_slice_download_data", C.c_int, [vp, p_u8, u64]),
+    ("bwtm_slice_download_samples", C.c_int, [vp, u64, p_u64, p_u64]),
+    ("bwtm_slice_extract", C.c_int, [vp, u64, u64, p_u8]),
     ("bwtm_merge_host", C.c_int, [C.POINTER(HostInput), C.POINTER(HostInput), ALLOC_FN, vp, C.c_int, C.POINTER(HostOutput), C.POINTER(vp)]),
     ("bwtm_merge_host_chained", C.c_int, [vp, C.POINTER(HostInput), ALLOC_FN, vp, C.c_int, C.POINTER(HostOutput), C.POINTER(vp)]),
     ("bwtm_last_error", C.c_char_p, []),
@@ -219,14 +235,21 @@ def _host_input(data, sequences, bases):
     return HostInput(data.ctypes.data, data.size, sequences, bases, None)
 
 
-def merge_host(a, b, samples=True, keep=False, chained=None):
+def merge_host(a, b, samples=True, keep=False, chained=None, buffers=None):
     """FMI::FMI(a, b) from host-resident inputs to a host-resident result (bwtm_merge_host).
-    a, b: (data uint8 array, sequences, bases); chained: a device Index (consumed) instead of a."""
+    a, b: (data uint8 array, sequences, bases); chained: a device Index (consumed) instead of a.
+    buffers: a dict that keeps the page-locked output buffers between calls (they are reused when large enough)."""
     res = HostMerge()
+    if buffers is not None:
+        res.buffers = buffers
 
     def alloc(user, what, nbytes):
-        buf = HostBuffer(nbytes)
-        res.buffers[what] = buf
+        buf = res.buffers.get(what)
+        if buf is None or buf.nbytes < nbytes:
+            if buf is not None:
+                buf.free()
+            buf = HostBuffer(nbytes)
+            res.buffers[what] = buf
         return buf.ptr
 
     cb = ALLOC_FN(alloc)
@@ -239,7 +262,8 @@ def merge_host(a, b, samples=True, keep=False, chained=None):
         ha = _host_input(*a)
         rc = lib().bwtm_merge_host(C.byref(ha), C.byref(hb), cb, None, 1 if samples else 0, C.byref(res.out), C.byref(kp) if keep else None)
     if rc != 0:
-        res.free()
+        if buffers is None:
+            res.free()
         check(rc)
     if keep:
         res.keep = Index(kp)
@@ -326,8 +350,16 @@ class Index:
         check(lib().bwtm_index_device_data(self.h, C.byref(ptr), C.byref(n)))
         return int(ptr.value or 0), int(n.value)
 
+    total_nbytes = nbytes            # a slice of a sharded result reports the size of the whole stream here
+
     def data(self):
         out = np.zeros(self.nbytes, dtype=np.uint8)
+        check(lib().bwtm_index_download_data(self.h, out.ctypes.data_as(p_u8), out.size))
+        return out
+
+    def download_into(self, out):
+        """Native bytes into a caller's uint8 array (e.g. page-locked memory)."""
+        assert out.dtype == np.uint8 and out.size >= self.nbytes
         check(lib().bwtm_index_download_data(self.h, out.ctypes.data_as(p_u8), out.size))
         return out
 
@@ -428,6 +460,87 @@ class RankArray:
         out = np.zeros(words, dtype=np.uint64)
         check(lib().bwtm_ra_download_bits(self.h, out.ctypes.data_as(p_u64), out.size))
         return out
+
+
+class Slice:
+    """One GPU's share of a merged index: the output records [rec_first, rec_last) (handle on bwtm_slice)."""
+
+    def __init__(self, a, b, ra, rec_first, rec_last):
+        out = vp()
+        check(lib().bwtm_interleave_range(a.h, b.h, ra.h, rec_first, rec_last, C.byref(out)))
+        self.h = out
+        self.total_nbytes = 0
+
+    def free(self):
+        if self.h:
+            lib().bwtm_slice_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def lasthead(self):
+        v = u64(0)
+        check(lib().bwtm_slice_lasthead(self.h, C.byref(v)))
+        return int(v.value)
+
+    def size_table(self, heads_before):
+        t = np.zeros(64, dtype=np.uint64)
+        check(lib().bwtm_slice_size_table(self.h, int(heads_before), t.ctypes.data_as(p_u64)))
+        return t
+
+    def encode(self, byte_offset):
+        check(lib().bwtm_slice_encode(self.h, int(byte_offset)))
+        return self
+
+    byte_first = property(lambda s: int(lib().bwtm_slice_byte_first(s.h)))
+    nbytes = property(lambda s: int(lib().bwtm_slice_bytes(s.h)))
+    block_first = property(lambda s: int(lib().bwtm_slice_block_first(s.h)))
+    blocks = property(lambda s: int(lib().bwtm_slice_blocks(s.h)))
+
+    def first_block_start(self):
+        """Sequence position at which the slice's first block starts; None if it has no block."""
+        v = u64(0)
+        check(lib().bwtm_slice_first_block_start(self.h, C.byref(v)))
+        return None if v.value == (1 << 64) - 1 else int(v.value)
+
+    def data(self):
+        out = np.zeros(self.nbytes, dtype=np.uint8)
+        check(lib().bwtm_slice_download_data(self.h, out.ctypes.data_as(p_u8), out.size))
+        return out
+
+    def samples(self, next_block_start):
+        nb = self.blocks
+        be = np.zeros(nb, dtype=np.uint64)
+        cum = np.zeros((SIGMA, nb), dtype=np.uint64)
+        check(lib().bwtm_slice_download_samples(self.h, int(next_block_start), be.ctypes.data_as(p_u64), cum.ctypes.data_as(p_u64)))
+        return be, cum
+
+    def extract(self, first, count):
+        out = np.zeros(count, dtype=np.uint8)
+        check(lib().bwtm_slice_extract(self.h, first, count, out.ctypes.data_as(p_u8)))
+        return out
+
+
+def merged_records(a, b):
+    return int(lib().bwtm_merged_records(a.h, b.h))
+
+
+def slice_bounds(nrecs, parts, part):
+    f, l = u64(0), u64(0)
+    check(lib().bwtm_slice_bounds(nrecs, parts, part, C.byref(f), C.byref(l)))
+    return int(f.value), int(l.value)
+
+
+def fold_offsets(tables):
+    """tables: [parts, 64] uint64 -> offsets [parts + 1] (byte offset of every slice, then the size of the stream)."""
+    tables = np.ascontiguousarray(tables, dtype=np.uint64)
+    out = np.zeros(tables.shape[0] + 1, dtype=np.uint64)
+    check(lib().bwtm_fold_offsets(tables.ctypes.data_as(p_u64), tables.shape[0], out.ctypes.data_as(p_u64)))
+    return out
 
 
 def ra_buffer_bytes(a, b):

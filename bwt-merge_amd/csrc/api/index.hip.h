@@ -214,12 +214,12 @@ int encode_size(bwtm_index* x, EncodePlan& plan)
   TRY(plan.group_base.alloc((ngroups + 1) * sizeof(u64)));
   TRY(plan.seg_base.alloc(nseg * sizeof(u64)));
   const u64 wave_grid = div_up(nseg * WAVE, BLOCK_THREADS);
-  LAUNCH("enc_lasthead", k_enc_lasthead, wave_grid, BLOCK_THREADS, x->recs.as<const uint4>(), x->nrecs, x->n, plan.ntiles, nseg, plan.lasthead.as<u64>());
+  LAUNCH("enc_lasthead", k_enc_lasthead, wave_grid, BLOCK_THREADS, x->recs.as<const uint4>(), x->nrecs, x->n, plan.ntiles, (u64)0, nseg, plan.lasthead.as<u64>());
   TRY(device_scan<1>(plan.lasthead.as<u64>(), plan.lasthead.as<u64>(), nseg));       // -> (last head before the segment) + 1
-  LAUNCH("enc_size", k_enc_size, wave_grid, BLOCK_THREADS, x->recs.as<const uint4>(), x->nrecs, x->n, plan.ntiles, nseg,
-    plan.lasthead.as<const u64>(), plan.table.as<u32>());
+  LAUNCH("enc_size", k_enc_size, wave_grid, BLOCK_THREADS, x->recs.as<const uint4>(), x->nrecs, x->n, plan.ntiles, (u64)0, nseg,
+    plan.lasthead.as<const u64>(), (u64)0, plan.table.as<u32>());
   LAUNCH("fold_group", k_fold_group, ngroups, WAVE, plan.table.as<const u32>(), nseg, plan.group_table.as<u64>());
-  LAUNCH("fold_top", k_fold_top, 1, WAVE, plan.group_table.as<const u64>(), ngroups, plan.group_base.as<u64>());
+  LAUNCH("fold_top", k_fold_top, 1, WAVE, plan.group_table.as<const u64>(), ngroups, (u64)0, plan.group_base.as<u64>());
   LAUNCH("fold_seg", k_fold_seg, ngroups, WAVE, plan.table.as<const u32>(), nseg, plan.group_base.as<const u64>(), plan.seg_base.as<u64>());
   plan.group_base_host.resize(ngroups + 1);
   HIP_TRY(hipMemcpyAsync(plan.group_base_host.data(), plan.group_base.p, (ngroups + 1) * sizeof(u64), hipMemcpyDeviceToHost, CTX.stream));
@@ -252,7 +252,7 @@ int encode_emit(bwtm_index* x, EncodePlan& plan, u8* host_out)
     auto launch = [&]() -> int
     {
       LAUNCH("enc_emit", k_enc_emit, div_up((s1 - s0) * WAVE, BLOCK_THREADS), BLOCK_THREADS, x->recs.as<const uint4>(), x->nrecs, x->n, plan.ntiles, s0, s1,
-        plan.lasthead.as<const u64>(), plan.seg_base.as<const u64>(), x->data.as<u8>(), x->block_start.as<u64>());
+        plan.lasthead.as<const u64>(), (u64)0, plan.seg_base.as<const u64>(), x->data.as<u8>(), x->block_start.as<u64>());
       return BWTM_OK;
     };
     rc = launch();

@@ -18,7 +18,7 @@ int interleave_impl(const bwtm_index* a, const bwtm_index* b, bwtm_ra* ra, bwtm_
   LAUNCH("interleave_sup", k_interleave_sup, div_up(x->nsup, BLOCK_THREADS), BLOCK_THREADS, a->view(), b->view(),
     ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), x->n, x->sup.as<u64>(), x->nsup);
   LAUNCH("interleave", k_interleave, div_up(ra->nchunks * WAVE, BLOCK_THREADS), BLOCK_THREADS, a->view(), b->view(),
-    ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), ra->nchunks, x->sup.as<const u64>(), x->recs.as<uint4>(), x->nrecs);
+    ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), (u64)0, ra->nchunks, (u64)0, x->nrecs, x->sup.as<const u64>(), x->recs.as<uint4>());
   return BWTM_OK;
 }
 

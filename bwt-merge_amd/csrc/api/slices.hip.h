@@ -1,0 +1,290 @@
+/*
+  api/slices.hip.h -- the result of a merge left SHARDED BY OUTPUT RANGE: every GPU interleaves and encodes only the
+  output records [rec_first, rec_last) (mergeBWT, bwt.cpp:215-282, cut by output position), and the two things that
+  cross a slice boundary travel as a few words between the GPUs:
+
+    1. the run that is open at the boundary: (position of the last head before the slice) + 1 -- the maximal run that
+       RunBuffer (utils.h:121-142) would still be extending there;
+    2. Run::write's dependence on array.size() % 64 (support.h:256-282): every slice publishes the number of bytes it
+       emits as a function of the byte offset it starts at (64 values, the composition of its segment tables); folding
+       the tables of the slices before it gives a slice its exact byte offset.
+
+  Needed for memory (BASELINE config 4: the result does not fit next to the replicated inputs) and for scaling (the
+  interleave / encode / download tail shrinks with the number of GPUs).  Part of bwtm_api.hip.
+*/
+#pragma once
+
+struct bwtm_slice
+{
+  bwtm_context* ctx = nullptr;
+  u64 n = 0, m = 0;                    // the WHOLE merged index
+  u64 C[8] = {};
+  u64 nrecs_total = 0;
+  u64 rec_first = 0, rec_last = 0;     // records of this slice
+  u64 rec_halo = 0;                    // first record held (rec_first - 1, or 0)
+  DevBuf recs;                         // records [rec_halo, rec_last)
+  DevBuf sup; u64 nsup = 0;            // super table of the whole result (small)
+  u64 seg_first = 0, seg_end = 0;      // encoder segments of this slice
+  // encoder state
+  DevBuf lasthead, table, group_table, group_base, seg_base;
+  u64 ngroups = 0;
+  int stage = 0;                       // 0 = interleaved, 1 = lasthead known, 2 = size table known, 3 = encoded
+  u64 head_carry = 0;
+  u32 halo_symbol = 0;                 // symbol at position 128 rec_first - 1
+  u64 byte_first = 0, byte_end = 0;    // stream offsets of the slice's bytes
+  DevBuf data;                         // bytes [byte_first & ~63, byte_end)
+  u64 block_first = 0, nblocks = 0;    // blocks whose first byte lies in the slice: [block_first, block_first + nblocks)
+  DevBuf block_start;                  // nblocks + 1 entries (the last one is filled in by download_samples)
+
+  const uint4* recs_virtual() const { return recs.as<const uint4>() - 4 * rec_halo; }
+  u64 pos_first() const { return rec_first << REC_SHIFT; }
+  IndexView view() const
+  {
+    IndexView v;
+    v.recs = recs_virtual(); v.sup = sup.as<const u64>();
+    v.n = n; v.m = m; v.nrecs = nrecs_total;
+    for(int c = 0; c < 8; c++) { v.C[c] = C[c]; }
+    return v;
+  }
+};
+
+namespace
+{
+
+constexpr u64 SLICE_ALIGN = SEG_TILES / 2;        // records per encoder segment (512): slices are cut at segment boundaries
+
+void slice_destroy(bwtm_slice* s)
+{
+  if(!s) { return; }
+  Scope scope(s->ctx);
+  delete s;
+}
+
+} // namespace
+
+extern "C" uint64_t bwtm_merged_records(const bwtm_index* a, const bwtm_index* b)
+{
+  return (a && b ? num_records(a->n + b->n) : 0);
+}
+
+extern "C" int bwtm_slice_bounds(uint64_t nrecs, int parts, int part, uint64_t* rec_first, uint64_t* rec_last)
+{
+  if(parts <= 0 || part < 0 || part >= parts || !rec_first || !rec_last) { return fail(BWTM_EINVAL, "bwtm_slice_bounds: bad argument"); }
+  // near-equal ranges of whole segments (getBounds over the segments, utils.cpp:169-187)
+  const u64 nseg = div_up(nrecs, SLICE_ALIGN);
+  const u64 lo = nseg * (u64)part / (u64)parts, hi = nseg * (u64)(part + 1) / (u64)parts;
+  *rec_first = std::min(nrecs, lo * SLICE_ALIGN);
+  *rec_last = (part + 1 == parts ? nrecs : std::min(nrecs, hi * SLICE_ALIGN));
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_fold_offsets(const uint64_t* tables, int parts, uint64_t* offsets)
+{
+  if(!tables || !offsets || parts < 0) { return fail(BWTM_EINVAL, "bwtm_fold_offsets: bad argument"); }
+  u64 off = 0;
+  for(int g = 0; g < parts; g++) { offsets[g] = off; off += tables[(u64)g * 64 + (off & 63)]; }
+  offsets[parts] = off;
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_interleave_range(const bwtm_index* a, const bwtm_index* b, bwtm_ra* ra, uint64_t rec_first, uint64_t rec_last, bwtm_slice** out)
+{
+  if(!a || !b || !ra || !out) { return fail(BWTM_EINVAL, "bwtm_interleave_range: null argument"); }
+  if(a->ctx != ra->ctx || b->ctx != ra->ctx) { return fail(BWTM_EINVAL, "bwtm_interleave_range: handles of different contexts"); }
+  ENTER(ra->ctx);
+  TRY(check_interleave_args(a, b, ra));
+  const u64 nrecs = ra->nrecs_out;
+  if(rec_first > rec_last || rec_last > nrecs || (rec_first != rec_last && (rec_first % SLICE_ALIGN != 0 || (rec_last % SLICE_ALIGN != 0 && rec_last != nrecs))))
+  {
+    return fail(BWTM_EINVAL, "bwtm_interleave_range: [%llu, %llu) is not a range of whole %llu-record segments of %llu records",
+      (unsigned long long)rec_first, (unsigned long long)rec_last, (unsigned long long)SLICE_ALIGN, (unsigned long long)nrecs);
+  }
+  bwtm_slice* s = new bwtm_slice();
+  s->ctx = t_ctx;
+  auto body = [&]() -> int
+  {
+    s->n = ra->n_out; s->m = a->m + b->m;
+    for(int c = 0; c < 8; c++) { s->C[c] = a->C[c] + b->C[c]; }
+    s->nrecs_total = nrecs; s->rec_first = rec_first; s->rec_last = rec_last;
+    s->rec_halo = (rec_first > 0 ? rec_first - 1 : 0);
+    if(rec_first < rec_last) { s->seg_first = rec_first / SLICE_ALIGN; s->seg_end = div_up(rec_last, SLICE_ALIGN); }   // an empty slice has no segments
+    s->nsup = num_supers(s->n);
+    TRY(s->recs.alloc((rec_last - s->rec_halo + 1) * 64));
+    TRY(s->sup.alloc(s->nsup * SUP_STRIDE * sizeof(u64)));
+    LAUNCH("interleave_sup", k_interleave_sup, div_up(s->nsup, BLOCK_THREADS), BLOCK_THREADS, a->view(), b->view(),
+      ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), s->n, s->sup.as<u64>(), s->nsup);
+    if(rec_last > s->rec_halo)
+    {
+      const u64 c0 = s->rec_halo >> 6, c1 = div_up(rec_last, 64);
+      LAUNCH("interleave", k_interleave, div_up((c1 - c0) * WAVE, BLOCK_THREADS), BLOCK_THREADS, a->view(), b->view(),
+        ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), c0, c1, s->rec_halo, rec_last, s->sup.as<const u64>(),
+        s->recs.as<uint4>() - 4 * s->rec_halo);
+    }
+    return BWTM_OK;
+  };
+  int rc = body();
+  if(rc != BWTM_OK) { delete s; return rc; }
+  *out = s;
+  return BWTM_OK;
+}
+
+extern "C" void bwtm_slice_free(bwtm_slice* slice) { slice_destroy(slice); }
+
+extern "C" int bwtm_slice_lasthead(bwtm_slice* s, uint64_t* lasthead)
+{
+  if(!s || !lasthead) { return fail(BWTM_EINVAL, "bwtm_slice_lasthead: null argument"); }
+  ENTER(s->ctx);
+  const u64 nseg = s->seg_end - s->seg_first;
+  *lasthead = 0;
+  s->stage = 1;
+  if(nseg == 0) { return BWTM_OK; }
+  const u64 ntiles = (s->n >> 6) + 1;
+  TRY(s->lasthead.alloc((nseg + 1) * sizeof(u64)));
+  HIP_TRY(hipMemsetAsync(s->lasthead.as<u64>() + nseg, 0, sizeof(u64), CTX.stream));
+  LAUNCH("enc_lasthead", k_enc_lasthead, div_up(nseg * WAVE, BLOCK_THREADS), BLOCK_THREADS, s->recs_virtual(), s->nrecs_total, s->n, ntiles,
+    s->seg_first, s->seg_end, s->lasthead.as<u64>() - s->seg_first);
+  // exclusive max-scan over nseg + 1 entries: entry k = (last head of the slice before its segment k) + 1, the extra entry = the slice's own
+  TRY(device_scan<1>(s->lasthead.as<u64>(), s->lasthead.as<u64>(), nseg + 1));
+  TRY(fetch_u64(s->lasthead.as<u64>() + nseg, 0));
+  // the symbol before the slice (for the samples of blocks opened by a run that began in an earlier slice)
+  DevBuf sym; TRY(sym.alloc(8));
+  if(s->rec_first > 0)
+  {
+    LAUNCH("extract", k_extract, 1, BLOCK_THREADS, s->view(), s->pos_first() - 1, (u64)1, sym.as<u8>());
+    CTX.host_scratch[1] = 0;
+    HIP_TRY(hipMemcpyAsync(CTX.host_scratch + 1, sym.p, 1, hipMemcpyDeviceToHost, CTX.stream));
+  }
+  HIP_TRY(hipStreamSynchronize(CTX.stream));
+  *lasthead = CTX.host_scratch[0];
+  s->halo_symbol = (s->rec_first > 0 ? (u32)(CTX.host_scratch[1] & 0xFF) : 0u);
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_slice_size_table(bwtm_slice* s, uint64_t heads_before, uint64_t* table)
+{
+  if(!s || !table) { return fail(BWTM_EINVAL, "bwtm_slice_size_table: null argument"); }
+  ENTER(s->ctx);
+  if(s->stage < 1) { return fail(BWTM_EINVAL, "bwtm_slice_size_table: call bwtm_slice_lasthead first"); }
+  const u64 nseg = s->seg_end - s->seg_first;
+  s->head_carry = heads_before;
+  s->stage = 2;
+  for(int o = 0; o < 64; o++) { table[o] = 0; }
+  if(nseg == 0) { return BWTM_OK; }
+  const u64 ntiles = (s->n >> 6) + 1;
+  s->ngroups = div_up(nseg, FOLD_GROUP);
+  TRY(s->table.alloc(nseg * 64 * sizeof(u32)));
+  TRY(s->group_table.alloc(s->ngroups * 64 * sizeof(u64)));
+  DevBuf slice_table; TRY(slice_table.alloc(64 * sizeof(u64)));
+  LAUNCH("enc_size", k_enc_size, div_up(nseg * WAVE, BLOCK_THREADS), BLOCK_THREADS, s->recs_virtual(), s->nrecs_total, s->n, ntiles, s->seg_first, s->seg_end,
+    s->lasthead.as<const u64>() - s->seg_first, heads_before, s->table.as<u32>() - s->seg_first * 64);
+  LAUNCH("fold_group", k_fold_group, s->ngroups, WAVE, s->table.as<const u32>(), nseg, s->group_table.as<u64>());
+  LAUNCH("fold_slice", k_fold_slice, 1, WAVE, s->group_table.as<const u64>(), s->ngroups, slice_table.as<u64>());
+  HIP_TRY(hipMemcpyAsync(table, slice_table.p, 64 * sizeof(u64), hipMemcpyDeviceToHost, CTX.stream));
+  HIP_TRY(hipStreamSynchronize(CTX.stream));
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_slice_encode(bwtm_slice* s, uint64_t byte_offset)
+{
+  if(!s) { return fail(BWTM_EINVAL, "bwtm_slice_encode: null argument"); }
+  ENTER(s->ctx);
+  if(s->stage < 2) { return fail(BWTM_EINVAL, "bwtm_slice_encode: call bwtm_slice_size_table first"); }
+  const u64 nseg = s->seg_end - s->seg_first;
+  s->byte_first = byte_offset; s->byte_end = byte_offset;
+  s->stage = 3;
+  if(nseg > 0)
+  {
+    const u64 ntiles = (s->n >> 6) + 1;
+    TRY(s->group_base.alloc((s->ngroups + 1) * sizeof(u64)));
+    TRY(s->seg_base.alloc(nseg * sizeof(u64)));
+    LAUNCH("fold_top", k_fold_top, 1, WAVE, s->group_table.as<const u64>(), s->ngroups, byte_offset, s->group_base.as<u64>());
+    LAUNCH("fold_seg", k_fold_seg, s->ngroups, WAVE, s->table.as<const u32>(), nseg, s->group_base.as<const u64>(), s->seg_base.as<u64>());
+    TRY(fetch_u64(s->group_base.as<u64>() + s->ngroups, 0));
+    HIP_TRY(hipStreamSynchronize(CTX.stream));
+    s->byte_end = CTX.host_scratch[0];
+    const u64 base = byte_offset & ~(u64)(RLE_BLOCK - 1);
+    s->block_first = div_up(byte_offset, RLE_BLOCK);
+    s->nblocks = div_up(s->byte_end, RLE_BLOCK) - s->block_first;
+    TRY(alloc_native(s->data, s->byte_end - base));
+    TRY(s->block_start.alloc((s->nblocks + 1) * sizeof(u64), true));
+    LAUNCH("enc_emit", k_enc_emit, div_up(nseg * WAVE, BLOCK_THREADS), BLOCK_THREADS, s->recs_virtual(), s->nrecs_total, s->n, ntiles, s->seg_first, s->seg_end,
+      s->lasthead.as<const u64>() - s->seg_first, s->head_carry, s->seg_base.as<const u64>() - s->seg_first, s->data.as<u8>() - base,
+      s->block_start.as<u64>() - s->block_first);
+  }
+  else
+  {
+    s->block_first = div_up(byte_offset, RLE_BLOCK); s->nblocks = 0;
+    TRY(s->block_start.alloc(sizeof(u64), true));
+  }
+  s->table.release(); s->group_table.release(); s->group_base.release(); s->seg_base.release(); s->lasthead.release();
+  return BWTM_OK;
+}
+
+extern "C" uint64_t bwtm_slice_byte_first(const bwtm_slice* s)  { return s ? s->byte_first : 0; }
+extern "C" uint64_t bwtm_slice_bytes(const bwtm_slice* s)       { return s ? s->byte_end - s->byte_first : 0; }
+extern "C" uint64_t bwtm_slice_block_first(const bwtm_slice* s) { return s ? s->block_first : 0; }
+extern "C" uint64_t bwtm_slice_blocks(const bwtm_slice* s)      { return s ? s->nblocks : 0; }
+
+extern "C" int bwtm_slice_first_block_start(bwtm_slice* s, uint64_t* position)
+{
+  if(!s || !position) { return fail(BWTM_EINVAL, "bwtm_slice_first_block_start: null argument"); }
+  ENTER(s->ctx);
+  if(s->stage < 3) { return fail(BWTM_EINVAL, "bwtm_slice_first_block_start: slice not encoded"); }
+  *position = ~0ull;                                 // no block starts in this slice
+  if(s->nblocks == 0) { return BWTM_OK; }
+  TRY(fetch_u64(s->block_start.as<u64>(), 0));
+  HIP_TRY(hipStreamSynchronize(CTX.stream));
+  *position = CTX.host_scratch[0];
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_slice_download_data(bwtm_slice* s, uint8_t* out, uint64_t capacity)
+{
+  if(!s || (!out && capacity > 0)) { return fail(BWTM_EINVAL, "bwtm_slice_download_data: null argument"); }
+  ENTER(s->ctx);
+  if(s->stage < 3) { return fail(BWTM_EINVAL, "bwtm_slice_download_data: slice not encoded"); }
+  const u64 bytes = s->byte_end - s->byte_first;
+  if(capacity < bytes) { return fail(BWTM_EINVAL, "bwtm_slice_download_data: buffer too small"); }
+  if(bytes > 0)
+  {
+    const u64 base = s->byte_first & ~(u64)(RLE_BLOCK - 1);
+    HIP_TRY(hipMemcpyAsync(out, s->data.as<u8>() + (s->byte_first - base), bytes, hipMemcpyDeviceToHost, CTX.stream));
+  }
+  HIP_TRY(hipStreamSynchronize(CTX.stream));
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_slice_download_samples(bwtm_slice* s, uint64_t next_block_start, uint64_t* block_end, uint64_t* cum)
+{
+  if(!s) { return fail(BWTM_EINVAL, "bwtm_slice_download_samples: null argument"); }
+  ENTER(s->ctx);
+  if(s->stage < 3) { return fail(BWTM_EINVAL, "bwtm_slice_download_samples: slice not encoded"); }
+  if(s->nblocks == 0) { return BWTM_OK; }
+  if(!block_end || !cum) { return fail(BWTM_EINVAL, "bwtm_slice_download_samples: null argument"); }
+  const u64 nb = s->nblocks;
+  CTX.host_scratch[62] = next_block_start;
+  HIP_TRY(hipMemcpyAsync(s->block_start.as<u64>() + nb, CTX.host_scratch + 62, sizeof(u64), hipMemcpyHostToDevice, CTX.stream));
+  DevBuf be, dc;
+  TRY(be.alloc(nb * sizeof(u64))); TRY(dc.alloc(6 * nb * sizeof(u64)));
+  LAUNCH("block_end", k_block_end, div_up(nb, BLOCK_THREADS), BLOCK_THREADS, s->block_start.as<const u64>(), (u64)0, nb, be.as<u64>());
+  LAUNCH("block_cum", k_block_cum_slice, div_up(nb, BLOCK_THREADS), BLOCK_THREADS, s->view(), s->block_start.as<const u64>(), (u64)0, nb, dc.as<u64>(), nb,
+    s->pos_first(), s->halo_symbol);
+  HIP_TRY(hipMemcpyAsync(block_end, be.p, nb * sizeof(u64), hipMemcpyDeviceToHost, CTX.stream));
+  HIP_TRY(hipMemcpyAsync(cum, dc.p, 6 * nb * sizeof(u64), hipMemcpyDeviceToHost, CTX.stream));
+  HIP_TRY(hipStreamSynchronize(CTX.stream));
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_slice_extract(bwtm_slice* s, uint64_t first, uint64_t count, uint8_t* out)
+{
+  if(!s || !out) { return fail(BWTM_EINVAL, "bwtm_slice_extract: null argument"); }
+  ENTER(s->ctx);
+  const u64 lo = s->pos_first(), hi = std::min(s->n, s->rec_last << REC_SHIFT);
+  if(first < lo || first + count > hi) { return fail(BWTM_EINVAL, "bwtm_slice_extract: range outside the slice"); }
+  if(count == 0) { return BWTM_OK; }
+  DevBuf d; TRY(d.alloc(count));
+  LAUNCH("extract", k_extract, div_up(count, BLOCK_THREADS), BLOCK_THREADS, s->view(), first, count, d.as<u8>());
+  HIP_TRY(hipMemcpyAsync(out, d.p, count, hipMemcpyDeviceToHost, CTX.stream));
+  HIP_TRY(hipStreamSynchronize(CTX.stream));
+  return BWTM_OK;
+}

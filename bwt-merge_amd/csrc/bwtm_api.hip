@@ -31,3 +31,4 @@ using namespace bwtm;
 #include "api/index.hip.h"
 #include "api/search.hip.h"
 #include "api/merge.hip.h"
+#include "api/slices.hip.h"

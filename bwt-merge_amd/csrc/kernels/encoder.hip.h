@@ -87,10 +87,14 @@ __device__ inline u32 chunk_tiles(const uint4* recs, u64 nrecs, u64 first_tile, 
   return (u32)__shfl((int)last, WAVE - 1, WAVE);
 }
 
-__global__ void __launch_bounds__(BLOCK_THREADS) k_enc_lasthead(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 nseg, u64* lasthead)
+// The three segment kernels cover the segments [seg_first, seg_end) and index `recs` and the per-segment arrays by GLOBAL
+// record / segment numbers: an output-range slice (one GPU's share of the result) passes the addresses of its local buffers
+// minus the offsets of its first record / segment.  `carry` = (last head before the first segment of the launch) + 1 as
+// known from the slices before (0 for the whole index): the run that is open at the slice boundary started there.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_enc_lasthead(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 seg_first, u64 seg_end, u64* lasthead)
 {
-  u64 seg = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
-  if(seg >= nseg) { return; }
+  u64 seg = seg_first + (((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6);
+  if(seg >= seg_end) { return; }
   u64 first = seg * SEG_TILES;
   u32 carry = (first == 0 ? 0u : symbol_at(recs, (first << 6) - 1));
   u64 best = NONE;
@@ -164,14 +168,15 @@ __device__ inline void for_each_long_event(const TileInfo& ti, u64 first_tile, u
   }
 }
 
-__global__ void __launch_bounds__(BLOCK_THREADS) k_enc_size(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 nseg,
-  const u64* prevhead, u32* table)
+__global__ void __launch_bounds__(BLOCK_THREADS) k_enc_size(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 seg_first, u64 seg_end,
+  const u64* prevhead, u64 head_carry, u32* table)
 {
-  u64 seg = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
-  if(seg >= nseg) { return; }
+  u64 seg = seg_first + (((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6);
+  if(seg >= seg_end) { return; }
   u64 first = seg * SEG_TILES;
   u32 carry = (first == 0 ? 0u : symbol_at(recs, (first << 6) - 1));
   u64 last = prevhead[seg];          // (last head before the segment) + 1, wave-uniform
+  if(head_carry > last) { last = head_carry; }
   u64 acc = 0;                       // bytes emitted so far under hypothesis "start offset = lane"
   const u32 o = lane_id();
   for(int k = 0; k < SEG_CHUNKS; k++)
@@ -218,11 +223,20 @@ __global__ void __launch_bounds__(WAVE) k_fold_group(const u32* table, u64 nseg,
   group_table[g * 64 + o] = acc;
 }
 
-// Fold 2: sequential pass over the groups from offset 0; group_base[ngroups] = total bytes.
-__global__ void __launch_bounds__(WAVE) k_fold_top(const u64* group_table, u64 ngroups, u64* group_base)
+// Fold 1b (output-range slices): composition of all group tables of a slice: bytes the slice emits as a function of the offset
+// it starts at (mod 64) -- what travels to the other GPUs.
+__global__ void __launch_bounds__(WAVE) k_fold_slice(const u64* group_table, u64 ngroups, u64* slice_table)
+{
+  u64 acc = 0; u32 o = lane_id();
+  for(u64 g = 0; g < ngroups; g++) { acc += group_table[g * 64 + ((o + acc) & 63)]; }
+  slice_table[o] = acc;
+}
+
+// Fold 2: sequential pass over the groups from the byte offset `start` (0 for the whole index); group_base[ngroups] = end offset.
+__global__ void __launch_bounds__(WAVE) k_fold_top(const u64* group_table, u64 ngroups, u64 start, u64* group_base)
 {
   if(threadIdx.x != 0) { return; }
-  u64 off = 0;
+  u64 off = start;
   for(u64 g = 0; g < ngroups; g++) { group_base[g] = off; off += group_table[g * 64 + (off & 63)]; }
   group_base[ngroups] = off;
 }
@@ -240,7 +254,7 @@ __global__ void __launch_bounds__(WAVE) k_fold_seg(const u32* table, u64 nseg, c
 // The launch covers the segments [seg_first, seg_end): the pipelined download copies the bytes of one range to the
 // host while the next range is written.
 __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 seg_first, u64 seg_end,
-  const u64* prevhead, const u64* seg_base, u8* out, u64* block_start)
+  const u64* prevhead, u64 head_carry, const u64* seg_base, u8* out, u64* block_start)
 {
   __shared__ __attribute__((aligned(16))) u8 stage[BLOCK_THREADS / WAVE][4096 + 32];
   u64 seg = seg_first + (((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6);
@@ -248,6 +262,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
   u64 first = seg * SEG_TILES;
   u32 carry = (first == 0 ? 0u : symbol_at(recs, (first << 6) - 1));
   u64 last = prevhead[seg];
+  if(head_carry > last) { last = head_carry; }
   u64 off = seg_base[seg];           // wave-uniform byte offset
   for(int k = 0; k < SEG_CHUNKS; k++)
   {

@@ -113,16 +113,19 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_interleave_sup(IndexView A, I
   (void)n_out;
 }
 
+// The launch covers the chunks [chunk_first, chunk_end) and writes the records [q_lo, q_hi) among them (an output-range
+// slice also wants the one record before its range: the encoder looks at the symbol there).  recs_out is indexed by the
+// GLOBAL record number: a slice passes its buffer's address minus the offset of its first record.
 __global__ void __launch_bounds__(BLOCK_THREADS) k_interleave(IndexView A, IndexView B, const u64* bits, const u64* chunk_base,
-  u64 nchunks, const u64* sup_out, uint4* recs_out, u64 nrecs_out)
+  u64 chunk_first, u64 chunk_end, u64 q_lo, u64 q_hi, const u64* sup_out, uint4* recs_out)
 {
-  u64 chunk = ((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6;
-  if(chunk >= nchunks) { return; }
+  u64 chunk = chunk_first + (((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6);
+  if(chunk >= chunk_end) { return; }
   u64 q = chunk * 64 + lane_id();
   u64 m0 = bits[2 * q], m1 = bits[2 * q + 1];
   u64 mine = (u64)__builtin_popcountll(m0) + (u64)__builtin_popcountll(m1);
   u64 incl = wave_incl_sum(mine);
-  if(q >= nrecs_out) { return; }
+  if(q < q_lo || q >= q_hi) { return; }
   u64 b_off = chunk_base[chunk] + incl - mine;
   u64 a_off = (q << REC_SHIFT) - b_off;
 

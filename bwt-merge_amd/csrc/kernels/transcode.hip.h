@@ -415,6 +415,26 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_block_cum(IndexView x, const 
   cum[1 * stride + b] = r[1]; cum[2 * stride + b] = r[2]; cum[3 * stride + b] = r[3]; cum[4 * stride + b] = r[4]; cum[5 * stride + b] = r[5];
 }
 
+// The same for an output-range slice whose records start at position `slice_start`: a block whose opening run began before
+// the slice (it belongs to the slice because the run ENDS there) is answered from the counts at the slice start and the
+// symbol of that run (the symbol at slice_start - 1), without the records of the slices before.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_block_cum_slice(IndexView x, const u64* block_start, u64 first, u64 count, u64* cum, u64 stride,
+  u64 slice_start, u32 run_symbol)
+{
+  u64 b = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(b >= count) { return; }
+  const u64 p = block_start[first + b];
+  u64 r[6]; index_ranks(x, (p < slice_start ? slice_start : p), r);
+  if(p < slice_start && run_symbol != 0)
+  {
+    const u64 d = slice_start - p;
+    r[1] -= (run_symbol == 1 ? d : 0); r[2] -= (run_symbol == 2 ? d : 0); r[3] -= (run_symbol == 3 ? d : 0);
+    r[4] -= (run_symbol == 4 ? d : 0); r[5] -= (run_symbol == 5 ? d : 0);
+  }
+  cum[0 * stride + b] = p - (r[1] + r[2] + r[3] + r[4] + r[5]);
+  cum[1 * stride + b] = r[1]; cum[2 * stride + b] = r[2]; cum[3 * stride + b] = r[3]; cum[4 * stride + b] = r[4]; cum[5 * stride + b] = r[5];
+}
+
 //------------------------------------------------------------------------------
 // Plain symbols (one byte each) -> records.  k_sym_counts: per-record symbol counts
 // (cnt[c * stride + q], c = 1..5 used); after an exclusive scan k_sym_recs writes the records.

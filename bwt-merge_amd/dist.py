@@ -2,10 +2,18 @@
 
 The path shards over the sequences of the second input (every LF chain is independent; the
 reference hands out sequence blocks to threads the same way, fmi.cpp:355-357).  Every rank
-searches its contiguous block, then ONE exchange combines the rank-array shards: each rank
+searches its contiguous block, then ONE bulk exchange combines the rank-array shards: each rank
 has set a disjoint subset of the bits of the interleaving bitvector, so an all-reduce with
 SUM over 64-bit words equals the bitwise OR (no carries).
+
+After the exchange every rank interleaves and encodes only its own range of the OUTPUT (mergeBWT
+cut by output position, bwt.cpp:215-282).  Two facts cross a slice boundary and travel as two tiny
+all-gathers (exchange_encoder_carries): the run that is still open at the boundary, and the byte
+offset modulo 64 that Run::write's block rule depends on (support.h:256-282).
+
+(The C++ host in csrc/host/multi_gpu.h does the same with one thread per GPU and librccl directly.)
 """
+import numpy as np
 
 
 def get_bounds(first, last, blocks):
@@ -39,3 +47,65 @@ def exchange_bitvector(words, dist=None):
         import torch.distributed as dist
     dist.all_reduce(words, op=dist.ReduceOp.SUM)
     return words
+
+
+def fold_offsets(tables):
+    """offsets[g] = byte offset at which slice g starts, offsets[parts] = size of the stream (bwtm_fold_offsets):
+    tables[g][o] = bytes slice g emits when the stream is at offset o (mod 64) where it starts."""
+    off = 0
+    out = []
+    for row in tables:
+        out.append(off)
+        off += int(row[off & 63])
+    out.append(off)
+    return out
+
+
+def all_gather_u64(values, rank, world, dist, torch, device):
+    """All-gather of a small vector of unsigned 64-bit integers per rank -> [world, len(values)] numpy uint64."""
+    mine = np.asarray(values, dtype=np.uint64).reshape(-1)
+    if dist is None or world == 1:
+        return mine.reshape(1, -1)
+    t = torch.from_numpy(mine.view(np.int64).copy()).to(device)
+    out = torch.empty(world * mine.size, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, t)
+    return out.cpu().numpy().view(np.uint64).reshape(world, mine.size)
+
+
+def exchange_encoder_carries(lasthead, size_table_fn, rank, world, dist, torch, device):
+    """The encoder's two carries across output slices.
+    lasthead: this slice's (position of the last run head) + 1, 0 if none; size_table_fn(heads_before) -> 64 sizes.
+    Returns (heads_before, byte offset of this slice, size of the whole stream)."""
+    heads = all_gather_u64([lasthead], rank, world, dist, torch, device)[:, 0]
+    heads_before = int(heads[:rank].max()) if rank > 0 else 0
+    table = size_table_fn(heads_before)
+    tables = all_gather_u64(table, rank, world, dist, torch, device)
+    offsets = fold_offsets(tables)
+    return heads_before, offsets[rank], offsets[world]
+
+
+def merge_sharded(pkg, A, B, rank, world, dist, torch, device):
+    """FMI::FMI(a, b) on `world` GPUs, as this rank sees it: search of its block of b's sequences, all-reduce of the
+    rank-array bitvector (RCCL over xGMI), then interleave + encode of its own slice of the output.  Returns the
+    encoded pkg.Slice (total_nbytes = size of the whole merged stream)."""
+    nbytes = pkg.ra_buffer_bytes(A, B)
+    buf = torch.zeros(nbytes // 8, dtype=torch.int64, device=device)
+    torch.cuda.synchronize()
+    ra = pkg.RankArray(A, B, buf.data_ptr(), nbytes)
+    first, last = shard_range(B.sequences, rank, world)
+    if first <= last:
+        ra.search(A, B, first, last)
+    pkg.synchronize()
+    if dist is not None:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)              # disjoint bits: sum == or
+        torch.cuda.synchronize()
+    ra.finalize()
+    rec_first, rec_last = pkg.slice_bounds(pkg.merged_records(A, B), world, rank)
+    S = pkg.Slice(A, B, ra, rec_first, rec_last)
+    _, offset, total = exchange_encoder_carries(S.lasthead(), S.size_table, rank, world, dist, torch, device)
+    S.encode(offset)
+    S.total_nbytes = total
+    pkg.synchronize()
+    ra.free()
+    del buf
+    return S

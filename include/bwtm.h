@@ -214,6 +214,49 @@ int bwtm_merge_host(const bwtm_host_input* a, const bwtm_host_input* b, bwtm_all
 int bwtm_merge_host_chained(bwtm_index* a, const bwtm_host_input* b, bwtm_alloc_fn alloc, void* user,
                             int want_samples, bwtm_host_output* out, bwtm_index** keep);
 
+/* --- the result sharded by output range (one slice per GPU) --------------------------------------------
+
+   After the rank-array exchange every GPU holds the whole interleaving bitvector, so each can interleave and
+   encode its own range of OUTPUT RECORDS (128 positions each) of mergeBWT (bwt.cpp:215-282).  Two facts cross a
+   slice boundary and are exchanged as a few words (all-gather):
+     * the run RunBuffer (utils.h:121-142) is still extending at the boundary: bwtm_slice_lasthead() of every slice
+       -> heads_before of slice g = max over the slices before g;
+     * array.size() % 64 in Run::write (support.h:256-282): bwtm_slice_size_table() = bytes the slice emits as a
+       function of the byte offset it starts at, mod 64 -> bwtm_fold_offsets() over all slices gives every slice its
+       exact byte offset in the merged stream.
+   The concatenation of the slices' bytes (and samples) is bit-identical to bwtm_index_encode() of the whole. */
+
+typedef struct bwtm_slice bwtm_slice;
+
+uint64_t bwtm_merged_records(const bwtm_index* a, const bwtm_index* b);        /* output records of merging a and b */
+/* Part `part` of `parts` near-equal ranges of whole 512-record encoder segments (getBounds, utils.cpp:169-187). */
+int bwtm_slice_bounds(uint64_t nrecs, int parts, int part, uint64_t* rec_first, uint64_t* rec_last);
+/* mergeBWT for the output records [rec_first, rec_last) (bounds from bwtm_slice_bounds). */
+int bwtm_interleave_range(const bwtm_index* a, const bwtm_index* b, bwtm_ra* ra, uint64_t rec_first, uint64_t rec_last,
+                          bwtm_slice** out);
+void bwtm_slice_free(bwtm_slice* slice);
+/* (position of the slice's last run head) + 1; 0 = the slice has none. */
+int bwtm_slice_lasthead(bwtm_slice* slice, uint64_t* lasthead);
+/* table[o] = bytes the slice emits when the stream is at offset o (mod 64) where the slice starts. */
+int bwtm_slice_size_table(bwtm_slice* slice, uint64_t heads_before, uint64_t table[64]);
+/* offsets[g] = byte offset of slice g, offsets[parts] = size of the stream; tables = [parts][64].  Pure host arithmetic. */
+int bwtm_fold_offsets(const uint64_t* tables, int parts, uint64_t* offsets);
+/* Run::write for the slice's runs, starting at its byte offset; block starts of BWT::build for its blocks. */
+int bwtm_slice_encode(bwtm_slice* slice, uint64_t byte_offset);
+uint64_t bwtm_slice_byte_first(const bwtm_slice* slice);
+uint64_t bwtm_slice_bytes(const bwtm_slice* slice);
+uint64_t bwtm_slice_block_first(const bwtm_slice* slice);      /* blocks whose first byte the slice emitted */
+uint64_t bwtm_slice_blocks(const bwtm_slice* slice);
+/* Sequence position at which the slice's first block starts (~0 if it has no block): the slice before it needs
+   it for the end of its last block. */
+int bwtm_slice_first_block_start(bwtm_slice* slice, uint64_t* position);
+int bwtm_slice_download_data(bwtm_slice* slice, uint8_t* out, uint64_t capacity);
+/* block_end[blocks] and cum[6][blocks] (row-major, this slice's blocks only); next_block_start = first block
+   start of the next non-empty slice, or bases of the merged index for the last one. */
+int bwtm_slice_download_samples(bwtm_slice* slice, uint64_t next_block_start, uint64_t* block_end, uint64_t* cum);
+/* Plain symbols of positions inside the slice. */
+int bwtm_slice_extract(bwtm_slice* slice, uint64_t first, uint64_t count, uint8_t* out);
+
 /* --- measurement ----------------------------------------------------------------------------- */
 
 /* When enabled, every kernel launch is bracketed by HIP events on the context's compute stream. */

@@ -70,3 +70,83 @@ def test_two_rank_exchange_equals_full_rank_array(tmp_path, oracle):
     for r in range(world):
         got = np.unpackbits(np.load(tmp_path / ("bits_%d.npy" % r)).view(np.uint8), bitorder="little")[: expect.size]
         assert np.array_equal(got, expect)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The encoder's carries across output slices (bwt-merge_amd/dist.py: exchange_encoder_carries), with a plain CPU
+# statement of what a slice computes: its run heads, the bytes Run::write emits for the runs that END in it.
+
+def _slice_events(sym, p0, p1, heads_before):
+    """Runs (symbol, length) that end at a head inside [p0, p1) (the virtual head at len(sym) belongs to the last slice),
+    and the slice's (last head) + 1."""
+    n = sym.size
+    heads = [h for h in range(p0, min(p1, n + 1)) if h == 0 or h == n or sym[h] != sym[h - 1]]
+    events, prev1 = [], heads_before
+    for h in heads:
+        if h > 0:
+            events.append((int(sym[h - 1]), h + 1 - prev1 if prev1 > 0 else h))
+        prev1 = h + 1
+    return events, (heads[-1] + 1 if heads else 0)
+
+
+def _slice_table(orc, events):
+    table = np.zeros(64, dtype=np.uint64)
+    for o in range(64):
+        off = o
+        for comp, length in events:
+            off += len(orc.run_write(comp, length, prefill=off % 64))
+        table[o] = off - o
+    return table
+
+
+def _slice_symbols():
+    rng = np.random.default_rng(99)
+    syms = rng.integers(0, 6, 400)
+    lens = rng.choice([1, 1, 2, 3, 41, 42, 43, 170, 3000], 400)
+    return np.repeat(syms.astype(np.uint8), lens)
+
+
+def _carry_worker(rank, world, port, result_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import _pkg
+    _pkg.load()
+    from bwt_merge_amd.dist import exchange_encoder_carries
+    from oracle import oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sym = _slice_symbols()
+    cut = [0, 37 * 128, sym.size + 1][rank: rank + 2]                 # two slices of whole records, the cut inside a long run or not
+    _, lasthead = _slice_events(sym, cut[0], cut[1], 0)
+    def table_fn(heads_before):
+        return _slice_table(orc, _slice_events(sym, cut[0], cut[1], heads_before)[0])
+    heads_before, offset, total = exchange_encoder_carries(lasthead, table_fn, rank, world, dist, torch, "cpu")
+    # this slice's bytes, written at its offset
+    data = bytearray()
+    off = offset
+    for comp, length in _slice_events(sym, cut[0], cut[1], heads_before)[0]:
+        piece = orc.run_write(comp, length, prefill=off % 64)
+        data += piece; off += len(piece)
+    np.save(os.path.join(result_dir, "slice_%d.npy" % rank), np.frombuffer(bytes(data), dtype=np.uint8))
+    np.save(os.path.join(result_dir, "meta_%d.npy" % rank), np.array([offset, total], dtype=np.uint64))
+    dist.destroy_process_group()
+
+
+def test_two_rank_encoder_carries_concatenate_to_the_whole_stream(tmp_path, oracle):
+    world = 2
+    mp.start_processes(_carry_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    whole = oracle.FMI.from_symbols(_slice_symbols()).data
+    parts = [np.load(tmp_path / ("slice_%d.npy" % r)) for r in range(world)]
+    metas = [np.load(tmp_path / ("meta_%d.npy" % r)) for r in range(world)]
+    assert int(metas[0][0]) == 0 and int(metas[1][0]) == parts[0].size
+    assert all(int(m[1]) == whole.size for m in metas)
+    assert np.array_equal(np.concatenate(parts), whole)
+
+
+def test_fold_offsets_binding_matches_host_logic(bwtm):
+    from bwt_merge_amd.dist import fold_offsets
+    rng = np.random.default_rng(3)
+    tables = rng.integers(0, 1000, (5, 64)).astype(np.uint64)
+    assert [int(x) for x in bwtm.fold_offsets(tables)] == fold_offsets(tables)
+    assert bwtm.slice_bounds(5000, 3, 1) == (1536, 3072) and bwtm.slice_bounds(300, 4, 0) == (0, 0) and bwtm.slice_bounds(300, 4, 3) == (0, 300)

@@ -24,10 +24,21 @@ def test_bench_single_gpu_small(bwtm):
     # at this size bwtm_search picks the per-chain walk; config 2 runs the frontier search
     assert d["roofline"]["kernel"] in ("k_lf_walk_binned", "k_frontier_step") and d["roofline"]["bound"] == "hbm"
     assert d["cpu_baseline"]["gpu_parity_on_sample"] is True and d["cpu_baseline"]["kind"] == "port"
+    assert d["verification"]["frontier_equals_walk"] is True and d["verification"]["extracted_reads_count"] >= 10000
+    h = d["host_to_host"]
+    assert h["value"] > 0 and h["value"] < d["value"] and h["pcie"]["h2d_GBs"] > 1 and h["bytes"]["d2h_data"] == d["config"]["native_bytes"][2]
+
+
+def test_bench_mixed_read_lengths(bwtm):
+    """BASELINE config 5's read mix (100 / 150 bp, half of the bases each) through ragged leaves."""
+    d = run_bench([sys.executable, "bench.py", "--workload", "mixed", "--reads", "150000", "--steps", "1", "--warmup", "1", "--cpu-sample-reads", "10000",
+                   "--no-host"])
+    assert d["verified"] is True and d["cpu_baseline"]["gpu_parity_on_sample"] is True
+    assert d["config"]["bases"][0] == 150000 // 5 * (3 * 101 + 2 * 151)
 
 
 def test_bench_distributed_path_on_one_rank(bwtm):
     d = run_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                    "--master-port", "29517", "bench.py", "--gpus", "1", "--force-dist", "--reads", "200000", "--steps", "2", "--warmup", "1",
                    "--no-cpu-baseline"])
-    assert d["verified"] is True and d["value"] > 0
+    assert d["value"] > 0 and d["config"]["native_bytes"][2] > 0

@@ -35,3 +35,33 @@ def test_leaf_bwt_with_duplicate_reads(synth, oracle):
     got = synth.leaf_bwt(reads).numpy()
     text = np.concatenate([np.concatenate([r.numpy(), [0]]) for r in reads]).astype(np.uint8)
     assert np.array_equal(got, oracle.FMI.from_text(text).symbols)
+
+
+def test_ragged_leaf_bwt_matches_brute_force(synth, oracle):
+    """Reads of different lengths in one leaf (what PlainData::read ingests, formats.cpp:133-161): the mixed 100 / 150 bp
+    workload of BASELINE config 5 and arbitrary lengths, including empty reads."""
+    n = 300
+    reads = synth.make_reads("mixed", 77, 40, n, 100, 1000)
+    lens = synth.read_lengths("mixed", 40, n, 100)
+    assert int((lens == 100).sum()) * 100 == pytest.approx(int((lens == 150).sum()) * 150, rel=0.05)      # half of the bases each
+    long_reads = oracle.generate_reads(77, n, 150, first_read=40).reshape(n, 151)
+    text = np.concatenate([np.concatenate([long_reads[j, :int(lens[j])], [0]]) for j in range(n)]).astype(np.uint8)
+    assert np.array_equal(synth.leaf_bwt(reads, lens).numpy(), oracle.FMI.from_text(text).symbols)
+    assert np.array_equal(synth.leaf_symbols("mixed", 77, 40, n, 100, 1000, "cpu").numpy(), oracle.FMI.from_text(text).symbols)
+    rng = np.random.default_rng(1)
+    lens = torch.from_numpy(rng.integers(0, 31, 120))
+    base = synth.generate_reads(9, 0, 120, 30)
+    t = torch.arange(30).unsqueeze(0)
+    reads = torch.where(t < lens.unsqueeze(1), base, torch.zeros_like(base))
+    text = np.concatenate([np.concatenate([base[j, :int(lens[j])].numpy(), [0]]) for j in range(120)]).astype(np.uint8)
+    assert np.array_equal(synth.leaf_bwt(reads, lens).numpy(), oracle.FMI.from_text(text).symbols)
+
+
+def test_reads_matrix_regenerates_single_reads(synth):
+    ids = np.array([0, 3, 4, 1000, 7])
+    m = synth.reads_matrix("mixed", 1001, ids, 100, 5000, 152)
+    assert list((m != 0).sum(axis=1)) == [100, 150, 150, 100, 100]
+    full = synth.make_reads("mixed", 1001, 0, 1001, 100, 5000).numpy()
+    assert np.array_equal(m[:, :150], full[ids])
+    g = synth.reads_matrix("iid", 1002, ids, 100, 5000, 102)
+    assert np.array_equal(g[:, :100], synth.generate_reads(1002, 0, 1001, 100).numpy()[ids])
