@@ -219,11 +219,10 @@ def main():
 
     # ---------------------------------------------------------------- host to host (SURVEY 8(d)'s T), rank 0 at N == 1
     host = None
+    dev_in.clear()                                   # the device copies of the inputs are not needed any more
+    torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_host:
         host = host_to_host(pkg, np, torch, dev, host_in, meta, args)
-    for t in dev_in:
-        del t
-    dev_in = []
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N == 1)
     cpu = None
@@ -343,6 +342,7 @@ def host_to_host(pkg, np, torch, dev, host_in, meta, args):
     sample_bytes = 8 * blocks + 48 * (blocks + 1)
     floor_ms = (in_bytes / (cal["h2d_GBs"] * 1e9) + (out_bytes + sample_bytes) / (cal["d2h_GBs"] * 1e9)) * 1e3
     host = {"value": round(merged / 1e9 / sec, 4), "unit": "Gbases/s", "ms_per_step": round(sec * 1e3, 2), "steps": len(times),
+            "ms_each": [round(t * 1e3, 1) for t in times],
             "includes": "H2D of both native inputs, transcode, search, interleave, encode, D2H of the native result and of its samples "
                         "(block_end + 6 cumulative arrays, 56 bytes per 64-byte block)",
             "phases_ms": {k: round(v, 2) for k, v in best.items()},

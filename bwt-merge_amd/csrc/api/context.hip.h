@@ -48,9 +48,17 @@ struct bwtm_context
   std::map<std::string, std::pair<double, uint64_t>> totals;
   std::vector<const char*> order;
 
-  // memory pool
+  // memory pool: released blocks by size (exact-size reuse is the fast path)
   std::multimap<u64, void*> free_blocks;
-  u64 cached_bytes = 0, held_bytes = 0, peak_bytes = 0;     // held = obtained from hipMalloc and not yet hipFree'd
+  u64 cached_bytes = 0, held_bytes = 0, peak_bytes = 0;     // held = physical memory obtained from the driver and not yet returned
+  // large blocks live in a reserved virtual address range and are backed by pooled physical chunks (see the pool below)
+  struct VBlock { u64 bytes = 0; std::vector<hipMemGenericAllocationHandle_t> chunks; hipEvent_t released = nullptr; };
+  bool vmm = false;
+  char* va_base = nullptr; u64 va_size = 0;
+  std::map<u64, u64> va_free;                               // offset -> size of the free address ranges
+  std::vector<hipMemGenericAllocationHandle_t> free_chunks; // physical chunks that are not mapped anywhere
+  std::map<void*, VBlock> vblocks;                          // every mapped block, in use or released
+  u64 device_total = 0;
 
   // small page-locked scratch for results read back by the host (a pageable destination would make
   // hipMemcpyAsync stage and block)
@@ -96,6 +104,9 @@ thread_local bwtm_context* t_ctx = nullptr;          // the context of the API c
 
 #define TRY(expr) do { int rc_ = (expr); if(rc_ != BWTM_OK) { return rc_; } } while(0)
 
+void vmm_setup(bwtm_context* c);
+void pool_trim(bwtm_context* c);
+
 int context_setup(bwtm_context* c, int device)
 {
   int count = 0;
@@ -107,6 +118,7 @@ int context_setup(bwtm_context* c, int device)
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   HIP_TRY(hipHostMalloc((void**)&c->host_scratch, 64 * sizeof(u64), hipHostMallocDefault));
+  vmm_setup(c);
   // Kernels that take more than the default 64 KiB of dynamic LDS (a per-device attribute).
   HIP_TRY(hipFuncSetAttribute((const void*)k_part_scatter_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void*)k_lf_walk_binned<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024));
@@ -125,8 +137,8 @@ void context_teardown(bwtm_context* c)
   if(c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); }
   for(auto& p : c->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
   c->pending.clear();
-  for(auto& kv : c->free_blocks) { (void)hipFree(kv.second); }
-  c->free_blocks.clear();
+  pool_trim(c);
+  if(c->va_base) { (void)hipMemAddressFree(c->va_base, c->va_size); c->va_base = nullptr; }
   if(c->host_scratch) { (void)hipHostFree(c->host_scratch); }
   if(c->stream) { (void)hipStreamDestroy(c->stream); }
   if(c->copy_stream) { (void)hipStreamDestroy(c->copy_stream); }
@@ -220,6 +232,20 @@ void profile_collect()
 
 //------------------------------------------------------------------------------
 // Pool.
+//
+// Small blocks come from hipMalloc and are reused by size.  Blocks of VMM_MIN bytes and more live in a virtual address
+// range reserved once per context and are backed by physical chunks of VMM_CHUNK bytes (hipMemCreate / hipMemMap): a
+// released block keeps its mapping and is handed out again when a block of (nearly) the same size is asked for -- the
+// steady state of a repeated merge, no driver call at all -- but when nothing fits, the chunks of released blocks of ANY
+// size are unmapped and mapped into the new block.  Memory therefore moves between buffers of different sizes (the
+// 38 GB native inputs of one phase become part of the 76 GB native output of a later one) without hipFree / hipMalloc:
+// on MI355X a hipMalloc that has to wait for deferred frees takes seconds (measured at 2 x 50 Gbase: 4.7 s of a 6.1 s
+// merge), mapping 32 GiB of pooled chunks takes about a millisecond (tools/microbench_vmm.hip).
+// A released block may still be in use by kernels queued before its release; exact-size reuse relies on stream order
+// (all work runs on the context's compute stream), unmapping waits for the event recorded at the release.
+
+constexpr u64 VMM_CHUNK = 128ull << 20;
+constexpr u64 VMM_MIN = 128ull << 20;
 
 u64 pool_round(u64 n)
 {
@@ -228,30 +254,193 @@ u64 pool_round(u64 n)
   return (n + g - 1) / g * g;
 }
 
+// BWTM_TRACE=1 in the environment: slow paths of the pool report to stderr.
+bool trace_enabled()
+{
+  static const bool on = (std::getenv("BWTM_TRACE") != nullptr);
+  return on;
+}
+
+double trace_now()
+{
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+void vmm_setup(bwtm_context* c)
+{
+  const char* env = std::getenv("BWTM_POOL_VMM");
+  if(env && env[0] == '0') { return; }
+  size_t free_b = 0, total_b = 0;
+  if(hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
+  c->device_total = total_b;
+  u64 want = ((u64)total_b * 4 + VMM_CHUNK - 1) / VMM_CHUNK * VMM_CHUNK;
+  void* va = nullptr;
+  if(hipMemAddressReserve(&va, want, VMM_CHUNK, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return; }
+  c->va_base = (char*)va; c->va_size = want;
+  c->va_free[0] = want;
+  c->vmm = true;
+}
+
+// Address range of `bytes` (first fit); ~0 when the reserved range is exhausted.
+u64 va_take(bwtm_context* c, u64 bytes)
+{
+  for(auto it = c->va_free.begin(); it != c->va_free.end(); ++it)
+  {
+    if(it->second >= bytes)
+    {
+      const u64 off = it->first, rest = it->second - bytes;
+      c->va_free.erase(it);
+      if(rest > 0) { c->va_free[off + bytes] = rest; }
+      return off;
+    }
+  }
+  return ~0ull;
+}
+
+void va_give(bwtm_context* c, u64 off, u64 bytes)
+{
+  auto next = c->va_free.lower_bound(off);
+  if(next != c->va_free.begin())
+  {
+    auto prev = std::prev(next);
+    if(prev->first + prev->second == off) { off = prev->first; bytes += prev->second; c->va_free.erase(prev); }
+  }
+  if(next != c->va_free.end() && off + bytes == next->first) { bytes += next->second; c->va_free.erase(next); }
+  c->va_free[off] = bytes;
+}
+
+// Unmaps a released block and returns its chunks to the chunk pool (the caller has made sure the GPU is done with it).
+void vmm_unmap(bwtm_context* c, void* p)
+{
+  auto it = c->vblocks.find(p);
+  if(it == c->vblocks.end()) { return; }
+  (void)hipMemUnmap(p, it->second.bytes);
+  for(auto h : it->second.chunks) { c->free_chunks.push_back(h); }
+  if(it->second.released) { (void)hipEventDestroy(it->second.released); }
+  va_give(c, (u64)((char*)p - c->va_base), it->second.bytes);
+  c->vblocks.erase(it);
+}
+
+// Moves the chunks of released blocks into the chunk pool until it holds `need` chunks.  wait = false: only blocks whose
+// release event has completed; wait = true: synchronises the compute stream first (then all of them have).
+void vmm_harvest(bwtm_context* c, u64 need, bool wait)
+{
+  if(c->free_chunks.size() >= need) { return; }
+  if(wait && c->stream) { (void)hipStreamSynchronize(c->stream); }
+  for(auto it = c->free_blocks.end(); it != c->free_blocks.begin() && c->free_chunks.size() < need; )     // largest first
+  {
+    --it;
+    auto vb = c->vblocks.find(it->second);
+    if(vb == c->vblocks.end()) { continue; }                  // a small hipMalloc block
+    if(!wait && vb->second.released && hipEventQuery(vb->second.released) != hipSuccess) { (void)hipGetLastError(); continue; }
+    void* p = it->second;
+    c->cached_bytes -= it->first;
+    it = c->free_blocks.erase(it);
+    vmm_unmap(c, p);
+  }
+}
+
+hipError_t vmm_alloc(bwtm_context* c, u64 n, void** p)
+{
+  const u64 need = n / VMM_CHUNK;
+  const double t0 = trace_now();
+  u64 created = 0;
+  // Below 40 % of the device's memory the pool simply grows; above it, idle blocks are recycled before new chunks are created.
+  const bool recycle_first = (c->held_bytes + n > c->device_total / 10 * 4);
+  if(recycle_first) { vmm_harvest(c, need, false); }
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = c->device;
+  while(c->free_chunks.size() < need)
+  {
+    hipMemGenericAllocationHandle_t h;
+    if(hipMemCreate(&h, VMM_CHUNK, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+    c->free_chunks.push_back(h); created++;
+    c->held_bytes += VMM_CHUNK; if(c->held_bytes > c->peak_bytes) { c->peak_bytes = c->held_bytes; }
+  }
+  if(c->free_chunks.size() < need) { vmm_harvest(c, need, false); }
+  if(c->free_chunks.size() < need) { vmm_harvest(c, need, true); }
+  if(c->free_chunks.size() < need) { return hipErrorOutOfMemory; }
+  const u64 off = va_take(c, n);
+  if(off == ~0ull) { return hipErrorOutOfMemory; }
+  char* base = c->va_base + off;
+  bwtm_context::VBlock vb; vb.bytes = n;
+  hipError_t e = hipSuccess;
+  for(u64 k = 0; k < need && e == hipSuccess; k++)
+  {
+    hipMemGenericAllocationHandle_t h = c->free_chunks.back();
+    e = hipMemMap(base + k * VMM_CHUNK, VMM_CHUNK, 0, h, 0);
+    if(e == hipSuccess) { c->free_chunks.pop_back(); vb.chunks.push_back(h); }
+  }
+  if(e == hipSuccess)
+  {
+    hipMemAccessDesc acc = {};
+    acc.location.type = hipMemLocationTypeDevice; acc.location.id = c->device; acc.flags = hipMemAccessFlagsProtReadWrite;
+    e = hipMemSetAccess(base, n, &acc, 1);
+  }
+  if(e != hipSuccess)
+  {
+    (void)hipGetLastError();
+    if(!vb.chunks.empty()) { (void)hipMemUnmap(base, vb.chunks.size() * VMM_CHUNK); }
+    for(auto h : vb.chunks) { c->free_chunks.push_back(h); }
+    va_give(c, off, n);
+    return e;
+  }
+  c->vblocks[base] = std::move(vb);
+  *p = base;
+  if(trace_enabled() && (trace_now() - t0 > 1.0 || n >= (4ull << 30)))
+  {
+    fprintf(stderr, "[bwtm] map %.2f GB: %.2f ms (%llu new chunks; held %.1f GB, cached %.1f GB)\n", n / 1e9, trace_now() - t0, (unsigned long long)created,
+      c->held_bytes / 1e9, c->cached_bytes / 1e9);
+  }
+  return hipSuccess;
+}
+
 void pool_trim(bwtm_context* c)
 {
+  const double t0 = trace_now();
   if(c->stream) { (void)hipStreamSynchronize(c->stream); }
-  for(auto& kv : c->free_blocks) { (void)hipFree(kv.second); c->held_bytes -= kv.first; }
+  const u64 bytes = c->cached_bytes; const size_t blocks = c->free_blocks.size();
+  for(auto& kv : c->free_blocks)
+  {
+    if(c->vblocks.count(kv.second)) { vmm_unmap(c, kv.second); }
+    else { (void)hipFree(kv.second); c->held_bytes -= kv.first; }
+  }
   c->free_blocks.clear(); c->cached_bytes = 0;
+  for(auto h : c->free_chunks) { (void)hipMemRelease(h); c->held_bytes -= VMM_CHUNK; }
+  c->free_chunks.clear();
+  if(trace_enabled()) { fprintf(stderr, "[bwtm] trim: %zu blocks, %.2f GB, %.1f ms\n", blocks, bytes / 1e9, trace_now() - t0); }
 }
 
 hipError_t pool_get(bwtm_context* c, u64 n, void** p, u64* actual)
 {
   n = pool_round(n);
+  const bool large = (c->vmm && n >= VMM_MIN);
+  if(large) { n = (n + VMM_CHUNK - 1) / VMM_CHUNK * VMM_CHUNK; }
   auto it = c->free_blocks.lower_bound(n);
-  if(it != c->free_blocks.end() && it->first <= n + n / 8)
+  if(it != c->free_blocks.end() && it->first <= n + n / 8 && (c->vblocks.count(it->second) != 0) == large)
   {
     *p = it->second; *actual = it->first; c->cached_bytes -= it->first; c->free_blocks.erase(it);
     return hipSuccess;
   }
+  *actual = n;
+  if(large) { return vmm_alloc(c, n, p); }
   hipError_t e = hipMalloc(p, n);
   if(e != hipSuccess) { (void)hipGetLastError(); pool_trim(c); e = hipMalloc(p, n); }
   if(e == hipSuccess) { c->held_bytes += n; if(c->held_bytes > c->peak_bytes) { c->peak_bytes = c->held_bytes; } }
-  *actual = n;
   return e;
 }
 
-void pool_put(bwtm_context* c, void* p, u64 n) { c->free_blocks.insert(std::make_pair(n, p)); c->cached_bytes += n; }
+void pool_put(bwtm_context* c, void* p, u64 n)
+{
+  auto vb = c->vblocks.find(p);
+  if(vb != c->vblocks.end())
+  {
+    // kernels queued before this point may still use the block: whoever unmaps it waits for this event
+    if(!vb->second.released) { (void)hipEventCreateWithFlags(&vb->second.released, hipEventDisableTiming); }
+    if(vb->second.released) { (void)hipEventRecord(vb->second.released, c->stream); }
+  }
+  c->free_blocks.insert(std::make_pair(n, p)); c->cached_bytes += n;
+}
 
 // RAII device buffer (pooled).  Released into the pool of the context it came from; the release must happen
 // inside a Scope of that context (handles enter their own context before they are destroyed).
