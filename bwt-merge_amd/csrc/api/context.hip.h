@@ -54,8 +54,6 @@ struct bwtm_context
   // large blocks live in a reserved virtual address range and are backed by pooled physical chunks (see the pool below)
   struct VBlock { u64 bytes = 0; std::vector<hipMemGenericAllocationHandle_t> chunks; hipEvent_t released = nullptr; };
   bool vmm = false;
-  char* va_base = nullptr; u64 va_size = 0;
-  std::map<u64, u64> va_free;                               // offset -> size of the free address ranges
   std::vector<hipMemGenericAllocationHandle_t> free_chunks; // physical chunks that are not mapped anywhere
   std::map<void*, VBlock> vblocks;                          // every mapped block, in use or released
   u64 device_total = 0;
@@ -138,7 +136,6 @@ void context_teardown(bwtm_context* c)
   for(auto& p : c->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
   c->pending.clear();
   pool_trim(c);
-  if(c->va_base) { (void)hipMemAddressFree(c->va_base, c->va_size); c->va_base = nullptr; }
   if(c->host_scratch) { (void)hipHostFree(c->host_scratch); }
   if(c->stream) { (void)hipStreamDestroy(c->stream); }
   if(c->copy_stream) { (void)hipStreamDestroy(c->copy_stream); }
@@ -243,9 +240,17 @@ void profile_collect()
 // merge), mapping 32 GiB of pooled chunks takes about a millisecond (tools/microbench_vmm.hip).
 // A released block may still be in use by kernels queued before its release; exact-size reuse relies on stream order
 // (all work runs on the context's compute stream), unmapping waits for the event recorded at the release.
+// ADDRESSES ARE NEVER REUSED: on this ROCm release a virtual address that is unmapped and mapped again onto other physical
+// memory keeps its old translation in the shader TLBs (tools/vmm_stress.hip: kernels write through the stale mapping while
+// copy engines see the new one; neither hipDeviceSynchronize nor freeing and re-reserving the range helps), whereas fresh
+// addresses always work.  Blocks therefore take their addresses from a process-wide bump allocator over address ranges
+// reserved 8 TiB at a time (64 TiB can be reserved); when that is exhausted -- after the order of a hundred merges of
+// 2 x 50 Gbase, which consume addresses on every recycling -- the pool falls back to plain hipMalloc blocks.
 
-constexpr u64 VMM_CHUNK = 128ull << 20;
-constexpr u64 VMM_MIN = 128ull << 20;
+// Chunk size and the smallest block that takes this path; BWTM_POOL_VMM_CHUNK / BWTM_POOL_VMM_MIN (bytes) override them
+// (the test-suite runs once with small values so that every buffer of every test goes through map / unmap).
+u64 VMM_CHUNK = 128ull << 20;
+u64 VMM_MIN = 128ull << 20;
 
 u64 pool_round(u64 n)
 {
@@ -266,47 +271,50 @@ double trace_now()
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+struct AddressSpace
+{
+  std::mutex mu;
+  char* segment = nullptr; u64 segment_size = 0, used = 0;
+  u64 reserved_total = 0;
+  bool exhausted = false;
+};
+AddressSpace g_va;
+constexpr u64 VA_SEGMENT = 8ull << 40, VA_LIMIT = 64ull << 40;
+
 void vmm_setup(bwtm_context* c)
 {
   const char* env = std::getenv("BWTM_POOL_VMM");
   if(env && env[0] == '0') { return; }
+  if(const char* v = std::getenv("BWTM_POOL_VMM_CHUNK")) { u64 x = std::strtoull(v, nullptr, 10); if(x >= (2ull << 20)) { VMM_CHUNK = x / (2ull << 20) * (2ull << 20); } }
+  if(const char* v = std::getenv("BWTM_POOL_VMM_MIN")) { u64 x = std::strtoull(v, nullptr, 10); if(x >= 4096) { VMM_MIN = x; } }
   size_t free_b = 0, total_b = 0;
   if(hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
   c->device_total = total_b;
-  u64 want = ((u64)total_b * 4 + VMM_CHUNK - 1) / VMM_CHUNK * VMM_CHUNK;
-  void* va = nullptr;
-  if(hipMemAddressReserve(&va, want, VMM_CHUNK, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return; }
-  c->va_base = (char*)va; c->va_size = want;
-  c->va_free[0] = want;
   c->vmm = true;
 }
 
-// Address range of `bytes` (first fit); ~0 when the reserved range is exhausted.
-u64 va_take(bwtm_context* c, u64 bytes)
+// A fresh address range of `bytes` (a multiple of the chunk size); nullptr when no more addresses can be had.
+char* va_take(u64 bytes)
 {
-  for(auto it = c->va_free.begin(); it != c->va_free.end(); ++it)
+  std::lock_guard<std::mutex> lock(g_va.mu);
+  if(g_va.exhausted) { return nullptr; }
+  if(!g_va.segment || g_va.used + bytes > g_va.segment_size)
   {
-    if(it->second >= bytes)
+    // the rest of the old segment is abandoned; reservations are never freed (a freed range comes back at the same address)
+    u64 want = std::max(VA_SEGMENT, bytes);
+    void* va = nullptr;
+    if(g_va.reserved_total + want > VA_LIMIT || hipMemAddressReserve(&va, want, VMM_CHUNK, nullptr, 0) != hipSuccess)
     {
-      const u64 off = it->first, rest = it->second - bytes;
-      c->va_free.erase(it);
-      if(rest > 0) { c->va_free[off + bytes] = rest; }
-      return off;
+      (void)hipGetLastError();
+      g_va.exhausted = true;
+      if(trace_enabled()) { fprintf(stderr, "[bwtm] address space for mapped blocks exhausted after %.1f TiB: falling back to hipMalloc blocks\n", g_va.reserved_total / 1099511627776.0); }
+      return nullptr;
     }
+    g_va.segment = (char*)va; g_va.segment_size = want; g_va.used = 0; g_va.reserved_total += want;
   }
-  return ~0ull;
-}
-
-void va_give(bwtm_context* c, u64 off, u64 bytes)
-{
-  auto next = c->va_free.lower_bound(off);
-  if(next != c->va_free.begin())
-  {
-    auto prev = std::prev(next);
-    if(prev->first + prev->second == off) { off = prev->first; bytes += prev->second; c->va_free.erase(prev); }
-  }
-  if(next != c->va_free.end() && off + bytes == next->first) { bytes += next->second; c->va_free.erase(next); }
-  c->va_free[off] = bytes;
+  char* p = g_va.segment + g_va.used;
+  g_va.used += bytes;
+  return p;
 }
 
 // Unmaps a released block and returns its chunks to the chunk pool (the caller has made sure the GPU is done with it).
@@ -317,8 +325,7 @@ void vmm_unmap(bwtm_context* c, void* p)
   (void)hipMemUnmap(p, it->second.bytes);
   for(auto h : it->second.chunks) { c->free_chunks.push_back(h); }
   if(it->second.released) { (void)hipEventDestroy(it->second.released); }
-  va_give(c, (u64)((char*)p - c->va_base), it->second.bytes);
-  c->vblocks.erase(it);
+  c->vblocks.erase(it);                                       // the address range is not used again
 }
 
 // Moves the chunks of released blocks into the chunk pool until it holds `need` chunks.  wait = false: only blocks whose
@@ -360,9 +367,8 @@ hipError_t vmm_alloc(bwtm_context* c, u64 n, void** p)
   if(c->free_chunks.size() < need) { vmm_harvest(c, need, false); }
   if(c->free_chunks.size() < need) { vmm_harvest(c, need, true); }
   if(c->free_chunks.size() < need) { return hipErrorOutOfMemory; }
-  const u64 off = va_take(c, n);
-  if(off == ~0ull) { return hipErrorOutOfMemory; }
-  char* base = c->va_base + off;
+  char* base = va_take(n);
+  if(!base) { return hipErrorOutOfMemory; }
   bwtm_context::VBlock vb; vb.bytes = n;
   hipError_t e = hipSuccess;
   for(u64 k = 0; k < need && e == hipSuccess; k++)
@@ -382,7 +388,6 @@ hipError_t vmm_alloc(bwtm_context* c, u64 n, void** p)
     (void)hipGetLastError();
     if(!vb.chunks.empty()) { (void)hipMemUnmap(base, vb.chunks.size() * VMM_CHUNK); }
     for(auto h : vb.chunks) { c->free_chunks.push_back(h); }
-    va_give(c, off, n);
     return e;
   }
   c->vblocks[base] = std::move(vb);
@@ -417,13 +422,20 @@ hipError_t pool_get(bwtm_context* c, u64 n, void** p, u64* actual)
   const bool large = (c->vmm && n >= VMM_MIN);
   if(large) { n = (n + VMM_CHUNK - 1) / VMM_CHUNK * VMM_CHUNK; }
   auto it = c->free_blocks.lower_bound(n);
-  if(it != c->free_blocks.end() && it->first <= n + n / 8 && (c->vblocks.count(it->second) != 0) == large)
+  if(it != c->free_blocks.end() && it->first <= n + n / 8 && (!c->vmm || (c->vblocks.count(it->second) != 0) == large))
   {
     *p = it->second; *actual = it->first; c->cached_bytes -= it->first; c->free_blocks.erase(it);
     return hipSuccess;
   }
   *actual = n;
-  if(large) { return vmm_alloc(c, n, p); }
+  if(large)
+  {
+    hipError_t ve = vmm_alloc(c, n, p);
+    if(ve == hipSuccess || !g_va.exhausted) { return ve; }
+    // no addresses left for mapped blocks: give the pooled chunks back to the driver and go on with hipMalloc blocks
+    pool_trim(c);
+    c->vmm = false;
+  }
   hipError_t e = hipMalloc(p, n);
   if(e != hipSuccess) { (void)hipGetLastError(); pool_trim(c); e = hipMalloc(p, n); }
   if(e == hipSuccess) { c->held_bytes += n; if(c->held_bytes > c->peak_bytes) { c->peak_bytes = c->held_bytes; } }

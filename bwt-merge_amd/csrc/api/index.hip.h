@@ -72,7 +72,8 @@ int upload_queue(bwtm_index* x, const u8* host_src)
   TRY(x->flags.alloc(sizeof(u32), true));
   // the kernel fills columns [0, nblocks) / [0, ngroups); the extra column of each exclusive scan is zeroed here
   HIP_TRY(hipMemsetAsync(x->block_start.as<u64>() + x->nblocks, 0, sizeof(u64), CTX.stream));
-  HIP_TRY(hipMemset2DAsync(x->gcum.as<u64>() + x->ngroups, gstride * sizeof(u64), 0, sizeof(u64), 6, CTX.stream));
+  // (plain 1-D calls: the 2-D memset / memcpy entry points of the runtime reject the pool's mapped blocks)
+  for(u64 c = 0; c < 6; c++) { HIP_TRY(hipMemsetAsync(x->gcum.as<u64>() + c * gstride + x->ngroups, 0, sizeof(u64), CTX.stream)); }
   const u64 group_bytes = (u64)GROUP * RLE_BLOCK;
   u64 groups_per_chunk = (host_src ? std::max<u64>(1, (u64)g_tune.upload_chunk / group_bytes) : x->ngroups);
   if(host_src) { TRY(fork_copy_stream()); }           // x->data may be a recycled block with queued users
@@ -335,7 +336,10 @@ int download_samples(bwtm_index* x, u64* block_end, u64* cum)
       if(nbe > 0) { HIP_TRY(hipMemcpyAsync(block_end + b0, st, nbe * sizeof(u64), hipMemcpyDeviceToHost, CTX.copy_stream)); }
       if(!x->cum.p)
       {
-        HIP_TRY(hipMemcpy2DAsync(cum + b0, stride * sizeof(u64), st + CH, CH * sizeof(u64), cnt * sizeof(u64), 6, hipMemcpyDeviceToHost, CTX.copy_stream));
+        for(u64 c = 0; c < 6; c++)
+        {
+          HIP_TRY(hipMemcpyAsync(cum + c * stride + b0, st + CH + c * CH, cnt * sizeof(u64), hipMemcpyDeviceToHost, CTX.copy_stream));
+        }
       }
       HIP_TRY(hipEventRecord(drained[k], CTX.copy_stream));
     }
