@@ -1,8 +1,14 @@
 /*
   bwt.h -- host facade: class BWT with the reference's public surface (bwt.h:41-189).  The
-  run-length data and its samples live on the host as plain arrays (what block_boundaries and
-  samples[c] encode, bwt.h:172-178); scalar queries run on them.  The interleaving constructor
+  run-length data and its samples live on the host as flat page-locked arrays (what block_boundaries
+  and samples[c] encode, bwt.h:172-178); scalar queries run on them.  The interleaving constructor
   BWT(a, b, ra) (bwt.h:73, bwt.cpp:286-314) runs on the GPU through the C ABI (include/bwtm.h).
+
+  A BWT may also own a DEVICE COPY (the rank structure of the same sequence): the result of a merge
+  stays on the device as the next merge's first input (bwt_merge.cpp:167-173), and with
+  MergeParameters::lazy_host the host form is produced only when something asks for it
+  (materialize(): encode + one download), so `bwt_merge a b c d out` uploads every input once and
+  downloads once.
 */
 #ifndef BWTM_HOST_BWT_H
 #define BWTM_HOST_BWT_H
@@ -38,11 +44,10 @@ struct RankArray
   void clear()
   {
     if(handle) { bwtm_ra_free(handle); handle = nullptr; }
-    if(a) { bwtm_index_free(a); a = nullptr; }
-    if(b) { bwtm_index_free(b); b = nullptr; }
+    a = nullptr; b = nullptr;
   }
   bwtm_ra*    handle;
-  bwtm_index* a;       // device copies of the inputs the array was built for
+  bwtm_index* a;       // device copies of the inputs the array was built for (owned by the two BWT objects)
   bwtm_index* b;
 };
 
@@ -57,34 +62,48 @@ public:
   typedef std::array<range_type, SIGMA> rank_ranges_type;
 
   BWT() {}
+  ~BWT() { dropDevice(); }
+  // A copy shares nothing with the original: the host form is copied, the device copy is not.
+  BWT(const BWT& other) : header(other.header), data(other.hostData()), block_end(other.block_end), cum_flat(other.cum_flat), cum_stride(other.cum_stride) {}
+  BWT(BWT&& other) noexcept { swap(other); }
+  BWT& operator=(const BWT& other) { if(this != &other) { BWT copy(other); swap(copy); } return *this; }
+  BWT& operator=(BWT&& other) noexcept { if(this != &other) { BWT moved(std::move(other)); swap(moved); } return *this; }
 
   // Interleaves a and b according to ra; all inputs are destroyed (bwt.h:69-73).
   BWT(BWT& a, BWT& b, RankArray& ra)
   {
-    a.destroy(); b.destroy();
     gpuCheck(bwtm_ra_finalize(ra.handle), "BWT::BWT()");
     bwtm_index* merged = nullptr;
     gpuCheck(bwtm_interleave(ra.a, ra.b, ra.handle, &merged), "BWT::BWT()");
-    gpuCheck(bwtm_index_encode(merged), "BWT::BWT()");
     this->header.sequences = a.sequences() + b.sequences();
     this->header.bases = a.size() + b.size();
     this->header.setOrder(a.header.order());
-    this->download(merged);
-    bwtm_index_free(merged);
-    a.data.clear(); b.data.clear(); ra.clear();
+    a.clear(); b.clear(); ra.clear();                      // the device copies of the inputs go before the encoder needs memory
+    this->adopt(merged);
+    this->materialize();
   }
 
   void swap(BWT& other)
   {
     std::swap(header, other.header); data.swap(other.data); block_end.swap(other.block_end);
-    for(size_type c = 0; c < SIGMA; c++) { cumulative[c].swap(other.cumulative[c]); }
+    cum_flat.swap(other.cum_flat); std::swap(cum_stride, other.cum_stride);
+    std::swap(device, other.device); std::swap(host_current, other.host_current);
   }
 
   size_type size() const { return header.bases; }
   size_type sequences() const { return header.sequences; }
-  size_type bytes() const { return data.size(); }
-  size_type blocks() const { return block_end.size(); }
-  size_type count(comp_type c) const { return cumulative[c].empty() ? 0 : cumulative[c].back(); }
+  size_type bytes() const { materialize(); return data.size(); }
+  size_type blocks() const { materialize(); return block_end.size(); }
+  size_type count(comp_type c) const { materialize(); return cum_stride == 0 ? 0 : cum(c, cum_stride - 1); }
+
+  // samples[c].sum(k): occurrences of c in blocks [0, k)  (CumulativeArray::sum, support.h:338-343)
+  size_type cum(size_type c, size_type k) const { return cum_flat[c * cum_stride + k]; }
+  // The six sample arrays as vectors (tests, serialization).
+  std::vector<size_type> cumulative(size_type c) const
+  {
+    materialize();
+    return std::vector<size_type>(cum_flat.begin() + c * cum_stride, cum_flat.begin() + (c + 1) * cum_stride);
+  }
 
   // Number of occurrences of c in [0, i).
   size_type rank(size_type i, comp_type c) const
@@ -92,7 +111,7 @@ public:
     if(c >= SIGMA) { return 0; }
     if(i > size()) { i = size(); }
     Cursor cur = seek(i);
-    size_type result = cumulative[c][cur.block];
+    size_type result = cum(c, cur.block);
     while(cur.seq_pos < i)
     {
       range_type run = Run::read(data, cur.rle_pos);
@@ -108,7 +127,7 @@ public:
   {
     if(i > size()) { i = size(); }
     Cursor cur = seek(i);
-    for(size_type c = 1; c < SIGMA; c++) { results[c] = cumulative[c][cur.block]; }
+    for(size_type c = 1; c < SIGMA; c++) { results[c] = cum(c, cur.block); }
     while(cur.seq_pos < i)
     {
       range_type run = Run::read(data, cur.rle_pos);
@@ -136,7 +155,7 @@ public:
       range_type run = Run::read(data, cur.rle_pos);
       if(cur.seq_pos + run.second > i)
       {
-        return range_type(cumulative[run.first][cur.block] + local[run.first] + (i - cur.seq_pos), run.first);
+        return range_type(cum(run.first, cur.block) + local[run.first] + (i - cur.seq_pos), run.first);
       }
       local[run.first] += run.second; cur.seq_pos += run.second;
     }
@@ -147,8 +166,9 @@ public:
   {
     if(c >= SIGMA || i == 0) { return 0; }
     if(i > count(c)) { return size(); }
-    size_type block = (size_type)(std::lower_bound(cumulative[c].begin(), cumulative[c].end(), i) - cumulative[c].begin()) - 1;
-    size_type seen = cumulative[c][block], rle_pos = block * SAMPLE_RATE, seq_pos = block_start(block);
+    const size_type* row = cum_flat.data() + c * cum_stride;
+    size_type block = (size_type)(std::lower_bound(row, row + cum_stride, i) - row) - 1;
+    size_type seen = row[block], rle_pos = block * SAMPLE_RATE, seq_pos = block_start(block);
     while(true)
     {
       range_type run = Run::read(data, rle_pos);
@@ -191,15 +211,17 @@ public:
 
   void characterCounts(std::vector<size_type>& counts) const
   {
+    materialize();
     counts.assign(SIGMA, 0);
-    for(size_type rle_pos = 0; rle_pos < bytes(); ) { range_type run = Run::read(data, rle_pos); counts[run.first] += run.second; }
+    for(size_type rle_pos = 0; rle_pos < data.size(); ) { range_type run = Run::read(data, rle_pos); counts[run.first] += run.second; }
   }
 
   // FNV-1a over the decoded sequence, one byte per position.
   size_type hash() const
   {
+    materialize();
     size_type h = FNV_OFFSET_BASIS;
-    for(size_type rle_pos = 0; rle_pos < bytes(); )
+    for(size_type rle_pos = 0; rle_pos < data.size(); )
     {
       range_type run = Run::read(data, rle_pos);
       for(size_type k = 0; k < run.second; k++) { h = fnv1a_hash((byte_type)run.first, h); }
@@ -210,53 +232,96 @@ public:
   // Builds the samples from the data (BWT::build) and fills the header from the counts.
   void buildFromData(AlphabeticOrder order = AO_DEFAULT)
   {
-    block_end.clear();
-    for(size_type c = 0; c < SIGMA; c++) { cumulative[c].assign(1, 0); }
+    dropDevice(); host_current = true;
+    std::vector<size_type> ends;
+    std::vector<size_type> rows[SIGMA];
+    for(size_type c = 0; c < SIGMA; c++) { rows[c].assign(1, 0); }
     size_type seq_pos = 0, rle_pos = 0, totals[SIGMA] = {};
-    while(rle_pos < bytes())
+    while(rle_pos < data.size())
     {
       range_type run = Run::read(data, rle_pos);
       seq_pos += run.second; totals[run.first] += run.second;
-      if(rle_pos >= bytes() || rle_pos % SAMPLE_RATE == 0)
+      if(rle_pos >= data.size() || rle_pos % SAMPLE_RATE == 0)
       {
-        block_end.push_back(seq_pos - 1);
-        for(size_type c = 0; c < SIGMA; c++) { cumulative[c].push_back(totals[c]); }
+        ends.push_back(seq_pos - 1);
+        for(size_type c = 0; c < SIGMA; c++) { rows[c].push_back(totals[c]); }
       }
     }
+    block_end.assign(ends.begin(), ends.end());
+    cum_stride = ends.size() + 1;
+    cum_flat.resizeUninitialized(SIGMA * cum_stride);
+    for(size_type c = 0; c < SIGMA; c++) { std::copy(rows[c].begin(), rows[c].end(), cum_flat.begin() + c * cum_stride); }
     header.sequences = totals[0]; header.bases = seq_pos; header.setOrder(order);
   }
 
+  // Drops the samples (the reference's BWT::destroy, bwt.cpp:514-521).
   void destroy()
   {
     block_end.clear(); block_end.shrink_to_fit();
-    for(size_type c = 0; c < SIGMA; c++) { cumulative[c].clear(); cumulative[c].shrink_to_fit(); }
+    cum_flat.clear(); cum_flat.shrink_to_fit(); cum_stride = 0;
   }
 
-  // Uploads the data to the device and returns the handle (the caller frees it).
-  bwtm_index* upload(const std::vector<size_type>& C) const
+  // Drops everything: host bytes, samples, the device copy.
+  void clear() { destroy(); data.clear(); dropDevice(); host_current = true; }
+
+  //--------------------------------------------------------------------------
+  // Device side.
+
+  // The device copy of this BWT (uploaded on first use and kept: a chained merge, bwt_merge.cpp:167-173, or a
+  // verification after a merge finds it there).
+  bwtm_index* onDevice(const std::vector<size_type>& C) const
   {
-    bwtm_index* ix = nullptr;
-    uint64_t c_array[BWTM_SIGMA + 1];
-    for(size_type c = 0; c <= SIGMA; c++) { c_array[c] = C[c]; }
-    gpuCheck(bwtm_index_upload(data.data(), data.size(), sequences(), size(), c_array, &ix), "BWT::upload()");
-    return ix;
+    if(!device)
+    {
+      uint64_t c_array[BWTM_SIGMA + 1];
+      for(size_type c = 0; c <= SIGMA; c++) { c_array[c] = C[c]; }
+      gpuCheck(bwtm_index_upload(data.data(), data.size(), sequences(), size(), c_array, &device), "BWT::onDevice()");
+      gpuCheck(bwtm_index_drop_native(device), "BWT::onDevice()");          // the host holds the bytes
+    }
+    return device;
+  }
+  // Hands the device copy to the caller (who frees or consumes it); nullptr if there is none.
+  bwtm_index* releaseDevice() { bwtm_index* d = device; device = nullptr; return d; }
+  bool deviceResident() const { return device != nullptr; }
+  void dropDevice() const { if(device) { bwtm_index_free(device); device = nullptr; } }
+
+  // Takes over a merged device index; the host form is produced by materialize() when somebody asks for it.
+  void adopt(bwtm_index* merged)
+  {
+    dropDevice();
+    device = merged; host_current = false;
+    data.clear(); destroy();
   }
 
-  // Copies data and samples of an encoded device index into this object.
-  void download(bwtm_index* ix)
+  // Takes over the host form a bwtm_merge_host call has just written into this object's arrays.
+  void adoptHost(bwtm_index* kept, size_type nblocks)
   {
-    data.bytes.resize(bwtm_index_bytes(ix));
-    gpuCheck(bwtm_index_download_data(ix, data.bytes.data(), data.bytes.size()), "BWT::download()");
-    size_type nblocks = bwtm_index_blocks(ix);
-    block_end.resize(nblocks);
-    std::vector<uint64_t> cum(SIGMA * (nblocks + 1));
-    gpuCheck(bwtm_index_download_samples(ix, block_end.data(), cum.data()), "BWT::download()");
-    for(size_type c = 0; c < SIGMA; c++) { cumulative[c].assign(cum.begin() + c * (nblocks + 1), cum.begin() + (c + 1) * (nblocks + 1)); }
+    dropDevice();
+    device = kept; host_current = true; cum_stride = nblocks + 1;
   }
+
+  // Makes the host form current: encodes on the device, downloads data and samples (once).
+  void materialize() const
+  {
+    if(host_current) { return; }
+    gpuCheck(bwtm_index_encode(device), "BWT::materialize()");
+    data.bytes.resizeUninitialized(bwtm_index_bytes(device));
+    gpuCheck(bwtm_index_download_data(device, data.bytes.data(), data.bytes.size()), "BWT::materialize()");
+    size_type nblocks = bwtm_index_blocks(device);
+    block_end.resizeUninitialized(nblocks);
+    cum_stride = nblocks + 1;
+    cum_flat.resizeUninitialized(SIGMA * cum_stride);
+    gpuCheck(bwtm_index_download_samples(device, block_end.data(), cum_flat.data()), "BWT::materialize()");
+    gpuCheck(bwtm_index_drop_native(device), "BWT::materialize()");         // keep only the rank structure on the device
+    host_current = true;
+  }
+
+  const BlockArray& hostData() const { materialize(); return data; }
 
   // Native format (reference bwt.cpp:111-148; layout SURVEY.md Appendix B).
   void serialize(std::ostream& out) const
   {
+    materialize();
     header.serialize(out);
     size_type nbytes = data.size();
     sdsl_compat::write_member(nbytes, out);
@@ -264,44 +329,54 @@ public:
     size_type padded = data.blocks() * BlockArray::BLOCK_SIZE;
     std::vector<char> zeros(std::min(padded - nbytes, (size_type)1 << 20), 0);
     for(size_type left = padded - nbytes; left > 0; ) { size_type n = std::min(left, (size_type)zeros.size()); out.write(zeros.data(), n); left -= n; }
-    size_type nblocks = blocks();
+    size_type nblocks = block_end.size();
     for(size_type c = 0; c < SIGMA; c++)
     {
       // element k = (count of c in block k) zero bits followed by a one bit (support.h:290-294)
       std::vector<size_type> ones(nblocks);
-      for(size_type k = 0; k < nblocks; k++) { ones[k] = cumulative[c][k + 1] + k; }
+      for(size_type k = 0; k < nblocks; k++) { ones[k] = cum(c, k + 1) + k; }
       sdsl_compat::SDVector::serialize(out, count(c) + nblocks, ones);
       sdsl_compat::write_member(nblocks, out);                     // CumulativeArray::m_size
     }
-    sdsl_compat::SDVector::serialize(out, size(), block_end);
+    sdsl_compat::SDVector::serialize(out, size(), std::vector<size_type>(block_end.begin(), block_end.end()));
   }
 
   void load(std::istream& in)
   {
+    dropDevice(); host_current = true;
     header.load(in);
     if(!header.check()) { std::cerr << "BWT::load(): Invalid header!" << std::endl; std::exit(EXIT_FAILURE); }
     size_type nbytes = 0; sdsl_compat::read_member(nbytes, in);
-    data.bytes.resize(nbytes);
+    data.bytes.resizeUninitialized(nbytes);
     in.read((char*)data.bytes.data(), nbytes);
     in.ignore(data.blocks() * BlockArray::BLOCK_SIZE - nbytes);
+    std::vector<size_type> rows[SIGMA];
     for(size_type c = 0; c < SIGMA; c++)
     {
       size_type universe = 0, m_size = 0; std::vector<size_type> ones;
       sdsl_compat::SDVector::load(in, universe, ones);
       sdsl_compat::read_member(m_size, in);
-      cumulative[c].assign(ones.size() + 1, 0);
-      for(size_type k = 0; k < ones.size(); k++) { cumulative[c][k + 1] = ones[k] - k; }
+      rows[c].assign(ones.size() + 1, 0);
+      for(size_type k = 0; k < ones.size(); k++) { rows[c][k + 1] = ones[k] - k; }
     }
-    size_type universe = 0;
-    sdsl_compat::SDVector::load(in, universe, block_end);
+    cum_stride = rows[0].size();
+    cum_flat.resizeUninitialized(SIGMA * cum_stride);
+    for(size_type c = 0; c < SIGMA; c++) { std::copy(rows[c].begin(), rows[c].end(), cum_flat.begin() + c * cum_stride); }
+    size_type universe = 0; std::vector<size_type> ends;
+    sdsl_compat::SDVector::load(in, universe, ends);
+    block_end.assign(ends.begin(), ends.end());
   }
 
-  NativeHeader           header;
-  BlockArray             data;
-  std::vector<size_type> block_end;            // last sequence position of each block (block_boundaries)
-  std::vector<size_type> cumulative[SIGMA];    // cumulative[c][k] = #c in blocks [0, k) (samples[c])
+  NativeHeader                   header;
+  mutable BlockArray             data;                 // valid after materialize() (always, unless the BWT came out of a lazy merge)
+  mutable HostArray<size_type>   block_end;            // last sequence position of each block (block_boundaries)
+  mutable HostArray<size_type>   cum_flat;             // [SIGMA][cum_stride]: cum(c, k) = #c in blocks [0, k) (samples[c])
+  mutable size_type              cum_stride = 0;       // blocks + 1
 
 private:
+  mutable bwtm_index* device = nullptr;                // device copy (rank structure only), owned
+  mutable bool        host_current = true;             // false: only the device holds the BWT (lazy result of a merge)
+
   struct Cursor { size_type block, rle_pos, seq_pos; };
 
   size_type block_start(size_type block) const { return (block == 0 ? 0 : block_end[block - 1] + 1); }
@@ -309,6 +384,7 @@ private:
   // The block that holds position i (or the one after the last when i == size()).
   Cursor seek(size_type i) const
   {
+    materialize();
     Cursor cur;
     cur.block = (size_type)(std::lower_bound(block_end.begin(), block_end.end(), i) - block_end.begin());
     cur.rle_pos = cur.block * SAMPLE_RATE; cur.seq_pos = block_start(cur.block);

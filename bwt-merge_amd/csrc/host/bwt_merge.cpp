@@ -19,7 +19,7 @@ static void printUsage()
   std::cerr << "  -b N          Set thread buffer size to N megabytes / thread (default: " << MergeParameters::defaultTB() << ")" << std::endl;
   std::cerr << "  -m N          Set the number of merge buffers to N (default: " << MergeParameters::defaultMB() << ")" << std::endl;
   std::cerr << "  -r N          Set run buffer size to N megabytes / thread (default: " << MergeParameters::defaultRB() << ")" << std::endl;
-  std::cerr << "  -s N          Set the number of sequence blocks to N (default: " << MergeParameters::defaultSB() << " / thread)" << std::endl;
+  std::cerr << "  -s N          Set the number of sequence blocks to N (default: " << MergeParameters::defaultSB() << " / thread; the device partitions the search itself)" << std::endl;
   std::cerr << "  -t N          Use N parallel threads (default: " << MergeParameters::defaultT() << " on this system)" << std::endl << std::endl;
   std::cerr << "  -d directory  Use the given directory for temporary files (default: .)" << std::endl;
   std::cerr << "  -v filename   Verify by querying with patterns from the given file" << std::endl << std::endl;
@@ -56,9 +56,8 @@ static void verifyFMI(const FMI& fmi, const std::string& name, const std::vector
       for(char ch : patterns[k]) { text.push_back(fmi.alpha.char2comp[(byte_type)ch]); }
       offsets[k + 1] = text.size();
     }
-    bwtm_index* ix = fmi.bwt.upload(fmi.alpha.C);
+    bwtm_index* ix = fmi.bwt.onDevice(fmi.alpha.C);                 // stays there: the merge that follows uses the same copy
     gpuCheck(bwtm_find_batch(ix, text.data(), offsets.data(), patterns.size(), sp.data(), ep.data()), "verifyFMI()");
-    bwtm_index_free(ix);
     size_type found = 0, matches = 0;
     for(size_type k = 0; k < patterns.size(); k++)
     {
@@ -161,7 +160,10 @@ int main(int argc, char** argv)
     FMI increment; load(increment, argv[optind + input], input_formats[input]);
     bytes_added += increment.size();
     verifyFMI(increment, "Input", patterns, pre_results);
-    merge(index, increment, parameters);
+    // Intermediate results of a chain are only ever the next merge's first input: they stay on the device.  The last
+    // merge produces the host-resident FMI inside its timer, like the reference's.
+    MergeParameters p = parameters; p.lazy_host = (input + 1 < inputs);
+    merge(index, increment, p);
   }
 
   serialize(index, argv[argc - 1], output_format);

@@ -19,8 +19,11 @@ void load(FMI& fmi, const std::string& filename, const std::string& format);
 /*
   The reference's knobs.  Buffer sizes, merge buffers and the temp directory have nothing to
   configure on the device (no buffer hierarchy, no temp files); they are accepted, printed and
-  otherwise ignored.  sequence_blocks is the number of bwtm_search() calls the search is split
-  into (the device partitions further on its own).
+  otherwise ignored.  sequence_blocks is honoured by the two-step API (buildRA: one bwtm_search()
+  call per block); the merging constructor searches all sequences in one call, which is what the
+  device wants (it partitions the work itself).
+  lazy_host (an addition): the merged FMI is left on the device and its host form is produced when
+  something asks for it; the tool sets it for every merge but the last of a chain.
 */
 struct MergeParameters
 {
@@ -33,7 +36,7 @@ struct MergeParameters
 
   MergeParameters() :
     run_buffer_size(RUN_BUFFER_SIZE), thread_buffer_size(THREAD_BUFFER_SIZE), merge_buffers(MERGE_BUFFERS),
-    threads(Parallel::max_threads), sequence_blocks(threads * BLOCKS_PER_THREAD), temp_dir(".") {}
+    threads(Parallel::max_threads), sequence_blocks(threads * BLOCKS_PER_THREAD), temp_dir("."), lazy_host(false) {}
 
   void sanitize()
   {
@@ -63,6 +66,7 @@ struct MergeParameters
   size_type merge_buffers;
   size_type threads, sequence_blocks;
   std::string temp_dir;
+  bool lazy_host;
 };
 
 inline std::ostream& operator<<(std::ostream& out, const MergeParameters& p)
@@ -140,19 +144,32 @@ public:
   Alphabet alpha;
 };
 
-// Search phase (buildRA, reference fmi.cpp:272-334) as a free function: uploads a and b and
+// Search phase (buildRA, reference fmi.cpp:272-334) as a free function: makes sure a and b are on the device and
 // fills a device rank array; parameters.sequence_blocks splits the sequences of b.
 inline void buildRA(const FMI& a, const FMI& b, const MergeParameters& parameters, RankArray& ra)
 {
   ra.clear();
-  ra.a = a.bwt.upload(a.alpha.C);
-  ra.b = b.bwt.upload(b.alpha.C);
+  ra.a = a.bwt.onDevice(a.alpha.C);
+  ra.b = b.bwt.onDevice(b.alpha.C);
   gpuCheck(bwtm_ra_create(ra.a, ra.b, &ra.handle), "buildRA()");
   if(b.sequences() == 0) { return; }
   for(range_type block : getBounds(range_type(0, b.sequences() - 1), parameters.sequence_blocks))
   {
     gpuCheck(bwtm_search(ra.a, ra.b, block.first, block.second, ra.handle), "buildRA()");
   }
+}
+
+// The output buffers of bwtm_merge_host are the result's own page-locked arrays.
+inline void* mergeSink(void* user, int what, uint64_t nbytes)
+{
+  BWT* bwt = (BWT*)user;
+  switch(what)
+  {
+  case BWTM_BUF_DATA:      bwt->data.bytes.resizeUninitialized(std::max<uint64_t>(nbytes, 1)); bwt->data.bytes.resizeUninitialized(nbytes); return bwt->data.bytes.data();
+  case BWTM_BUF_BLOCK_END: bwt->block_end.resizeUninitialized(std::max<uint64_t>(nbytes / sizeof(size_type), 1)); bwt->block_end.resizeUninitialized(nbytes / sizeof(size_type)); return bwt->block_end.data();
+  case BWTM_BUF_CUM:       bwt->cum_flat.resizeUninitialized(nbytes / sizeof(size_type)); return bwt->cum_flat.data();
+  }
+  return nullptr;
 }
 
 inline FMI::FMI(FMI& a, FMI& b, MergeParameters parameters)
@@ -162,14 +179,47 @@ inline FMI::FMI(FMI& a, FMI& b, MergeParameters parameters)
     std::cerr << "FMI::FMI(): Cannot merge BWTs with different alphabets" << std::endl;
     std::exit(EXIT_FAILURE);
   }
-  // One search call over all sequences is the fastest split on the device; more blocks only
-  // when the caller asks for them explicitly through a smaller-than-default setting.
-  MergeParameters p = parameters; p.sequence_blocks = 1;
-  RankArray ra;
-  buildRA(a, b, p, ra);
   Alphabet merged = a.alpha;
   for(size_type c = 0; c <= merged.sigma; c++) { merged.C[c] += b.alpha.C[c]; }
-  this->bwt = BWT(a.bwt, b.bwt, ra);
+  this->bwt.header.sequences = a.sequences() + b.sequences();
+  this->bwt.header.bases = a.size() + b.size();
+  this->bwt.header.setOrder(a.bwt.header.order());
+  if(parameters.lazy_host)
+  {
+    // Device only: the result is the next merge's first input; nothing is encoded or downloaded now.
+    bwtm_index* A = a.bwt.onDevice(a.alpha.C); bwtm_index* B = b.bwt.onDevice(b.alpha.C);
+    bwtm_ra* ra = nullptr; bwtm_index* M = nullptr;
+    gpuCheck(bwtm_ra_create(A, B, &ra), "FMI::FMI()");
+    if(b.sequences() > 0) { gpuCheck(bwtm_search(A, B, 0, b.sequences() - 1, ra), "FMI::FMI()"); }
+    gpuCheck(bwtm_ra_finalize(ra), "FMI::FMI()");
+    gpuCheck(bwtm_interleave(A, B, ra, &M), "FMI::FMI()");
+    bwtm_ra_free(ra);
+    a.bwt.clear(); b.bwt.clear();
+    this->bwt.adopt(M);
+  }
+  else
+  {
+    // Host to host in one pipelined call (bwtm_merge_host): b is uploaded from its page-locked bytes, a likewise unless it
+    // is already on the device (the result of the previous merge); data and samples land in this object's arrays.
+    std::vector<uint64_t> cb(b.alpha.C.begin(), b.alpha.C.end()), ca(a.alpha.C.begin(), a.alpha.C.end());
+    const BlockArray& bdata = b.bwt.hostData();
+    bwtm_host_input hb = { bdata.data(), bdata.size(), b.sequences(), b.size(), cb.data() };
+    bwtm_host_output out;
+    bwtm_index* kept = nullptr;
+    b.bwt.dropDevice();
+    if(a.bwt.deviceResident())
+    {
+      gpuCheck(bwtm_merge_host_chained(a.bwt.releaseDevice(), &hb, mergeSink, &this->bwt, 1, &out, &kept), "FMI::FMI()");
+    }
+    else
+    {
+      const BlockArray& adata = a.bwt.hostData();
+      bwtm_host_input ha = { adata.data(), adata.size(), a.sequences(), a.size(), ca.data() };
+      gpuCheck(bwtm_merge_host(&ha, &hb, mergeSink, &this->bwt, 1, &out, &kept), "FMI::FMI()");
+    }
+    this->bwt.adoptHost(kept, out.blocks);
+    a.bwt.clear(); b.bwt.clear();
+  }
   this->alpha = merged;
 }
 
@@ -245,9 +295,10 @@ inline void FMI::serialize(const std::string& filename) const
   const Alphabet order_alpha = createAlphabet(Format::order());
   Format::encode(out, bwt.header, [&](auto&& f)
   {
-    for(size_type rle_pos = 0; rle_pos < bwt.bytes(); )
+    const BlockArray& data = bwt.hostData();
+    for(size_type rle_pos = 0; rle_pos < data.size(); )
     {
-      range_type run = Run::read(bwt.data, rle_pos);
+      range_type run = Run::read(data, rle_pos);
       f((size_type)(Format::characters ? order_alpha.comp2char[run.first] : run.first), run.second);
     }
   });
@@ -276,7 +327,7 @@ inline size_type sizeInBytes(const FMI& fmi)
   // Exact for data, header and alphabet; the Elias-Fano samples are estimated from their parameters
   // (2 + log2(n / m) bits per block), serializing them only to count bytes would take seconds.
   size_type blocks = fmi.bwt.blocks();
-  size_type total = 24 + 8 + fmi.bwt.data.blocks() * BlockArray::BLOCK_SIZE + 256 + 6 + 7 * 8 + 8 + 3 * 8;
+  size_type total = 24 + 8 + fmi.bwt.hostData().blocks() * BlockArray::BLOCK_SIZE + 256 + 6 + 7 * 8 + 8 + 3 * 8;
   for(size_type c = 0; c <= BWT::SIGMA; c++)
   {
     size_type universe = (c < BWT::SIGMA ? fmi.bwt.count((comp_type)c) + blocks : fmi.size());

@@ -42,7 +42,7 @@ int main(int argc, char** argv)
 
   FMI a, b;
   load(a, argv[1], "plain_default"); load(b, argv[2], "plain_default");
-  FMI a2 = a, b2 = b;
+  FMI a2 = a, b2 = b, a3 = a, b3 = b, b4 = b, b5 = b;
   std::vector<byte_type> sa = symbolsOf(a), sb = symbolsOf(b);
   size_type na = a.size(), nb = b.size();
 
@@ -84,7 +84,8 @@ int main(int argc, char** argv)
 
   // The merging constructor == FMI::FMI(a, b, parameters).
   FMI merged(a, b, MergeParameters());
-  CHECK(a.bwt.bytes() == 0 && b.bwt.bytes() == 0);                      // inputs are consumed
+  CHECK(a.bwt.bytes() == 0 && b.bwt.bytes() == 0 && !a.bwt.deviceResident() && !b.bwt.deviceResident());   // inputs are consumed
+  CHECK(merged.bwt.deviceResident());                                      // the result is also there as the next merge's input
   CHECK(merged.size() == na + nb);
   std::vector<byte_type> expected = readFile(argv[3]);
   CHECK(merged.bwt.data.bytes == expected);
@@ -96,7 +97,7 @@ int main(int argc, char** argv)
   {
     FMI rebuilt; rebuilt.bwt.data = merged.bwt.data; rebuilt.bwt.buildFromData();
     CHECK(rebuilt.bwt.block_end == merged.bwt.block_end);
-    for(size_type c = 0; c < 6; c++) { CHECK(rebuilt.bwt.cumulative[c] == merged.bwt.cumulative[c]); }
+    for(size_type c = 0; c < 6; c++) { CHECK(rebuilt.bwt.cumulative(c) == merged.bwt.cumulative(c)); }
     CHECK(rebuilt.bwt.header.sequences == merged.sequences() && rebuilt.bwt.header.bases == merged.size());
   }
 
@@ -108,6 +109,23 @@ int main(int argc, char** argv)
     CHECK(interleaved.data.bytes == expected);
   }
 
+  // Chaining (bwt_merge.cpp:167-173): a lazy merge leaves its result on the device; as the first input of the next merge it is
+  // not uploaded again, and the outcome equals the one computed from host copies only.
+  {
+    MergeParameters lazy; lazy.lazy_host = true;
+    FMI on_device(a3, b3, lazy);
+    CHECK(on_device.bwt.deviceResident() && on_device.bwt.data.bytes.empty() && on_device.size() == na + nb);
+    FMI host_copy = merged;                                               // a copy has no device side
+    CHECK(!host_copy.bwt.deviceResident());
+    FMI chained(on_device, b4, MergeParameters());                        // first input taken from the device
+    FMI from_host(host_copy, b5, MergeParameters());                      // both inputs uploaded from the host
+    CHECK(chained.size() == na + 2 * nb && chained.bwt.data.bytes == from_host.bwt.data.bytes);
+    CHECK(chained.bwt.block_end == from_host.bwt.block_end && chained.bwt.cum_flat == from_host.bwt.cum_flat);
+    CHECK(chained.alpha.C == from_host.alpha.C);
+    FMI again = on_device;                                                // consumed above: empty
+    CHECK(again.bwt.bytes() == 0);
+  }
+
   // Native file round trip.
   {
     std::string name = work + "/merged.native";
@@ -115,7 +133,7 @@ int main(int argc, char** argv)
     FMI back; load(back, name, "native");
     CHECK(back.bwt.data.bytes == merged.bwt.data.bytes);
     CHECK(back.bwt.block_end == merged.bwt.block_end);
-    for(size_type c = 0; c < 6; c++) { CHECK(back.bwt.cumulative[c] == merged.bwt.cumulative[c]); }
+    for(size_type c = 0; c < 6; c++) { CHECK(back.bwt.cumulative(c) == merged.bwt.cumulative(c)); }
     CHECK(back.alpha == merged.alpha && back.alpha.C == merged.alpha.C);
     CHECK(back.bwt.header.sequences == merged.sequences() && back.bwt.header.bases == merged.size() && back.bwt.header.check());
     CHECK(back.bwt.hash() == merged.bwt.hash());

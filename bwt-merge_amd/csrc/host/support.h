@@ -6,11 +6,103 @@
 #ifndef BWTM_HOST_SUPPORT_H
 #define BWTM_HOST_SUPPORT_H
 
+#include <cstdlib>
 #include <cstring>
+#include <bwtm.h>
 #include "utils.h"
 
 namespace bwtmerge
 {
+
+// A flat array in PAGE-LOCKED host memory (bwtm_host_alloc) when a GPU is usable, in plain memory otherwise (the
+// converters run without one): transfers from / to it run at PCIe speed and overlap with kernels.  The part of
+// std::vector's interface the facade uses.
+template<class T>
+class HostArray
+{
+public:
+  typedef T value_type;
+
+  HostArray() : ptr(nullptr), count(0), capacity(0), pinned(false) {}
+  explicit HostArray(size_type n) : HostArray() { resize(n); }
+  HostArray(const HostArray& other) : HostArray() { assign(other.ptr, other.ptr + other.count); }
+  HostArray(HostArray&& other) noexcept : HostArray() { swap(other); }
+  HostArray& operator=(const HostArray& other) { if(this != &other) { assign(other.ptr, other.ptr + other.count); } return *this; }
+  HostArray& operator=(HostArray&& other) noexcept { if(this != &other) { release(); swap(other); } return *this; }
+  ~HostArray() { release(); }
+
+  size_type size() const { return count; }
+  bool empty() const { return count == 0; }
+  T* data() { return ptr; }
+  const T* data() const { return ptr; }
+  T& operator[](size_type i) { return ptr[i]; }
+  const T& operator[](size_type i) const { return ptr[i]; }
+  T& back() { return ptr[count - 1]; }
+  const T& back() const { return ptr[count - 1]; }
+  T* begin() { return ptr; }
+  T* end() { return ptr + count; }
+  const T* begin() const { return ptr; }
+  const T* end() const { return ptr + count; }
+
+  void reserve(size_type n)
+  {
+    if(n <= capacity) { return; }
+    bool new_pinned = false;
+    T* fresh = allocate(n, new_pinned);
+    if(count > 0) { std::memcpy((void*)fresh, (const void*)ptr, count * sizeof(T)); }
+    deallocate(ptr, pinned);
+    ptr = fresh; capacity = n; pinned = new_pinned;
+  }
+  void resize(size_type n, T value = T())
+  {
+    if(n > capacity) { reserve(n); }
+    for(size_type k = count; k < n; k++) { ptr[k] = value; }
+    count = n;
+  }
+  // Sets the size without initializing new elements (buffers that a download fills).
+  void resizeUninitialized(size_type n) { if(n > capacity) { reserve(n); } count = n; }
+  void push_back(T v)
+  {
+    if(count == capacity) { reserve(capacity < 1024 ? 4096 : 2 * capacity); }
+    ptr[count++] = v;
+  }
+  template<class It> void assign(It first, It last)
+  {
+    size_type n = (size_type)(last - first);
+    resizeUninitialized(n);
+    for(size_type k = 0; k < n; k++, ++first) { ptr[k] = *first; }
+  }
+  void assign(size_type n, T value) { count = 0; resize(n, value); }
+  void clear() { count = 0; }
+  void shrink_to_fit() { if(count == 0) { release(); } }
+  void swap(HostArray& other) { std::swap(ptr, other.ptr); std::swap(count, other.count); std::swap(capacity, other.capacity); std::swap(pinned, other.pinned); }
+
+  bool operator==(const HostArray& other) const { return count == other.count && (count == 0 || std::memcmp(ptr, other.ptr, count * sizeof(T)) == 0); }
+  bool operator!=(const HostArray& other) const { return !(*this == other); }
+  bool operator==(const std::vector<T>& other) const { return count == other.size() && (count == 0 || std::memcmp(ptr, other.data(), count * sizeof(T)) == 0); }
+
+private:
+  static T* allocate(size_type n, bool& is_pinned)
+  {
+    static bool pinned_available = true;                 // one failed attempt (no GPU) switches to plain memory for good
+    void* p = nullptr;
+    if(pinned_available && n * sizeof(T) >= PINNED_MIN)
+    {
+      if(bwtm_host_alloc(n * sizeof(T), &p) == BWTM_OK) { is_pinned = true; return (T*)p; }
+      pinned_available = false;
+    }
+    p = std::malloc(n * sizeof(T) > 0 ? n * sizeof(T) : 1);
+    if(!p) { std::cerr << "HostArray: cannot allocate " << n * sizeof(T) << " bytes" << std::endl; std::exit(EXIT_FAILURE); }
+    is_pinned = false;
+    return (T*)p;
+  }
+  static void deallocate(T* p, bool is_pinned) { if(!p) { return; } if(is_pinned) { bwtm_host_free(p); } else { std::free(p); } }
+  void release() { deallocate(ptr, pinned); ptr = nullptr; count = 0; capacity = 0; pinned = false; }
+
+  const static size_type PINNED_MIN = 1 << 20;           // small arrays are not worth a pinning call
+
+  T* ptr; size_type count, capacity; bool pinned;
+};
 
 // char <-> comp maps and the C array.  Default order $ACGTN = 0..5; every other byte maps to N.
 class Alphabet
@@ -74,7 +166,7 @@ public:
   void swap(BlockArray& other) { bytes.swap(other.bytes); }
   const value_type* data() const { return bytes.data(); }
 
-  std::vector<value_type> bytes;
+  HostArray<value_type> bytes;
 };
 
 // 7 data bits per byte, least significant group first, high bit = "continues".
