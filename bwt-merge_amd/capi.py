@@ -43,6 +43,7 @@ SYMBOLS = [
     ("bwtm_host_alloc", C.c_int, [u64, C.POINTER(vp)]),
     ("bwtm_host_free", None, [vp]),
     ("bwtm_ra_download_runs", C.c_int, [vp, p_u64, p_u64, u64, p_u64]),
+    ("bwtm_ra_or_from", C.c_int, [vp, vp, u64]),
     ("bwtm_merge_consume", C.c_int, [vp, vp, C.POINTER(vp)]),
     ("bwtm_merged_records", u64, [vp, vp]),
     ("bwtm_slice_bounds", C.c_int, [u64, C.c_int, C.c_int, p_u64, p_u64]),
@@ -434,6 +435,11 @@ class RankArray:
         n = u64(0)
         check(lib().bwtm_ra_device_buffer(self.h, C.byref(ptr), C.byref(n)))
         return int(ptr.value), int(n.value)
+
+    def or_from(self, other):
+        """self |= other's bits (another rank array for the same inputs on the same device)."""
+        ptr, n = other.device_buffer()
+        check(lib().bwtm_ra_or_from(self.h, vp(ptr), n))
 
     def finalize(self):
         check(lib().bwtm_ra_finalize(self.h))

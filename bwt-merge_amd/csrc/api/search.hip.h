@@ -402,6 +402,18 @@ extern "C" int bwtm_ra_device_buffer(bwtm_ra* ra, void** device_ptr, uint64_t* n
   return BWTM_OK;
 }
 
+extern "C" int bwtm_ra_or_from(bwtm_ra* ra, const void* device_bits, uint64_t nbytes)
+{
+  if(!ra || !device_bits) { return fail(BWTM_EINVAL, "bwtm_ra_or_from: null argument"); }
+  ENTER(ra->ctx);
+  if(ra->finalized) { return fail(BWTM_EINVAL, "bwtm_ra_or_from: rank array already finalized"); }
+  const u64 nwords = ra->nchunks * CHUNK_WORDS;
+  if(nbytes != nwords * sizeof(u64)) { return fail(BWTM_EINVAL, "bwtm_ra_or_from: buffer of %llu bytes, expected %llu", (unsigned long long)nbytes, (unsigned long long)(nwords * sizeof(u64))); }
+  LAUNCH("bits_or", k_bits_or, div_up(nwords, BLOCK_THREADS), BLOCK_THREADS, ra->bits_as<u64>(), (const u64*)device_bits, nwords);
+  HIP_TRY(hipStreamSynchronize(CTX.stream));          // the source buffer belongs to somebody else: done with it on return
+  return BWTM_OK;
+}
+
 namespace
 {
 int ra_finalize(bwtm_ra* ra)

@@ -6,7 +6,7 @@
 #include <sstream>
 #include <unistd.h>
 
-#include "fmi.h"
+#include "multi_gpu.h"
 
 using namespace bwtmerge;
 
@@ -26,7 +26,9 @@ static void printUsage()
   std::cerr << "  -i formats    Read the inputs in the given formats (default: native)" << std::endl;
   std::cerr << "                Multiple comma-separated formats can be provided." << std::endl;
   std::cerr << "  -o format     Write the output in the given format (default: native)" << std::endl;
-  std::cerr << "  -g N          Use GPU N (default: 0; the buffer options have no effect on the device)" << std::endl << std::endl;
+  std::cerr << "  -g N[,M,...]  Use GPU N (default: 0), or one host thread per listed GPU: the sequences of the increment are" << std::endl;
+  std::cerr << "                sharded over them and every GPU produces its range of the output" << std::endl;
+  std::cerr << "                (the buffer options have no effect on the device)" << std::endl << std::endl;
   printFormats(std::cerr);
 }
 
@@ -70,12 +72,20 @@ static void verifyFMI(const FMI& fmi, const std::string& name, const std::vector
   std::cout << std::endl;
 }
 
-static void merge(FMI& index, FMI& increment, const MergeParameters& parameters)
+static void merge(FMI& index, FMI& increment, const MergeParameters& parameters, const std::vector<int>& devices)
 {
   double increment_mb = inMegabytes(increment.size());
   double start = readTimer();
-  FMI temp(index, increment, parameters);
-  index.swap(temp);
+  if(devices.size() > 1)
+  {
+    FMI temp; mergeMultiGPU(index, increment, devices, temp);      // one host thread per GPU, result assembled on the host
+    index.swap(temp);
+  }
+  else
+  {
+    FMI temp(index, increment, parameters);
+    index.swap(temp);
+  }
   double seconds = readTimer() - start;
   std::cout << "BWTs merged in " << seconds << " seconds (" << (increment_mb / seconds) << " MB/s)" << std::endl << std::endl;
 }
@@ -87,7 +97,8 @@ int main(int argc, char** argv)
   double start = readTimer();
   std::cout << "BWT-merge" << std::endl << std::endl;
 
-  int c = 0, device = 0;
+  int c = 0;
+  std::vector<int> devices;
   bool verify = false;
   MergeParameters parameters;
   std::string pattern_name, output_format;
@@ -102,7 +113,12 @@ int main(int argc, char** argv)
     case 's': parameters.setSB(std::stoul(optarg)); break;
     case 't': parameters.setT(std::stoul(optarg)); break;
     case 'd': parameters.setTemp(optarg); break;
-    case 'g': device = std::stoi(optarg); break;
+    case 'g':
+      {
+        std::istringstream ss(optarg);
+        for(std::string token; std::getline(ss, token, ','); ) { devices.push_back(std::stoi(token)); }
+      }
+      break;
     case 'v': pattern_name = optarg; verify = true; break;
     case 'i':
       {
@@ -140,7 +156,8 @@ int main(int argc, char** argv)
   if(verify) { std::cout << "Patterns:         " << pattern_name << std::endl; }
   std::cout << std::endl << parameters << std::endl;
 
-  gpuCheck(bwtm_init(device), "bwt_merge");
+  if(devices.empty()) { devices.push_back(0); }
+  gpuCheck(bwtm_init(devices[0]), "bwt_merge");
 
   std::vector<std::string> patterns;
   std::vector<size_type> pre_results, post_results;
@@ -163,7 +180,7 @@ int main(int argc, char** argv)
     // Intermediate results of a chain are only ever the next merge's first input: they stay on the device.  The last
     // merge produces the host-resident FMI inside its timer, like the reference's.
     MergeParameters p = parameters; p.lazy_host = (input + 1 < inputs);
-    merge(index, increment, p);
+    merge(index, increment, p, devices);
   }
 
   serialize(index, argv[argc - 1], output_format);

@@ -6,7 +6,7 @@
 */
 #include <cstdio>
 #include <thread>
-#include "fmi.h"
+#include "multi_gpu.h"
 
 using namespace bwtmerge;
 size_type Parallel::max_threads = 4;
@@ -43,6 +43,7 @@ int main(int argc, char** argv)
   FMI a, b;
   load(a, argv[1], "plain_default"); load(b, argv[2], "plain_default");
   FMI a2 = a, b2 = b, a3 = a, b3 = b, b4 = b, b5 = b;
+  FMI a6 = a, b6 = b, a7 = a, b7 = b, a8 = a, b8 = b;
   std::vector<byte_type> sa = symbolsOf(a), sb = symbolsOf(b);
   size_type na = a.size(), nb = b.size();
 
@@ -124,6 +125,22 @@ int main(int argc, char** argv)
     CHECK(chained.alpha.C == from_host.alpha.C);
     FMI again = on_device;                                                // consumed above: empty
     CHECK(again.bwt.bytes() == 0);
+  }
+
+  // One host thread per GPU (multi_gpu.h).  On this box the "GPUs" are contexts of GPU 0: 1, 2 and 3 threads, each
+  // searching its block of b's sequences and producing its range of the output; same bytes and samples as the single call.
+  {
+    std::vector<std::vector<int>> device_lists = { {0}, {0, 0}, {0, 0, 0} };
+    FMI* as[3] = { &a6, &a7, &a8 }; FMI* bs[3] = { &b6, &b7, &b8 };
+    for(size_type k = 0; k < 3; k++)
+    {
+      FMI sharded; MultiGPUTimes times;
+      mergeMultiGPU(*as[k], *bs[k], device_lists[k], sharded, &times);
+      CHECK(sharded.bwt.data.bytes == expected);
+      CHECK(sharded.bwt.block_end == merged.bwt.block_end && sharded.bwt.cum_flat == merged.bwt.cum_flat);
+      CHECK(sharded.alpha.C == merged.alpha.C && sharded.size() == merged.size() && sharded.sequences() == merged.sequences());
+      CHECK(as[k]->bwt.bytes() == 0 && times.total > 0);
+    }
   }
 
   // Native file round trip.

@@ -1,0 +1,214 @@
+/*
+  multi_gpu.h -- FMI::FMI(a, b, parameters) on several GPUs of one node from ONE process: one host thread per GPU,
+  each bound to its own library context (the reference's ParallelLoop workers, fmi.cpp:351-358, become threads
+  that own a GPU each).
+
+    1. every thread uploads both inputs to its GPU (the indexes are replicated: every LF chain touches arbitrary
+       positions of both; eight uploads run on eight PCIe links at once);
+    2. thread g searches block g of b's sequences (getBounds, utils.cpp:169-187) into its own bitvector;
+    3. ONE exchange: all-reduce (sum == or, the bits are disjoint) of the bitvectors -- RCCL over xGMI, called
+       directly (ncclAllReduce on the buffer bwtm_ra_device_buffer() exposes);
+    4. every thread interleaves and encodes only ITS range of the output (bwtm_interleave_range / bwtm_slice_*);
+       the two encoder carries (open run, byte offset mod 64) cross the threads through shared host variables;
+    5. every thread downloads its slice straight into its place in the result's page-locked arrays
+       (eight D2H streams, each 1 / G of the output).
+
+  Devices may repeat (e.g. {0, 0}): then the "GPUs" are contexts of one GPU and step 3 uses bwtm_ra_or_from()
+  instead of RCCL -- how the slicing logic is tested on a one-GPU box.
+*/
+#ifndef BWTM_HOST_MULTI_GPU_H
+#define BWTM_HOST_MULTI_GPU_H
+
+#include <condition_variable>
+#include <mutex>
+#include <set>
+#include <thread>
+
+#include "fmi.h"
+
+#ifdef BWTM_WITH_RCCL
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#endif
+
+namespace bwtmerge
+{
+
+// Reusable barrier for a fixed number of threads (C++17 has none).
+class ThreadBarrier
+{
+public:
+  explicit ThreadBarrier(size_type n) : threads(n), waiting(0), generation(0) {}
+  void wait()
+  {
+    std::unique_lock<std::mutex> lock(mu);
+    size_type gen = generation;
+    if(++waiting == threads) { waiting = 0; generation++; cv.notify_all(); }
+    else { cv.wait(lock, [&] { return gen != generation; }); }
+  }
+private:
+  std::mutex mu; std::condition_variable cv;
+  size_type threads, waiting, generation;
+};
+
+struct MultiGPUTimes
+{
+  double upload = 0, search = 0, exchange = 0, interleave_encode = 0, download = 0, total = 0;   // seconds, thread 0's view
+};
+
+// Merges a and b (both consumed) into `result` using the given devices.
+inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& result, MultiGPUTimes* times = nullptr)
+{
+  if(a.alpha != b.alpha)
+  {
+    std::cerr << "FMI::FMI(): Cannot merge BWTs with different alphabets" << std::endl;
+    std::exit(EXIT_FAILURE);
+  }
+  const size_type G = devices.size();
+  if(G == 0) { std::cerr << "mergeMultiGPU(): no devices" << std::endl; std::exit(EXIT_FAILURE); }
+  const bool distinct = (std::set<int>(devices.begin(), devices.end()).size() == G);
+
+  Alphabet merged = a.alpha;
+  for(size_type c = 0; c <= merged.sigma; c++) { merged.C[c] += b.alpha.C[c]; }
+  const BlockArray& adata = a.bwt.hostData(); const BlockArray& bdata = b.bwt.hostData();
+  a.bwt.dropDevice(); b.bwt.dropDevice();
+  std::vector<uint64_t> ca(a.alpha.C.begin(), a.alpha.C.end()), cb(b.alpha.C.begin(), b.alpha.C.end());
+  std::vector<range_type> blocks = (b.sequences() > 0 ? getBounds(range_type(0, b.sequences() - 1), G) : std::vector<range_type>());
+
+#ifdef BWTM_WITH_RCCL
+  std::vector<ncclComm_t> comms(G, nullptr);
+  if(distinct && G > 1)
+  {
+    if(ncclCommInitAll(comms.data(), (int)G, devices.data()) != ncclSuccess) { std::cerr << "mergeMultiGPU(): ncclCommInitAll failed" << std::endl; std::exit(EXIT_FAILURE); }
+  }
+#else
+  if(distinct && G > 1) { std::cerr << "mergeMultiGPU(): built without RCCL, cannot combine rank arrays across devices" << std::endl; std::exit(EXIT_FAILURE); }
+#endif
+
+  // What the threads share.
+  ThreadBarrier barrier(G);
+  std::vector<void*> bits(G, nullptr); std::vector<uint64_t> bits_bytes(G, 0);
+  std::vector<uint64_t> heads(G, 0), tables(G * 64, 0), offsets(G + 1, 0), first_block_start(G, ~(uint64_t)0);
+  std::vector<uint64_t> block_first(G, 0), block_count(G, 0);
+  BWT& out = result.bwt;
+  double t0 = readTimer();
+  MultiGPUTimes local;
+
+  auto worker = [&](size_type g)
+  {
+    bwtm_context* ctx = nullptr;
+    gpuCheck(bwtm_context_create(devices[g], &ctx), "mergeMultiGPU()");
+    gpuCheck(bwtm_context_make_current(ctx), "mergeMultiGPU()");
+    bwtm_index *A = nullptr, *B = nullptr; bwtm_ra* ra = nullptr; bwtm_slice* slice = nullptr;
+    gpuCheck(bwtm_index_upload(adata.data(), adata.size(), a.sequences(), a.size(), ca.data(), &A), "mergeMultiGPU()");
+    gpuCheck(bwtm_index_drop_native(A), "mergeMultiGPU()");
+    gpuCheck(bwtm_index_upload(bdata.data(), bdata.size(), b.sequences(), b.size(), cb.data(), &B), "mergeMultiGPU()");
+    gpuCheck(bwtm_index_drop_native(B), "mergeMultiGPU()");
+    if(g == 0) { local.upload = readTimer() - t0; }
+
+    gpuCheck(bwtm_ra_create(A, B, &ra), "mergeMultiGPU()");
+    if(g < blocks.size()) { gpuCheck(bwtm_search(A, B, blocks[g].first, blocks[g].second, ra), "mergeMultiGPU()"); }
+    gpuCheck(bwtm_ra_device_buffer(ra, &bits[g], &bits_bytes[g]), "mergeMultiGPU()");      // synchronizes: the search is done
+    if(g == 0) { local.search = readTimer() - t0 - local.upload; }
+
+    // The one exchange.
+    barrier.wait();
+    double t_x = readTimer();
+    if(G > 1)
+    {
+      if(distinct)
+      {
+#ifdef BWTM_WITH_RCCL
+        hipStream_t stream = nullptr;
+        if(hipSetDevice(devices[g]) != hipSuccess || hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { std::cerr << "mergeMultiGPU(): no stream" << std::endl; std::exit(EXIT_FAILURE); }
+        if(ncclAllReduce(bits[g], bits[g], bits_bytes[g] / sizeof(uint64_t), ncclUint64, ncclSum, comms[g], stream) != ncclSuccess)
+        {
+          std::cerr << "mergeMultiGPU(): ncclAllReduce failed" << std::endl; std::exit(EXIT_FAILURE);
+        }
+        (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream);
+#endif
+      }
+      else
+      {
+        // contexts of one GPU: thread 0 collects all shards, then everybody takes the union from it
+        if(g == 0) { for(size_type h = 1; h < G; h++) { gpuCheck(bwtm_ra_or_from(ra, bits[h], bits_bytes[h]), "mergeMultiGPU()"); } }
+        barrier.wait();
+        if(g != 0) { gpuCheck(bwtm_ra_or_from(ra, bits[0], bits_bytes[0]), "mergeMultiGPU()"); }
+      }
+      barrier.wait();
+    }
+    if(g == 0) { local.exchange = readTimer() - t_x; }
+
+    // This thread's range of the output.
+    double t_i = readTimer();
+    gpuCheck(bwtm_ra_finalize(ra), "mergeMultiGPU()");
+    uint64_t rec_first = 0, rec_last = 0;
+    gpuCheck(bwtm_slice_bounds(bwtm_merged_records(A, B), (int)G, (int)g, &rec_first, &rec_last), "mergeMultiGPU()");
+    gpuCheck(bwtm_interleave_range(A, B, ra, rec_first, rec_last, &slice), "mergeMultiGPU()");
+    bwtm_ra_free(ra); bwtm_index_free(A); bwtm_index_free(B);
+    gpuCheck(bwtm_slice_lasthead(slice, &heads[g]), "mergeMultiGPU()");
+    barrier.wait();
+    uint64_t before = 0;
+    for(size_type h = 0; h < g; h++) { before = std::max(before, heads[h]); }
+    gpuCheck(bwtm_slice_size_table(slice, before, tables.data() + 64 * g), "mergeMultiGPU()");
+    barrier.wait();
+    if(g == 0) { gpuCheck(bwtm_fold_offsets(tables.data(), (int)G, offsets.data()), "mergeMultiGPU()"); }
+    barrier.wait();
+    gpuCheck(bwtm_slice_encode(slice, offsets[g]), "mergeMultiGPU()");
+    gpuCheck(bwtm_slice_first_block_start(slice, &first_block_start[g]), "mergeMultiGPU()");
+    block_first[g] = bwtm_slice_block_first(slice); block_count[g] = bwtm_slice_blocks(slice);
+    if(g == 0)
+    {
+      // the result's arrays, sized now that the stream's length is known
+      const size_type nbytes = offsets[G], nblocks = (nbytes + Run::BLOCK_SIZE - 1) / Run::BLOCK_SIZE;
+      out.data.bytes.resizeUninitialized(nbytes);
+      out.block_end.resizeUninitialized(nblocks);
+      out.cum_stride = nblocks + 1;
+      out.cum_flat.resizeUninitialized(BWT::SIGMA * out.cum_stride);
+      for(size_type c = 0; c < BWT::SIGMA; c++) { out.cum_flat[c * out.cum_stride + nblocks] = merged.C[c + 1] - merged.C[c]; }
+      local.interleave_encode = readTimer() - t_i;
+    }
+    barrier.wait();
+
+    // Download: every slice into its place.
+    double t_d = readTimer();
+    gpuCheck(bwtm_slice_download_data(slice, out.data.bytes.data() + offsets[g], bwtm_slice_bytes(slice)), "mergeMultiGPU()");
+    if(block_count[g] > 0)
+    {
+      uint64_t next = a.size() + b.size();
+      for(size_type h = G; h-- > g + 1; ) { if(first_block_start[h] != ~(uint64_t)0) { next = first_block_start[h]; } }
+      HostArray<size_type> cum_local(BWT::SIGMA * block_count[g]);
+      gpuCheck(bwtm_slice_download_samples(slice, next, out.block_end.data() + block_first[g], cum_local.data()), "mergeMultiGPU()");
+      for(size_type c = 0; c < BWT::SIGMA; c++)
+      {
+        std::memcpy(out.cum_flat.data() + c * out.cum_stride + block_first[g], cum_local.data() + c * block_count[g], block_count[g] * sizeof(size_type));
+      }
+    }
+    bwtm_slice_free(slice);
+    barrier.wait();
+    if(g == 0) { local.download = readTimer() - t_d; }
+    gpuCheck(bwtm_context_make_current(nullptr), "mergeMultiGPU()");
+    bwtm_context_destroy(ctx);
+  };
+
+  std::vector<std::thread> threads;
+  for(size_type g = 1; g < G; g++) { threads.emplace_back(worker, g); }
+  worker(0);
+  for(std::thread& t : threads) { t.join(); }
+#ifdef BWTM_WITH_RCCL
+  for(ncclComm_t c : comms) { if(c) { ncclCommDestroy(c); } }
+#endif
+
+  out.header.sequences = a.sequences() + b.sequences();
+  out.header.bases = a.size() + b.size();
+  out.header.setOrder(a.bwt.header.order());
+  out.adoptHost(nullptr, out.block_end.size());
+  result.alpha = merged;
+  a.bwt.clear(); b.bwt.clear();
+  local.total = readTimer() - t0;
+  if(times) { *times = local; }
+}
+
+} // namespace bwtmerge
+
+#endif // BWTM_HOST_MULTI_GPU_H

@@ -20,6 +20,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_chunk_popc(const u64* bits, u
   if(lane_id() == 0) { cnt[chunk] = v; }
 }
 
+// dst |= src over the words of two interleaving bitvectors (shards of one rank array searched into separate buffers of the same
+// device; the bits of different shards are disjoint).
+__global__ void __launch_bounds__(BLOCK_THREADS) k_bits_or(u64* dst, const u64* src, u64 nwords)
+{
+  u64 k = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(k < nwords) { u64 v = src[k]; if(v != 0) { dst[k] |= v; } }
+}
+
 // RA[i] for every B position (tests / facade): one wave per chunk, one lane per record.
 __global__ void __launch_bounds__(BLOCK_THREADS) k_ra_extract(const u64* bits, const u64* chunk_base, u64 nchunks, u64 nb, u64* ra)
 {

@@ -156,6 +156,10 @@ int bwtm_search(const bwtm_index* a, const bwtm_index* b, uint64_t seq_first, ui
    computed on different GPUs can be combined with one collective (sum == or, set bits are
    disjoint). */
 int bwtm_ra_device_buffer(bwtm_ra* ra, void** device_ptr, uint64_t* nbytes);
+/* ra |= the interleaving bitvector of another rank array for the same inputs that lives ON THE SAME DEVICE (shards
+   searched into separate buffers, e.g. by two contexts of one GPU); across devices use a collective on
+   bwtm_ra_device_buffer().  Blocking. */
+int bwtm_ra_or_from(bwtm_ra* ra, const void* device_bits, uint64_t nbytes);
 /* Finishes the rank array after all bwtm_search() calls / the exchange. */
 int bwtm_ra_finalize(bwtm_ra* ra);
 uint64_t bwtm_ra_values(const bwtm_ra* ra);   /* number of set bits after finalize (must equal bases of b) */

@@ -140,6 +140,25 @@ def test_rank_array_runs_form(gpu, oracle):
     assert ra.runs()[0].size == 0
 
 
+def test_shards_in_separate_buffers_of_one_gpu(gpu, oracle):
+    """bwtm_ra_or_from: shards searched into separate rank arrays on one device are united (what the multi-GPU host does
+    when its "GPUs" are contexts of one GPU; across devices the same union is an all-reduce)."""
+    a = oracle.FMI.from_text(oracle.generate_reads(8300, 1500, 80)); b = oracle.FMI.from_text(oracle.generate_reads(8301, 1700, 90))
+    oranks, ocounts, _ = oracle.search(a, b, threads=2)
+    A, B = upload(gpu, a), upload(gpu, b)
+    parts = []
+    for first, last in ((0, 499), (500, 1199), (1200, 1699)):
+        ra = gpu.RankArray(A, B)
+        ra.search(A, B, first, last)
+        parts.append(ra)
+    parts[0].or_from(parts[1]); parts[0].or_from(parts[2])
+    parts[0].finalize()
+    ranks, counts = parts[0].runs()
+    assert np.array_equal(ranks, oranks) and np.array_equal(counts, ocounts)
+    with pytest.raises(gpu.BwtmError):
+        parts[0].or_from(parts[1])                              # already finalized
+
+
 def test_upload_rejects_inconsistent_alphabet(gpu, oracle):
     """A caller-supplied C must agree with the symbol counts of the stream (it feeds every LF step)."""
     f = oracle.FMI.from_text(oracle.generate_reads(5, 40, 30))

@@ -85,6 +85,29 @@ def test_cli_chained_merge_with_verification(bwtm, oracle, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_one_thread_per_gpu(bwtm, oracle, tmp_path):
+    """bwt_merge -g 0,0,0: three host threads, each with its own context (here on the same GPU), shard the search and
+    produce one output slice each; the file equals the single-GPU result, also for a chained merge."""
+    build_host()
+    sets = [oracle.generate_reads(4100 + k, 2500 + 300 * k, 100) for k in range(3)]
+    names = []
+    for k, t in enumerate(sets):
+        names.append(str(tmp_path / ("in%d.plain" % k)))
+        write_plain(names[-1], oracle.FMI.from_text(t))
+    exe = os.path.join(HOST, "bwt_merge")
+    outs = {}
+    for label, g in (("one", "0"), ("three", "0,0,0")):
+        out = subprocess.run([exe, "-g", g, "-i", "plain_default", names[0], names[1], names[2], str(tmp_path / (label + ".native"))],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert out.stdout.count("BWTs merged in ") == 2
+        outs[label] = np.fromfile(tmp_path / (label + ".native"), dtype=np.uint8)
+    assert np.array_equal(outs["one"], outs["three"])
+    direct = oracle.FMI.from_text(np.concatenate(sets))
+    assert np.array_equal(outs["three"][32:32 + direct.nbytes], direct.data)           # header (24 B) + byte count (8 B), then BWT::data
+
+
+@pytest.mark.gpu
 def test_cli_errors_like_reference(bwtm, tmp_path):
     build_host()
     exe = os.path.join(HOST, "bwt_merge")
