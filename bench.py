@@ -214,6 +214,15 @@ def main():
     if rank == 0 and last is not None and not args.no_verify and not sharded:
         verified, checks = verify_full_size(pkg, synth, np, last, meta, args, wargs, load_inputs)
         log("full-size verification: %s %s" % (verified, checks))
+    if sharded and last is not None and not args.no_verify:
+        # every rank: its slice of the sharded result == the same byte range of the result it computes alone
+        ok = verify_slice(pkg, np, last, load_inputs)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        verified = bool(flag.item() == 1)
+        checks = {"every_slice_equals_the_single_gpu_result": verified, "slices": world}
+        if rank == 0:
+            log("sharded verification: %s" % verified)
     if last is not None:
         last.free()
 
@@ -298,6 +307,22 @@ def verify_full_size(pkg, synth, np, last, meta, args, wargs, load_inputs):
         checks["frontier_equals_walk"] = bool(np.array_equal(bits[0], bits[1]))
         del bits
     return all(v for k, v in checks.items() if isinstance(v, bool)), checks
+
+
+def verify_slice(pkg, np, slice_, load_inputs):
+    """The bytes of this rank's output slice against the same range of the stream the rank computes on its own."""
+    A, B = load_inputs()
+    full = pkg.merge_consume(A, B)
+    ok = (full.nbytes == slice_.total_nbytes)
+    first, count = slice_.byte_first, slice_.nbytes
+    if ok and count > 0:
+        ptr, _ = full.device_data()
+        ref = np.zeros(count, dtype=np.uint8)
+        hip = ctypes.CDLL("libamdhip64.so.7")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        ok = (hip.hipMemcpy(ref.ctypes.data, ptr + first, count, 2) == 0) and bool(np.array_equal(ref, slice_.data()))
+    full.free()
+    return ok
 
 
 def host_to_host(pkg, np, torch, dev, host_in, meta, args):

@@ -6,6 +6,12 @@
   UNVERIFIED AGAINST REAL SDSL OUTPUT: sdsl-lite is not available in this environment, so files
   written here round-trip through this reader (tests) but byte compatibility with SDSL-built
   files is unpinned.  Only serialization is provided; queries use plain arrays (bwt.h).
+  The payload the hot path computes (header, BWT::data, the sample VALUES, C) is pinned against the
+  oracle; what is unpinned is the bit layout of sd_vector / select_support_mcl around those values.
+  The select supports follow sdsl-lite's two construction paths as recalled: vectors below 100 000
+  bits take init_slow (every superblock, the last partial one included, is long or mini by its span),
+  larger ones init_fast (the last partial superblock is always stored long, with the width of the
+  vector's last position, and its entry in the superblock array is left 0).
 */
 #ifndef BWTM_HOST_SDSL_COMPAT_H
 #define BWTM_HOST_SDSL_COMPAT_H
@@ -84,12 +90,15 @@ struct SelectMCL
     size_type capacity = ((n + 63) / 64) * 64;
     size_type logn = hi(capacity) + 1, logn4 = logn * logn * logn * logn;
     size_type sb = (arg_cnt + SUPER - 1) / SUPER;
+    const bool fast = (n >= 100000);                                   // select_support_mcl's constructor: init_slow below, init_fast from there on
+    const bool tail_long = (fast && arg_cnt % SUPER != 0);             // init_fast: "handle last block: append long superblock"
     PackedVector superblock(sb, logn);
     std::vector<bool> is_long(sb, false);
     bool any_long = false;
     for(size_type s = 0; s < sb; s++)
     {
       size_type first = args[s * SUPER], last = args[std::min(arg_cnt, (s + 1) * SUPER) - 1];
+      if(tail_long && s + 1 == sb) { is_long[s] = true; any_long = true; continue; }   // its superblock entry stays 0
       superblock.set(s, first);
       if(last - first > logn4) { is_long[s] = true; any_long = true; }
     }
@@ -102,7 +111,7 @@ struct SelectMCL
       size_type begin = s * SUPER, end = std::min(arg_cnt, (s + 1) * SUPER);
       if(is_long[s])
       {
-        PackedVector block(SUPER, hi(args[end - 1]) + 1);
+        PackedVector block(SUPER, (tail_long && s + 1 == sb ? hi(n - 1) : hi(args[end - 1])) + 1);
         for(size_type k = begin; k < end; k++) { block.set(k - begin, args[k]); }
         block.serialize(out, true);
       }

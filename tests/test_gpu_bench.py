@@ -41,4 +41,4 @@ def test_bench_distributed_path_on_one_rank(bwtm):
     d = run_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                    "--master-port", "29517", "bench.py", "--gpus", "1", "--force-dist", "--reads", "200000", "--steps", "2", "--warmup", "1",
                    "--no-cpu-baseline"])
-    assert d["value"] > 0 and d["config"]["native_bytes"][2] > 0
+    assert d["value"] > 0 and d["config"]["native_bytes"][2] > 0 and d["verified"] is True
