@@ -342,11 +342,17 @@ def host_to_host(pkg, np, torch, dev, host_in, meta, args):
         times.append(dt)
         if best is None or dt <= min(times):
             best = dict(res.times)
-    t_data = []
+    t_data, t_compact, compact_phases, width = [], [], None, None
     for _ in range(2):
         t0 = time.perf_counter()
         r2 = pkg.merge_host(a, b, samples=False, buffers=buffers)
         t_data.append(time.perf_counter() - t0)
+    for k in range(3):                                                   # the first call allocates the buffers of the compact form
+        t0 = time.perf_counter()
+        r3 = pkg.merge_host(a, b, samples=2, buffers=buffers)
+        if k > 0:
+            t_compact.append(time.perf_counter() - t0)
+        compact_phases, width = dict(r3.times), r3.out.sample_width
     # PCIe calibration: plain page-locked copies of the same buffers
     hip = ctypes.CDLL("libamdhip64.so.7")
     hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
@@ -374,6 +380,9 @@ def host_to_host(pkg, np, torch, dev, host_in, meta, args):
             "phases_ms": {k: round(v, 2) for k, v in best.items()},
             "data_only": {"value": round(merged / 1e9 / min(t_data), 4), "ms_per_step": round(min(t_data) * 1e3, 2),
                           "note": "without the D2H of the samples"},
+            "compact_samples": {"value": round(merged / 1e9 / (sum(t_compact) / len(t_compact)), 4), "ms_per_step": round(sum(t_compact) / len(t_compact) * 1e3, 2),
+                                "sample_width": width, "phases_ms": {k: round(v, 2) for k, v in compact_phases.items()},
+                                "note": "samples as %d-byte fields + anchors (%d bytes per block instead of 56): what the C++ facade downloads" % (width, 6 * width + 1)},
             "bytes": {"h2d": in_bytes, "d2h_data": out_bytes, "d2h_samples": sample_bytes},
             "pcie": dict(cal, spec_GBs=PCIE_SPEC_GBS, transfer_floor_ms=round(floor_ms, 2))}
     log("host to host: %.1f ms per merge (%.2f Gbases/s); phases %s; pcie %s" % (sec * 1e3, host["value"], host["phases_ms"], host["pcie"]))

@@ -27,6 +27,7 @@ class HostOutput(C.Structure):
     """bwtm_host_output"""
     _fields_ = [("data", C.c_void_p), ("nbytes", u64), ("blocks", u64), ("sequences", u64), ("bases", u64),
                 ("C", u64 * (SIGMA + 1)), ("block_end", C.c_void_p), ("cum", C.c_void_p),
+                ("sample_width", C.c_int), ("fields", C.c_void_p), ("anchors", C.c_void_p),
                 ("ms_upload", C.c_double), ("ms_search", C.c_double), ("ms_interleave", C.c_double),
                 ("ms_encode_download", C.c_double), ("ms_samples", C.c_double), ("ms_total", C.c_double)]
 
@@ -82,6 +83,8 @@ SYMBOLS = [
     ("bwtm_index_device_data", C.c_int, [vp, C.POINTER(vp), p_u64]),
     ("bwtm_index_download_data", C.c_int, [vp, p_u8, u64]),
     ("bwtm_index_download_samples", C.c_int, [vp, p_u64, p_u64]),
+    ("bwtm_index_samples_width", C.c_int, [vp, C.POINTER(C.c_int)]),
+    ("bwtm_index_download_samples_compact", C.c_int, [vp, C.c_int, vp, p_u64]),
     ("bwtm_rank_batch", C.c_int, [vp, p_u64, p_u8, u64, p_u64]),
     ("bwtm_inverse_select_batch", C.c_int, [vp, p_u64, u64, p_u64, p_u8]),
     ("bwtm_find_batch", C.c_int, [vp, p_u8, p_u64, u64, p_u64, p_u64]),
@@ -223,11 +226,38 @@ class HostMerge:
             self.keep.free()
             self.keep = None
 
+    def expanded_samples(self):
+        """(block_end, cum) whatever form the call returned."""
+        if self.out.sample_width == 8:
+            return self.block_end, self.cum
+        return expand_samples(self.out.sample_width, self.fields, self.anchors, self.out.blocks, self.out.bases)
+
+    fields = property(lambda s: s.buffers[3].array.view(np.uint16 if s.out.sample_width == 2 else np.uint32)[: SIGMA * s.out.blocks].reshape(SIGMA, s.out.blocks))
+    anchors = property(lambda s: s.buffers[4].array.view(np.uint64)[: SIGMA * ((s.out.blocks + 63) // 64)].reshape(SIGMA, (s.out.blocks + 63) // 64))
     data = property(lambda s: s.buffers[0].array[: s.out.nbytes])
     block_end = property(lambda s: s.buffers[1].array.view(np.uint64)[: s.out.blocks])
     cum = property(lambda s: s.buffers[2].array.view(np.uint64)[: SIGMA * (s.out.blocks + 1)].reshape(SIGMA, s.out.blocks + 1))
     C = property(lambda s: np.array(list(s.out.C), dtype=np.uint64))
     times = property(lambda s: {k: getattr(s.out, k) for k in ("ms_upload", "ms_search", "ms_interleave", "ms_encode_download", "ms_samples", "ms_total")})
+
+
+def expand_samples(width, fields, anchors, blocks, bases):
+    """Compact samples -> (block_end[blocks], cum[6][blocks + 1]) as bwtm_index_download_samples returns them."""
+    f = fields.astype(np.uint64)
+    k = np.arange(blocks, dtype=np.int64)
+    group = k // 64
+    excl = np.cumsum(f, axis=1) - f                                  # exclusive prefix over all blocks ...
+    first = excl[:, (group * 64)]                                    # ... minus the prefix at the block's anchor
+    at = anchors[:, group] + (excl - first)                          # row 0: block starts; rows 1..5: counts before the block
+    starts = at[0]
+    block_end = np.concatenate([starts[1:], np.array([bases], dtype=np.uint64)]) - np.uint64(1) if blocks > 0 else np.zeros(0, dtype=np.uint64)
+    cum = np.zeros((SIGMA, blocks + 1), dtype=np.uint64)
+    if blocks > 0:
+        cum[1:, :blocks] = at[1:]
+        cum[1:, blocks] = at[1:, -1] + f[1:, -1]
+        cum[0, :blocks] = starts - at[1:].sum(axis=0)
+        cum[0, blocks] = np.uint64(bases) - cum[1:, blocks].sum()
+    return block_end, cum
 
 
 def _host_input(data, sequences, bases):
@@ -239,6 +269,7 @@ def _host_input(data, sequences, bases):
 def merge_host(a, b, samples=True, keep=False, chained=None, buffers=None):
     """FMI::FMI(a, b) from host-resident inputs to a host-resident result (bwtm_merge_host).
     a, b: (data uint8 array, sequences, bases); chained: a device Index (consumed) instead of a.
+    samples: False / 0 = none, True / 1 = block_end + cum, 2 = the compact form (fields + anchors).
     buffers: a dict that keeps the page-locked output buffers between calls (they are reused when large enough)."""
     res = HostMerge()
     if buffers is not None:
@@ -258,10 +289,10 @@ def merge_host(a, b, samples=True, keep=False, chained=None, buffers=None):
     kp = vp()
     if chained is not None:
         h, chained.h = chained.h, None                     # consumed by the call
-        rc = lib().bwtm_merge_host_chained(h, C.byref(hb), cb, None, 1 if samples else 0, C.byref(res.out), C.byref(kp) if keep else None)
+        rc = lib().bwtm_merge_host_chained(h, C.byref(hb), cb, None, int(samples), C.byref(res.out), C.byref(kp) if keep else None)
     else:
         ha = _host_input(*a)
-        rc = lib().bwtm_merge_host(C.byref(ha), C.byref(hb), cb, None, 1 if samples else 0, C.byref(res.out), C.byref(kp) if keep else None)
+        rc = lib().bwtm_merge_host(C.byref(ha), C.byref(hb), cb, None, int(samples), C.byref(res.out), C.byref(kp) if keep else None)
     if rc != 0:
         if buffers is None:
             res.free()
@@ -370,6 +401,20 @@ class Index:
         cum = np.zeros((SIGMA, nb + 1), dtype=np.uint64)
         check(lib().bwtm_index_download_samples(self.h, be.ctypes.data_as(p_u64), cum.ctypes.data_as(p_u64)))
         return be, cum
+
+    def samples_compact(self, width=None):
+        """(width, fields [6][blocks] of uint16 / uint32, anchors [6][ceil(blocks / 64)] uint64); see include/bwtm.h."""
+        if width is None:
+            w = C.c_int(0)
+            check(lib().bwtm_index_samples_width(self.h, C.byref(w)))
+            width = w.value
+        if width == 8:
+            return 8, None, None
+        nb = self.blocks
+        fields = np.zeros((SIGMA, nb), dtype=(np.uint16 if width == 2 else np.uint32))
+        anchors = np.zeros((SIGMA, (nb + 63) // 64), dtype=np.uint64)
+        check(lib().bwtm_index_download_samples_compact(self.h, width, fields.ctypes.data_as(vp), anchors.ctypes.data_as(p_u64)))
+        return width, fields, anchors
 
     def rank(self, positions, comps):
         positions, pp = _u64(positions)

@@ -353,6 +353,66 @@ int download_samples(bwtm_index* x, u64* block_end, u64* cum)
   return BWTM_OK;
 }
 
+// Width of the compact sample fields: 2 or 4 bytes when every block encodes fewer than 2^16 - 1 / 2^32 - 1 positions, else 8
+// (= use the full arrays).  Synchronises.
+int samples_width(bwtm_index* x, int* width)
+{
+  *width = 2;
+  if(x->nblocks == 0) { return BWTM_OK; }
+  DevBuf m; TRY(m.alloc(sizeof(u64), true));
+  LAUNCH("block_field_max", k_block_field_max, div_up(x->nblocks, BLOCK_THREADS), BLOCK_THREADS, x->view(), x->block_start.as<const u64>(), x->nblocks,
+    m.as<unsigned long long>());
+  TRY(fetch_u64(m.as<u64>(), 0));
+  HIP_TRY(hipStreamSynchronize(CTX.stream));
+  const u64 mx = CTX.host_scratch[0];
+  *width = (mx < 0xFFFFull ? 2 : (mx < 0xFFFFFFFFull ? 4 : 8));
+  return BWTM_OK;
+}
+
+// Compact samples to the host, chunked through two staging buffers like download_samples.
+template<class T>
+int download_samples_compact(bwtm_index* x, T* fields, u64* anchors)
+{
+  const u64 nb = x->nblocks, nanch = div_up(nb, 64);
+  if(nb == 0) { return BWTM_OK; }
+  const u64 CH = 1ull << 22;                                  // blocks per chunk (a multiple of 64)
+  DevBuf stage_f[2], stage_a[2];
+  hipEvent_t filled[2] = {nullptr, nullptr}, drained[2] = {nullptr, nullptr};
+  auto body = [&]() -> int
+  {
+    for(int k = 0; k < 2; k++)
+    {
+      TRY(stage_f[k].alloc(6 * CH * sizeof(T))); TRY(stage_a[k].alloc(6 * (CH / 64) * sizeof(u64)));
+      HIP_TRY(hipEventCreateWithFlags(&filled[k], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&drained[k], hipEventDisableTiming));
+    }
+    u64 round = 0;
+    for(u64 b0 = 0; b0 < nb; b0 += CH, round++)
+    {
+      const int k = (int)(round & 1);
+      const u64 cnt = std::min(CH, nb - b0), na = div_up(cnt, 64);
+      if(round >= 2) { HIP_TRY(hipStreamWaitEvent(CTX.stream, drained[k], 0)); }
+      LAUNCH("block_fields", k_block_fields<T>, div_up(cnt, BLOCK_THREADS), BLOCK_THREADS, x->view(), x->block_start.as<const u64>(), b0, cnt,
+        stage_f[k].as<T>(), CH, stage_a[k].as<u64>(), CH / 64);
+      HIP_TRY(hipEventRecord(filled[k], CTX.stream));
+      HIP_TRY(hipStreamWaitEvent(CTX.copy_stream, filled[k], 0));
+      for(u64 c = 0; c < 6; c++)
+      {
+        HIP_TRY(hipMemcpyAsync(fields + c * nb + b0, stage_f[k].as<T>() + c * CH, cnt * sizeof(T), hipMemcpyDeviceToHost, CTX.copy_stream));
+        HIP_TRY(hipMemcpyAsync(anchors + c * nanch + b0 / 64, stage_a[k].as<u64>() + c * (CH / 64), na * sizeof(u64), hipMemcpyDeviceToHost, CTX.copy_stream));
+      }
+      HIP_TRY(hipEventRecord(drained[k], CTX.copy_stream));
+    }
+    return BWTM_OK;
+  };
+  int rc = body();
+  hipError_t e1 = hipStreamSynchronize(CTX.copy_stream), e2 = hipStreamSynchronize(CTX.stream);
+  for(int k = 0; k < 2; k++) { if(filled[k]) { (void)hipEventDestroy(filled[k]); } if(drained[k]) { (void)hipEventDestroy(drained[k]); } }
+  if(rc != BWTM_OK) { return rc; }
+  if(e1 != hipSuccess || e2 != hipSuccess) { return fail(BWTM_ENODEV, "sample download failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); }
+  return BWTM_OK;
+}
+
 } // namespace
 
 //------------------------------------------------------------------------------
@@ -491,6 +551,26 @@ extern "C" int bwtm_index_download_samples(bwtm_index* x, uint64_t* block_end, u
   ENTER(x->ctx);
   if(!x->has_native) { return fail(BWTM_EINVAL, "index has no native samples (call bwtm_index_encode first)"); }
   return download_samples(x, block_end, cum);
+}
+
+extern "C" int bwtm_index_samples_width(bwtm_index* x, int* width)
+{
+  if(!x || !width) { return fail(BWTM_EINVAL, "bwtm_index_samples_width: null argument"); }
+  ENTER(x->ctx);
+  if(!x->has_native) { return fail(BWTM_EINVAL, "index has no native samples (call bwtm_index_encode first)"); }
+  return samples_width(x, width);
+}
+
+extern "C" int bwtm_index_download_samples_compact(bwtm_index* x, int width, void* fields, uint64_t* anchors)
+{
+  if(!x) { return fail(BWTM_EINVAL, "null index"); }
+  ENTER(x->ctx);
+  if(!x->has_native) { return fail(BWTM_EINVAL, "index has no native samples (call bwtm_index_encode first)"); }
+  if(x->nblocks > 0 && (!fields || !anchors)) { return fail(BWTM_EINVAL, "bwtm_index_download_samples_compact: null argument"); }
+  int need = 0; TRY(samples_width(x, &need));
+  if(width != 2 && width != 4) { return fail(BWTM_EINVAL, "bwtm_index_download_samples_compact: width must be 2 or 4"); }
+  if(width < need) { return fail(BWTM_EINVAL, "bwtm_index_download_samples_compact: a block encodes too many positions for %d-byte fields (need %d)", width, need); }
+  return (width == 2 ? download_samples_compact<unsigned short>(x, (unsigned short*)fields, anchors) : download_samples_compact<u32>(x, (u32*)fields, anchors));
 }
 
 extern "C" int bwtm_rank_batch(const bwtm_index* x, const uint64_t* positions, const uint8_t* comps, uint64_t count, uint64_t* out_ranks)

@@ -17,7 +17,7 @@ int interleave_impl(const bwtm_index* a, const bwtm_index* b, bwtm_ra* ra, bwtm_
   TRY(x->sup.alloc(x->nsup * SUP_STRIDE * sizeof(u64)));
   LAUNCH("interleave_sup", k_interleave_sup, div_up(x->nsup, BLOCK_THREADS), BLOCK_THREADS, a->view(), b->view(),
     ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), x->n, x->sup.as<u64>(), x->nsup);
-  LAUNCH("interleave", k_interleave, div_up(ra->nchunks * WAVE, BLOCK_THREADS), BLOCK_THREADS, a->view(), b->view(),
+  LAUNCH("interleave", k_interleave, ra->nchunks, BLOCK_THREADS, a->view(), b->view(),
     ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), (u64)0, ra->nchunks, (u64)0, x->nrecs, x->sup.as<const u64>(), x->recs.as<uint4>());
   return BWTM_OK;
 }
@@ -123,6 +123,7 @@ int merge_host_impl(bwtm_index* a_dev, const bwtm_host_input* a_host, const bwtm
     out->sequences = x->m; out->bases = x->n;
     for(int c = 0; c <= 6; c++) { out->C[c] = x->C[c]; }
     out->data = nullptr; out->nbytes = 0; out->blocks = 0; out->block_end = nullptr; out->cum = nullptr;
+    out->sample_width = 0; out->fields = nullptr; out->anchors = nullptr;
     std::unique_ptr<EncodePlan> plan_holder(new EncodePlan());
     EncodePlan& plan = *plan_holder;
     if(x->n > 0) { TRY(encode_size(x, plan)); }
@@ -135,17 +136,28 @@ int merge_host_impl(bwtm_index* a_dev, const bwtm_host_input* a_host, const bwtm
     if(x->n > 0) { TRY(encode_emit(x, plan, out->data)); }
     else { TRY(encode_blocking(x)); }
     plan_holder.reset();                                           // the size tables return to the pool
-    if(want_samples)
+    int width = 8;
+    if(want_samples == BWTM_SAMPLES_COMPACT) { TRY(samples_width(x, &width)); }      // queued behind the encoder; its wait overlaps with the data's D2H
+    if(want_samples && width == 8)
     {
       out->block_end = (u64*)alloc(user, BWTM_BUF_BLOCK_END, out->blocks * sizeof(u64));
       out->cum = (u64*)alloc(user, BWTM_BUF_CUM, 6 * (out->blocks + 1) * sizeof(u64));
       if((!out->block_end && out->blocks > 0) || !out->cum) { return fail(BWTM_ENOMEM, "bwtm_merge_host: the caller's allocator returned no buffer for the samples"); }
     }
+    else if(want_samples)
+    {
+      out->fields = alloc(user, BWTM_BUF_FIELDS, 6 * out->blocks * (u64)width);
+      out->anchors = (u64*)alloc(user, BWTM_BUF_ANCHORS, 6 * div_up(out->blocks, 64) * sizeof(u64));
+      if(out->blocks > 0 && (!out->fields || !out->anchors)) { return fail(BWTM_ENOMEM, "bwtm_merge_host: the caller's allocator returned no buffer for the samples"); }
+    }
+    if(want_samples) { out->sample_width = width; }
     HIP_TRY(hipStreamSynchronize(CTX.copy_stream));
     HIP_TRY(hipStreamSynchronize(CTX.stream));
     const double t4 = now_ms();
     out->ms_encode_download = t4 - t3;
-    if(want_samples) { TRY(download_samples(x, out->block_end, out->cum)); }
+    if(want_samples && width == 8) { TRY(download_samples(x, out->block_end, out->cum)); }
+    else if(want_samples && width == 2) { TRY(download_samples_compact<unsigned short>(x, (unsigned short*)out->fields, out->anchors)); }
+    else if(want_samples) { TRY(download_samples_compact<u32>(x, (u32*)out->fields, out->anchors)); }
     const double t5 = now_ms();
     out->ms_samples = t5 - t4;
     out->ms_total = t5 - t0;

@@ -64,7 +64,8 @@ public:
   BWT() {}
   ~BWT() { dropDevice(); }
   // A copy shares nothing with the original: the host form is copied, the device copy is not.
-  BWT(const BWT& other) : header(other.header), data(other.hostData()), block_end(other.block_end), cum_flat(other.cum_flat), cum_stride(other.cum_stride) {}
+  BWT(const BWT& other) : header(other.header), data(other.hostData()), block_end(other.block_end), cum_flat(other.cum_flat), cum_stride(other.cum_stride),
+    sample_width(other.sample_width), fields(other.fields), anchors(other.anchors) {}
   BWT(BWT&& other) noexcept { swap(other); }
   BWT& operator=(const BWT& other) { if(this != &other) { BWT copy(other); swap(copy); } return *this; }
   BWT& operator=(BWT&& other) noexcept { if(this != &other) { BWT moved(std::move(other)); swap(moved); } return *this; }
@@ -87,22 +88,89 @@ public:
   {
     std::swap(header, other.header); data.swap(other.data); block_end.swap(other.block_end);
     cum_flat.swap(other.cum_flat); std::swap(cum_stride, other.cum_stride);
+    std::swap(sample_width, other.sample_width); fields.swap(other.fields); anchors.swap(other.anchors);
     std::swap(device, other.device); std::swap(host_current, other.host_current);
   }
 
   size_type size() const { return header.bases; }
   size_type sequences() const { return header.sequences; }
   size_type bytes() const { materialize(); return data.size(); }
-  size_type blocks() const { materialize(); return block_end.size(); }
+  size_type blocks() const { materialize(); return cum_stride == 0 ? 0 : cum_stride - 1; }
   size_type count(comp_type c) const { materialize(); return cum_stride == 0 ? 0 : cum(c, cum_stride - 1); }
 
+  // The samples exist in one of two forms.  FULL (sample_width == 8): block_end[] and cum_flat[6][blocks + 1], the values
+  // block_boundaries and samples[c] hold.  COMPACT (2 or 4; what a merge downloads: 12 or 24 instead of 56 bytes per block):
+  // FIELDS [6][blocks] = positions in block k and its occurrences of 1..5, ANCHORS [6][blocks / 64] = start position and
+  // counts before every 64th block (include/bwtm.h).  The accessors below hide the difference; expandSamples() converts.
+  size_type field(size_type c, size_type k) const
+  {
+    const size_type at = c * (cum_stride - 1) + k;
+    return (sample_width == 2 ? (size_type)fields[at] : (size_type)((const std::uint32_t*)fields.data())[at]);
+  }
+  // start position (c == 0) / occurrences of c (1..5) before block k, k <= blocks, compact form
+  size_type compactAt(size_type c, size_type k) const
+  {
+    const size_type nb = cum_stride - 1, nanch = (nb + 63) / 64;
+    size_type g = k / 64, from = g * 64;
+    if(g >= nanch) { g = nanch - 1; from = g * 64; }          // k == blocks on a group boundary: walk the last group
+    size_type v = anchors[c * nanch + g];
+    for(size_type j = from; j < k; j++) { v += field(c, j); }
+    return v;
+  }
+  size_type blockStart(size_type k) const
+  {
+    if(sample_width == 8) { return (k == 0 ? 0 : block_end[k - 1] + 1); }
+    return (cum_stride <= 1 ? 0 : compactAt(0, k));
+  }
+  size_type blockEnd(size_type k) const { return (sample_width == 8 ? block_end[k] : blockStart(k + 1) - 1); }
+
   // samples[c].sum(k): occurrences of c in blocks [0, k)  (CumulativeArray::sum, support.h:338-343)
-  size_type cum(size_type c, size_type k) const { return cum_flat[c * cum_stride + k]; }
+  size_type cum(size_type c, size_type k) const
+  {
+    if(sample_width == 8) { return cum_flat[c * cum_stride + k]; }
+    if(cum_stride <= 1) { return 0; }
+    if(c != 0) { return compactAt(c, k); }
+    size_type rest = 0;
+    for(size_type s = 1; s < SIGMA; s++) { rest += compactAt(s, k); }
+    return compactAt(0, k) - rest;
+  }
   // The six sample arrays as vectors (tests, serialization).
   std::vector<size_type> cumulative(size_type c) const
   {
     materialize();
-    return std::vector<size_type>(cum_flat.begin() + c * cum_stride, cum_flat.begin() + (c + 1) * cum_stride);
+    std::vector<size_type> row(cum_stride);
+    for(size_type k = 0; k < cum_stride; k++) { row[k] = cum(c, k); }
+    return row;
+  }
+  std::vector<size_type> blockEnds() const
+  {
+    materialize();
+    std::vector<size_type> ends(blocks());
+    for(size_type k = 0; k < ends.size(); k++) { ends[k] = blockEnd(k); }
+    return ends;
+  }
+
+  // Compact -> full form (one pass; the queries below work on either).
+  void expandSamples() const
+  {
+    materialize();
+    if(sample_width == 8) { return; }
+    const size_type nb = cum_stride - 1, nanch = (nb + 63) / 64;
+    HostArray<size_type> ends(nb), flat(SIGMA * cum_stride);
+    size_type run[SIGMA] = {};
+    for(size_type k = 0; k <= nb; k++)
+    {
+      if(k < nb && k % 64 == 0) { for(size_type c = 0; c < SIGMA; c++) { run[c] = anchors[c * nanch + k / 64]; } }
+      size_type rest = 0;
+      for(size_type c = 1; c < SIGMA; c++) { flat[c * cum_stride + k] = run[c]; rest += run[c]; }
+      flat[k] = run[0] - rest;                                            // row 0: endmarkers = start - the five
+      if(k > 0) { ends[k - 1] = run[0] - 1; }
+      if(k < nb) { for(size_type c = 0; c < SIGMA; c++) { run[c] += field(c, k); } }
+    }
+    if(nb == 0) { for(size_type c = 0; c < SIGMA; c++) { flat[c * cum_stride] = 0; } }
+    block_end.swap(ends); cum_flat.swap(flat);
+    fields.clear(); fields.shrink_to_fit(); anchors.clear(); anchors.shrink_to_fit();
+    sample_width = 8;
   }
 
   // Number of occurrences of c in [0, i).
@@ -166,9 +234,11 @@ public:
   {
     if(c >= SIGMA || i == 0) { return 0; }
     if(i > count(c)) { return size(); }
-    const size_type* row = cum_flat.data() + c * cum_stride;
-    size_type block = (size_type)(std::lower_bound(row, row + cum_stride, i) - row) - 1;
-    size_type seen = row[block], rle_pos = block * SAMPLE_RATE, seq_pos = block_start(block);
+    // the last block k with cum(c, k) < i
+    size_type lo = 0, hi = cum_stride - 1;                   // cum(c, lo) < i <= cum(c, hi)
+    while(hi - lo > 1) { size_type mid = (lo + hi) / 2; if(cum(c, mid) < i) { lo = mid; } else { hi = mid; } }
+    size_type block = lo;
+    size_type seen = cum(c, block), rle_pos = block * SAMPLE_RATE, seq_pos = blockStart(block);
     while(true)
     {
       range_type run = Run::read(data, rle_pos);
@@ -232,7 +302,7 @@ public:
   // Builds the samples from the data (BWT::build) and fills the header from the counts.
   void buildFromData(AlphabeticOrder order = AO_DEFAULT)
   {
-    dropDevice(); host_current = true;
+    dropDevice(); host_current = true; sample_width = 8;
     std::vector<size_type> ends;
     std::vector<size_type> rows[SIGMA];
     for(size_type c = 0; c < SIGMA; c++) { rows[c].assign(1, 0); }
@@ -259,6 +329,8 @@ public:
   {
     block_end.clear(); block_end.shrink_to_fit();
     cum_flat.clear(); cum_flat.shrink_to_fit(); cum_stride = 0;
+    fields.clear(); fields.shrink_to_fit(); anchors.clear(); anchors.shrink_to_fit();
+    sample_width = 8;
   }
 
   // Drops everything: host bytes, samples, the device copy.
@@ -294,10 +366,10 @@ public:
   }
 
   // Takes over the host form a bwtm_merge_host call has just written into this object's arrays.
-  void adoptHost(bwtm_index* kept, size_type nblocks)
+  void adoptHost(bwtm_index* kept, size_type nblocks, int width = 8)
   {
     dropDevice();
-    device = kept; host_current = true; cum_stride = nblocks + 1;
+    device = kept; host_current = true; cum_stride = nblocks + 1; sample_width = width;
   }
 
   // Makes the host form current: encodes on the device, downloads data and samples (once).
@@ -308,10 +380,22 @@ public:
     data.bytes.resizeUninitialized(bwtm_index_bytes(device));
     gpuCheck(bwtm_index_download_data(device, data.bytes.data(), data.bytes.size()), "BWT::materialize()");
     size_type nblocks = bwtm_index_blocks(device);
-    block_end.resizeUninitialized(nblocks);
     cum_stride = nblocks + 1;
-    cum_flat.resizeUninitialized(SIGMA * cum_stride);
-    gpuCheck(bwtm_index_download_samples(device, block_end.data(), cum_flat.data()), "BWT::materialize()");
+    int width = 8;
+    gpuCheck(bwtm_index_samples_width(device, &width), "BWT::materialize()");
+    sample_width = width;
+    if(width == 8)
+    {
+      block_end.resizeUninitialized(nblocks);
+      cum_flat.resizeUninitialized(SIGMA * cum_stride);
+      gpuCheck(bwtm_index_download_samples(device, block_end.data(), cum_flat.data()), "BWT::materialize()");
+    }
+    else
+    {
+      anchors.resizeUninitialized(SIGMA * ((nblocks + 63) / 64));
+      fields.resizeUninitialized(SIGMA * nblocks * (size_type)width / 2);
+      gpuCheck(bwtm_index_download_samples_compact(device, width, fields.data(), anchors.data()), "BWT::materialize()");
+    }
     gpuCheck(bwtm_index_drop_native(device), "BWT::materialize()");         // keep only the rank structure on the device
     host_current = true;
   }
@@ -329,7 +413,8 @@ public:
     size_type padded = data.blocks() * BlockArray::BLOCK_SIZE;
     std::vector<char> zeros(std::min(padded - nbytes, (size_type)1 << 20), 0);
     for(size_type left = padded - nbytes; left > 0; ) { size_type n = std::min(left, (size_type)zeros.size()); out.write(zeros.data(), n); left -= n; }
-    size_type nblocks = block_end.size();
+    expandSamples();
+    size_type nblocks = blocks();
     for(size_type c = 0; c < SIGMA; c++)
     {
       // element k = (count of c in block k) zero bits followed by a one bit (support.h:290-294)
@@ -343,7 +428,7 @@ public:
 
   void load(std::istream& in)
   {
-    dropDevice(); host_current = true;
+    dropDevice(); host_current = true; sample_width = 8;
     header.load(in);
     if(!header.check()) { std::cerr << "BWT::load(): Invalid header!" << std::endl; std::exit(EXIT_FAILURE); }
     size_type nbytes = 0; sdsl_compat::read_member(nbytes, in);
@@ -372,6 +457,9 @@ public:
   mutable HostArray<size_type>   block_end;            // last sequence position of each block (block_boundaries)
   mutable HostArray<size_type>   cum_flat;             // [SIGMA][cum_stride]: cum(c, k) = #c in blocks [0, k) (samples[c])
   mutable size_type              cum_stride = 0;       // blocks + 1
+  mutable int                    sample_width = 8;     // 8: block_end + cum_flat; 2 / 4: fields16 / fields32 + anchors
+  mutable HostArray<std::uint16_t> fields;             // raw storage of the fields, 16 or 32 bits each (field())
+  mutable HostArray<size_type>   anchors;
 
 private:
   mutable bwtm_index* device = nullptr;                // device copy (rank structure only), owned
@@ -379,15 +467,27 @@ private:
 
   struct Cursor { size_type block, rle_pos, seq_pos; };
 
-  size_type block_start(size_type block) const { return (block == 0 ? 0 : block_end[block - 1] + 1); }
-
   // The block that holds position i (or the one after the last when i == size()).
   Cursor seek(size_type i) const
   {
     materialize();
     Cursor cur;
-    cur.block = (size_type)(std::lower_bound(block_end.begin(), block_end.end(), i) - block_end.begin());
-    cur.rle_pos = cur.block * SAMPLE_RATE; cur.seq_pos = block_start(cur.block);
+    if(sample_width == 8)
+    {
+      cur.block = (size_type)(std::lower_bound(block_end.begin(), block_end.end(), i) - block_end.begin());
+      cur.seq_pos = (cur.block == 0 ? 0 : block_end[cur.block - 1] + 1);
+    }
+    else
+    {
+      // the group whose anchor is the last one <= i, then a walk over at most 64 fields
+      const size_type nb = cum_stride - 1, nanch = (nb + 63) / 64;
+      size_type g = (nanch == 0 ? 0 : (size_type)(std::upper_bound(anchors.begin(), anchors.begin() + nanch, i) - anchors.begin()));
+      if(g > 0) { g--; }
+      size_type k = g * 64, start = (nanch == 0 ? 0 : anchors[g]);
+      while(k < nb && start + field(0, k) <= i) { start += field(0, k); k++; }
+      cur.block = k; cur.seq_pos = start;
+    }
+    cur.rle_pos = cur.block * SAMPLE_RATE;
     return cur;
   }
 };

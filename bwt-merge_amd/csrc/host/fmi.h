@@ -168,6 +168,8 @@ inline void* mergeSink(void* user, int what, uint64_t nbytes)
   case BWTM_BUF_DATA:      bwt->data.bytes.resizeUninitialized(std::max<uint64_t>(nbytes, 1)); bwt->data.bytes.resizeUninitialized(nbytes); return bwt->data.bytes.data();
   case BWTM_BUF_BLOCK_END: bwt->block_end.resizeUninitialized(std::max<uint64_t>(nbytes / sizeof(size_type), 1)); bwt->block_end.resizeUninitialized(nbytes / sizeof(size_type)); return bwt->block_end.data();
   case BWTM_BUF_CUM:       bwt->cum_flat.resizeUninitialized(nbytes / sizeof(size_type)); return bwt->cum_flat.data();
+  case BWTM_BUF_ANCHORS:   bwt->anchors.resizeUninitialized(std::max<uint64_t>(nbytes / sizeof(size_type), 1)); bwt->anchors.resizeUninitialized(nbytes / sizeof(size_type)); return bwt->anchors.data();
+  case BWTM_BUF_FIELDS:    bwt->fields.resizeUninitialized(std::max<uint64_t>(nbytes / 2, 1)); bwt->fields.resizeUninitialized(nbytes / 2); return bwt->fields.data();
   }
   return nullptr;
 }
@@ -209,15 +211,15 @@ inline FMI::FMI(FMI& a, FMI& b, MergeParameters parameters)
     b.bwt.dropDevice();
     if(a.bwt.deviceResident())
     {
-      gpuCheck(bwtm_merge_host_chained(a.bwt.releaseDevice(), &hb, mergeSink, &this->bwt, 1, &out, &kept), "FMI::FMI()");
+      gpuCheck(bwtm_merge_host_chained(a.bwt.releaseDevice(), &hb, mergeSink, &this->bwt, BWTM_SAMPLES_COMPACT, &out, &kept), "FMI::FMI()");
     }
     else
     {
       const BlockArray& adata = a.bwt.hostData();
       bwtm_host_input ha = { adata.data(), adata.size(), a.sequences(), a.size(), ca.data() };
-      gpuCheck(bwtm_merge_host(&ha, &hb, mergeSink, &this->bwt, 1, &out, &kept), "FMI::FMI()");
+      gpuCheck(bwtm_merge_host(&ha, &hb, mergeSink, &this->bwt, BWTM_SAMPLES_COMPACT, &out, &kept), "FMI::FMI()");
     }
-    this->bwt.adoptHost(kept, out.blocks);
+    this->bwt.adoptHost(kept, out.blocks, out.sample_width);
     a.bwt.clear(); b.bwt.clear();
   }
   this->alpha = merged;

@@ -97,8 +97,21 @@ int main(int argc, char** argv)
   }
   {
     FMI rebuilt; rebuilt.bwt.data = merged.bwt.data; rebuilt.bwt.buildFromData();
-    CHECK(rebuilt.bwt.block_end == merged.bwt.block_end);
+    CHECK(merged.bwt.sample_width == 2);                                     // the merge downloaded the compact samples
+    CHECK(rebuilt.bwt.blockEnds() == merged.bwt.blockEnds());
     for(size_type c = 0; c < 6; c++) { CHECK(rebuilt.bwt.cumulative(c) == merged.bwt.cumulative(c)); }
+    // queries on the compact form == queries on the full form
+    FMI expanded = merged; expanded.bwt.expandSamples();
+    CHECK(expanded.bwt.sample_width == 8 && expanded.bwt.block_end == rebuilt.bwt.block_end && expanded.bwt.cum_flat == rebuilt.bwt.cum_flat);
+    for(size_type i = 0; i <= merged.size(); i += 41)
+    {
+      for(comp_type c = 0; c < 6; c++) { CHECK(merged.bwt.rank(i, c) == expanded.bwt.rank(i, c)); }
+      if(i < merged.size()) { CHECK(merged.bwt.inverse_select(i) == expanded.bwt.inverse_select(i) && merged.bwt[i] == expanded.bwt[i]); }
+    }
+    for(comp_type c = 0; c < 6; c++)
+    {
+      for(size_type k = 1; k <= merged.bwt.count(c); k += 97) { CHECK(merged.bwt.select(k, c) == expanded.bwt.select(k, c)); }
+    }
     CHECK(rebuilt.bwt.header.sequences == merged.sequences() && rebuilt.bwt.header.bases == merged.size());
   }
 
@@ -121,7 +134,8 @@ int main(int argc, char** argv)
     FMI chained(on_device, b4, MergeParameters());                        // first input taken from the device
     FMI from_host(host_copy, b5, MergeParameters());                      // both inputs uploaded from the host
     CHECK(chained.size() == na + 2 * nb && chained.bwt.data.bytes == from_host.bwt.data.bytes);
-    CHECK(chained.bwt.block_end == from_host.bwt.block_end && chained.bwt.cum_flat == from_host.bwt.cum_flat);
+    CHECK(chained.bwt.blockEnds() == from_host.bwt.blockEnds());
+    for(size_type c = 0; c < 6; c++) { CHECK(chained.bwt.cumulative(c) == from_host.bwt.cumulative(c)); }
     CHECK(chained.alpha.C == from_host.alpha.C);
     FMI again = on_device;                                                // consumed above: empty
     CHECK(again.bwt.bytes() == 0);
@@ -137,7 +151,8 @@ int main(int argc, char** argv)
       FMI sharded; MultiGPUTimes times;
       mergeMultiGPU(*as[k], *bs[k], device_lists[k], sharded, &times);
       CHECK(sharded.bwt.data.bytes == expected);
-      CHECK(sharded.bwt.block_end == merged.bwt.block_end && sharded.bwt.cum_flat == merged.bwt.cum_flat);
+      CHECK(sharded.bwt.blockEnds() == merged.bwt.blockEnds());
+      for(size_type c = 0; c < 6; c++) { CHECK(sharded.bwt.cumulative(c) == merged.bwt.cumulative(c)); }
       CHECK(sharded.alpha.C == merged.alpha.C && sharded.size() == merged.size() && sharded.sequences() == merged.sequences());
       CHECK(as[k]->bwt.bytes() == 0 && times.total > 0);
     }
@@ -149,7 +164,7 @@ int main(int argc, char** argv)
     serialize(merged, name, "native");
     FMI back; load(back, name, "native");
     CHECK(back.bwt.data.bytes == merged.bwt.data.bytes);
-    CHECK(back.bwt.block_end == merged.bwt.block_end);
+    CHECK(back.bwt.blockEnds() == merged.bwt.blockEnds());
     for(size_type c = 0; c < 6; c++) { CHECK(back.bwt.cumulative(c) == merged.bwt.cumulative(c)); }
     CHECK(back.alpha == merged.alpha && back.alpha.C == merged.alpha.C);
     CHECK(back.bwt.header.sequences == merged.sequences() && back.bwt.header.bases == merged.size() && back.bwt.header.check());

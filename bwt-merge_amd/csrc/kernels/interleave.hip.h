@@ -121,42 +121,99 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_interleave_sup(IndexView A, I
   (void)n_out;
 }
 
+// One workgroup of 256 threads per chunk of 64 output records; FOUR lanes per record, lane k of a quad owns the 32 positions of
+// word k and writes the 16 bytes {plane0, plane1, plane2, header word k}: every wave store is 1 KiB of consecutive bytes.
+// A lane needs the number of B symbols before its word (= ones of the bitvector before it: chunk base + a workgroup scan of the
+// words' popcounts) -- that gives its cursors into A and B -- and, for the header, the number of each symbol before its record.
+// The latter comes from the OUTPUT itself: the lanes count the symbols of their finished words and a second workgroup scan turns
+// the counts into prefixes; only the counts at the chunk start are rank queries (two per 64 records instead of two per record).
 // The launch covers the chunks [chunk_first, chunk_end) and writes the records [q_lo, q_hi) among them (an output-range
 // slice also wants the one record before its range: the encoder looks at the symbol there).  recs_out is indexed by the
 // GLOBAL record number: a slice passes its buffer's address minus the offset of its first record.
+// The source symbols of a chunk are two contiguous ranges, at most 8192 positions of A and of B: their plane words are
+// staged in LDS with coalesced 16-byte loads (257 words cover 8192 positions at any alignment), and every lane then takes
+// the 32-bit windows at its two cursors from there.
+constexpr u32 IL_WORDS = 2 * CHUNK_WORDS + 8;            // 264 staged words per plane
+
+__device__ inline void stage_planes(const IndexView& x, u64 first_word, u32 (*planes)[IL_WORDS])
+{
+  const u64 last = 4 * x.nrecs;
+  for(u32 k = threadIdx.x; k < IL_WORDS; k += BLOCK_THREADS)
+  {
+    const u64 wi = first_word + k;
+    const uint4 v = (wi < last ? x.recs[wi] : make_uint4(0, 0, 0, 0));
+    planes[0][k] = v.x; planes[1][k] = v.y; planes[2][k] = v.z;
+  }
+}
+
+__device__ inline void window32(const u32 (*planes)[IL_WORDS], u64 first_word, u64 pos, u32& p0, u32& p1, u32& p2)
+{
+  const u32 k = (u32)((pos >> 5) - first_word), sh = (u32)(pos & 31);
+  p0 = (u32)((((u64)planes[0][k + 1] << 32) | planes[0][k]) >> sh);
+  p1 = (u32)((((u64)planes[1][k + 1] << 32) | planes[1][k]) >> sh);
+  p2 = (u32)((((u64)planes[2][k + 1] << 32) | planes[2][k]) >> sh);
+}
+
 __global__ void __launch_bounds__(BLOCK_THREADS) k_interleave(IndexView A, IndexView B, const u64* bits, const u64* chunk_base,
   u64 chunk_first, u64 chunk_end, u64 q_lo, u64 q_hi, const u64* sup_out, uint4* recs_out)
 {
-  u64 chunk = chunk_first + (((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6);
+  __shared__ u64 wave_tot[3][BLOCK_THREADS / WAVE];
+  __shared__ u64 base_rel[6];
+  __shared__ u32 planes_a[3][IL_WORDS], planes_b[3][IL_WORDS];
+  const u64 chunk = chunk_first + blockIdx.x;
   if(chunk >= chunk_end) { return; }
-  u64 q = chunk * 64 + lane_id();
-  u64 m0 = bits[2 * q], m1 = bits[2 * q + 1];
-  u64 mine = (u64)__builtin_popcountll(m0) + (u64)__builtin_popcountll(m1);
-  u64 incl = wave_incl_sum(mine);
-  if(q < q_lo || q >= q_hi) { return; }
-  u64 b_off = chunk_base[chunk] + incl - mine;
-  u64 a_off = (q << REC_SHIFT) - b_off;
+  const u32 t = threadIdx.x, lane = lane_id(), wave = t >> 6;
+  const u64 w = chunk * (2 * CHUNK_WORDS) + t;                     // 32-bit word of the bitvector = 32-position word of the output
+  const u32 m = ((const u32*)bits)[w];
+  const u64 ones = (u64)__builtin_popcount(m);
+  // counts at the chunk start, relative to the super table entry of the output (one lane; consumed after the barrier below)
+  const u64 b_chunk = chunk_base[chunk];
+  const u64 a_chunk = (chunk << (REC_SHIFT + 6)) - b_chunk;
+  const u64 wa0 = a_chunk >> 5, wb0 = b_chunk >> 5;
+  stage_planes(A, wa0, planes_a); stage_planes(B, wb0, planes_b);
+  if(t == 0)
+  {
+    u64 ra[6], rb[6];
+    index_ranks(A, (a_chunk > A.n ? A.n : a_chunk), ra);
+    index_ranks(B, (b_chunk > B.n ? B.n : b_chunk), rb);
+    const u64* sp = sup_out + ((chunk << 6) >> SUPER_REC_SHIFT) * SUP_STRIDE;
+    for(int c = 1; c < 6; c++) { base_rel[c] = ra[c] + rb[c] - sp[c]; }
+  }
+  // cursors: B symbols before this word
+  const u64 ones_incl = wave_incl_sum(ones);
+  if(lane == WAVE - 1) { wave_tot[0][wave] = ones_incl; }
+  __syncthreads();
+  u64 b_off = b_chunk + ones_incl - ones;
+  for(u32 k = 0; k < wave; k++) { b_off += wave_tot[0][k]; }
+  const u64 a_off = (w << 5) - b_off;
 
-  // Header: counts of symbols 1..5 before output position 128 q.
-  u64 ra[6], rb[6];
-  index_ranks(A, (a_off > A.n ? A.n : a_off), ra);
-  index_ranks(B, (b_off > B.n ? B.n : b_off), rb);
-  const u64* s = sup_out + (q >> SUPER_REC_SHIFT) * SUP_STRIDE;
+  u32 a0, a1, a2, b0, b1, b2;
+  window32(planes_a, wa0, a_off, a0, a1, a2); window32(planes_b, wb0, b_off, b0, b1, b2);
+  const ExpandMasks eb = expand_masks(m), ea = expand_masks(~m);
+  const u32 o0 = expand32(b0, eb) | expand32(a0, ea);
+  const u32 o1 = expand32(b1, eb) | expand32(a1, ea);
+  const u32 o2 = expand32(b2, eb) | expand32(a2, ea);
+
+  // symbol counts of this word -> prefixes over the chunk (16-bit fields: a chunk has 8192 positions)
+  const u64 c14 = (u64)__builtin_popcount(plane_match(o0, o1, o2, 1)) | ((u64)__builtin_popcount(plane_match(o0, o1, o2, 2)) << 16)
+                | ((u64)__builtin_popcount(plane_match(o0, o1, o2, 3)) << 32) | ((u64)__builtin_popcount(plane_match(o0, o1, o2, 4)) << 48);
+  const u64 c5 = (u64)__builtin_popcount(plane_match(o0, o1, o2, 5));
+  const u64 incl14 = wave_incl_sum(c14), incl5 = wave_incl_sum(c5);
+  if(lane == WAVE - 1) { wave_tot[1][wave] = incl14; wave_tot[2][wave] = incl5; }
+  __syncthreads();
+  u64 before14 = incl14 - c14, before5 = incl5 - c5;
+  for(u32 k = 0; k < wave; k++) { before14 += wave_tot[1][k]; before5 += wave_tot[2][k]; }
+  // the header belongs to the record: take the prefixes of the quad's first lane
+  const int first = (int)(lane & ~3u);
+  const u64 rec14 = shfl_u64(before14, first), rec5 = shfl_u64(before5, first);
   u32 rel[6]; u32 h[4];
-  for(int c = 1; c < 6; c++) { rel[c] = (u32)(ra[c] + rb[c] - s[c]); }
+  rel[0] = 0;
+  rel[1] = (u32)(base_rel[1] + (rec14 & 0xFFFF)); rel[2] = (u32)(base_rel[2] + ((rec14 >> 16) & 0xFFFF));
+  rel[3] = (u32)(base_rel[3] + ((rec14 >> 32) & 0xFFFF)); rel[4] = (u32)(base_rel[4] + (rec14 >> 48));
+  rel[5] = (u32)(base_rel[5] + rec5);
   pack_header(rel, h);
-
-  // Planes: two halves of 64 positions.
-  u64 a0, a1, a2, b0, b1, b2, lo0, lo1, lo2, hi0, hi1, hi2;
-  load_window(A, a_off, a0, a1, a2); load_window(B, b_off, b0, b1, b2);
-  deposit64(m0, a0, a1, a2, b0, b1, b2, lo0, lo1, lo2);
-  u64 nb0 = (u64)__builtin_popcountll(m0);
-  load_window(A, a_off + 64 - nb0, a0, a1, a2); load_window(B, b_off + nb0, b0, b1, b2);
-  deposit64(m1, a0, a1, a2, b0, b1, b2, hi0, hi1, hi2);
-
-  uint4* dst = recs_out + 4 * q;
-  dst[0] = make_uint4((u32)lo0, (u32)lo1, (u32)lo2, h[0]);
-  dst[1] = make_uint4((u32)(lo0 >> 32), (u32)(lo1 >> 32), (u32)(lo2 >> 32), h[1]);
-  dst[2] = make_uint4((u32)hi0, (u32)hi1, (u32)hi2, h[2]);
-  dst[3] = make_uint4((u32)(hi0 >> 32), (u32)(hi1 >> 32), (u32)(hi2 >> 32), h[3]);
+  const u32 k = lane & 3;
+  const u32 hk = (k == 0 ? h[0] : (k == 1 ? h[1] : (k == 2 ? h[2] : h[3])));
+  const u64 q = w >> 2;
+  if(q >= q_lo && q < q_hi) { recs_out[w] = make_uint4(o0, o1, o2, hk); }
 }

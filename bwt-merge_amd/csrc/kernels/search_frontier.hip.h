@@ -361,23 +361,37 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_tile_build_frontier(const uns
     }
     const u64 left = (nsteps - t0 + NW - 1) / NW;                  // steps of this wave from t0 on
     const u32 cnt = (left < (u64)WAVE ? (u32)left : (u32)WAVE);
+    // Software pipeline over the runs: the offsets of run j + 1 (the first 8 x 64 of them: a run of config 2 has ~330) are in
+    // flight while the bits of run j are set, so the wave always has dependent-load latency to hide behind LDS atomics.
+    constexpr u32 UN = 8;
+    u32 cur[UN], nxt[UN];
+    auto fetch = [&](u32 j, u32* off, u32& lo_out, u32& hi_out, u64& base_out)
+    {
+      lo_out = (u32)__shfl((int)my_lo, (int)j, WAVE); hi_out = (u32)__shfl((int)my_hi, (int)j, WAVE);
+      base_out = shfl_u64(my_base, (int)j);
+#pragma unroll
+      for(u32 u = 0; u < UN; u++)
+      {
+        const u64 kk = (u64)lo_out + lane + u * WAVE;
+        off[u] = (kk < hi_out && base_out + kk < emit_cap ? (u32)emit16[base_out + kk] : 0xFFFFFFFFu);
+      }
+    };
+    u32 lo = 0, hi = 0, nlo = 0, nhi = 0; u64 base = 0, nbase = 0;
+    if(cnt > 0) { fetch(0, cur, lo, hi, base); }
     for(u32 j = 0; j < cnt; j++)
     {
-      const u32 lo = (u32)__shfl((int)my_lo, (int)j, WAVE), hi = (u32)__shfl((int)my_hi, (int)j, WAVE);
-      const u64 base = shfl_u64(my_base, (int)j);
+      if(j + 1 < cnt) { fetch(j + 1, nxt, nlo, nhi, nbase); }
       seen |= (hi > lo);
-      for(u32 k = lo + lane; k < hi; k += 4 * WAVE)
+#pragma unroll
+      for(u32 u = 0; u < UN; u++) { if(cur[u] != 0xFFFFFFFFu) { atomicOr(&tile[cur[u] >> 5], 1u << (cur[u] & 31)); } }
+      // the rest of a long run (more than 512 emits of one step in one tile)
+      for(u64 k = (u64)lo + lane + UN * WAVE; k < hi; k += WAVE)
       {
-        u32 off[4];
-#pragma unroll
-        for(u32 u = 0; u < 4; u++)
-        {
-          const u32 kk = k + u * WAVE;
-          off[u] = (kk < hi && base + kk < emit_cap ? (u32)emit16[base + kk] : 0xFFFFFFFFu);
-        }
-#pragma unroll
-        for(u32 u = 0; u < 4; u++) { if(off[u] != 0xFFFFFFFFu) { atomicOr(&tile[off[u] >> 5], 1u << (off[u] & 31)); } }
+        if(base + k < emit_cap) { const u32 o = emit16[base + k]; atomicOr(&tile[o >> 5], 1u << (o & 31)); }
       }
+#pragma unroll
+      for(u32 u = 0; u < UN; u++) { cur[u] = nxt[u]; }
+      lo = nlo; hi = nhi; base = nbase;
     }
   }
   if(seen && lane == 0) { any = 1; }

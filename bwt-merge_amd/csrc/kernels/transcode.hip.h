@@ -415,6 +415,49 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_block_cum(IndexView x, const 
   cum[1 * stride + b] = r[1]; cum[2 * stride + b] = r[2]; cum[3 * stride + b] = r[3]; cum[4 * stride + b] = r[4]; cum[5 * stride + b] = r[5];
 }
 
+// Compact form of the samples (what travels to the host when the caller asks for it: 12 or 24 bytes per block instead of 56).
+// Per block the six FIELDS: positions in the block and occurrences of 1..5 in it (differences of the ranks at consecutive block
+// starts), stored 16 or 32 bits wide; every 64th block an ANCHOR: its absolute start position and absolute counts of 1..5.
+// block_end, samples[c].sum() of any block = its anchor + at most 63 fields.  k_block_field_max decides the width.
+__device__ inline void block_fields(const IndexView& x, const u64* block_start, u64 b, u64 f[6], u64 at[6])
+{
+  const u64 p0 = block_start[b], p1 = block_start[b + 1];
+  u64 r0[6], r1[6];
+  index_ranks(x, p0, r0); index_ranks(x, p1, r1);
+  f[0] = p1 - p0; at[0] = p0;
+#pragma unroll
+  for(int c = 1; c < 6; c++) { f[c] = r1[c] - r0[c]; at[c] = r0[c]; }
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_block_field_max(IndexView x, const u64* block_start, u64 nblocks, unsigned long long* out_max)
+{
+  u64 b = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  u64 m = 0;
+  if(b < nblocks)
+  {
+    u64 f[6], at[6]; block_fields(x, block_start, b, f, at);
+    m = f[0];                                               // the block's length bounds its five counts
+  }
+  m = wave_max(m);
+  if(lane_id() == 0 && m > 0) { atomicMax(out_max, (unsigned long long)m); }
+}
+
+template<class T>
+__global__ void __launch_bounds__(BLOCK_THREADS) k_block_fields(IndexView x, const u64* block_start, u64 first, u64 count, T* fields, u64 stride,
+  u64* anchors, u64 anchor_stride)
+{
+  u64 k = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(k >= count) { return; }
+  u64 f[6], at[6]; block_fields(x, block_start, first + k, f, at);
+#pragma unroll
+  for(int c = 0; c < 6; c++) { fields[c * stride + k] = (T)f[c]; }
+  if(((first + k) & 63) == 0)
+  {
+#pragma unroll
+    for(int c = 0; c < 6; c++) { anchors[c * anchor_stride + (k >> 6)] = at[c]; }       // `first` is a multiple of 64
+  }
+}
+
 // The same for an output-range slice whose records start at position `slice_start`: a block whose opening run began before
 // the slice (it belongs to the slice because the run ENDS there) is answered from the counts at the slice start and the
 // symbol of that run (the symbol at slice_start - 1), without the records of the slices before.

@@ -122,6 +122,14 @@ int bwtm_index_download_data(bwtm_index* index, uint8_t* out, uint64_t capacity)
    of each block (the set bits of block_boundaries, bwt.h:176) and cum[6][blocks + 1]
    row-major = CumulativeArray::sum(k) of samples[c] (support.h:338-343). */
 int bwtm_index_download_samples(bwtm_index* index, uint64_t* block_end, uint64_t* cum);
+/* The same information in 12 or 24 instead of 56 bytes per block (the reference keeps it compressed too: seven
+   sd_vectors).  FIELDS [6][blocks], `width` bytes each: positions in block k, then its occurrences of symbols 1..5;
+   ANCHORS [6][ceil(blocks / 64)] of uint64: start position and counts of 1..5 before block 64 j.  Hence
+     block_end[k]   = anchors[0][k / 64] + sum(fields[0][64 (k / 64) .. k]) - 1
+     cum[c][k]      = anchors[c][k / 64] + sum(fields[c][64 (k / 64) .. k - 1])          (c = 1..5; c = 0: start - the five)
+   bwtm_index_samples_width() tells the narrowest width that holds every field: 2, 4, or 8 (= use the full arrays above). */
+int bwtm_index_samples_width(bwtm_index* index, int* width);
+int bwtm_index_download_samples_compact(bwtm_index* index, int width, void* fields, uint64_t* anchors);
 
 /* Queries on the device structure (batch forms of BWT::rank, bwt.cpp:318-341, and
    BWT::inverse_select, bwt.cpp:445-464).  Arrays are host arrays of length `count`. */
@@ -200,7 +208,10 @@ typedef struct
   const uint64_t* C;                         /* Alphabet::C or NULL */
 } bwtm_host_input;
 /* The library asks the caller for the output buffers once their sizes are known. */
-enum { BWTM_BUF_DATA = 0, BWTM_BUF_BLOCK_END = 1, BWTM_BUF_CUM = 2 };
+enum { BWTM_BUF_DATA = 0, BWTM_BUF_BLOCK_END = 1, BWTM_BUF_CUM = 2, BWTM_BUF_FIELDS = 3, BWTM_BUF_ANCHORS = 4 };
+/* want_samples: none, the full arrays (block_end + cum), or the compact form (fields + anchors; falls back to the full
+   arrays, sample_width = 8, when a block encodes 2^32 - 1 positions or more). */
+enum { BWTM_SAMPLES_NONE = 0, BWTM_SAMPLES_FULL = 1, BWTM_SAMPLES_COMPACT = 2 };
 typedef void* (*bwtm_alloc_fn)(void* user, int what, uint64_t nbytes);
 typedef struct
 {
@@ -209,6 +220,9 @@ typedef struct
   uint64_t C[BWTM_SIGMA + 1];
   uint64_t* block_end;                       /* [blocks]            (NULL unless samples were requested) */
   uint64_t* cum;                             /* [6][blocks + 1]     (NULL unless samples were requested) */
+  int sample_width;                          /* 0 = no samples; 8 = block_end + cum above; 2 / 4 = fields + anchors below */
+  void* fields;                              /* [6][blocks] of sample_width bytes (bwtm_index_download_samples_compact) */
+  uint64_t* anchors;                         /* [6][ceil(blocks / 64)] */
   double ms_upload, ms_search, ms_interleave, ms_encode_download, ms_samples, ms_total;
 } bwtm_host_output;
 /* `keep` (optional) receives the merged device index (rank structure only) for a chained merge. */

@@ -209,6 +209,44 @@ def test_host_to_host_merge(gpu, oracle, chunks):
             hb.free()
 
 
+def test_compact_samples(gpu, oracle):
+    """The 12 / 24-byte form of the samples (fields + anchors) expands to exactly the arrays BWT::build computes, at both
+    widths, and the library falls back to the full arrays when a block encodes 2^32 - 1 positions or more."""
+    rng = np.random.default_rng(23)
+    cases = []
+    syms = rng.integers(0, 6, 40000); lens = rng.choice([1, 1, 2, 3, 41, 42, 170], 40000)
+    cases.append((oracle.FMI.from_symbols(np.repeat(syms.astype(np.uint8), lens)), 2))                 # 16-bit fields
+    syms = rng.integers(0, 6, 3000).astype(np.uint64); lens = rng.choice([1, 2, 50, 70000, 300000], 3000).astype(np.uint64)
+    cases.append((oracle.FMI.from_runs(syms, lens), 4))                                               # runs >= 65535: 32-bit fields
+    cases.append((oracle.FMI.from_runs(np.array([1, 2, 3], dtype=np.uint64), np.array([10, 5_000_000_000, 7], dtype=np.uint64)), 8))
+    cases.append((oracle.FMI.from_symbols(np.array([3], dtype=np.uint8)), 2))
+    for f, expect_width in cases:
+        ix = upload(gpu, f)
+        width, fields, anchors = ix.samples_compact()
+        assert width == expect_width
+        obe, ocum = f.samples
+        if width != 8:
+            be, cum = gpu.capi.expand_samples(width, fields, anchors, f.blocks, f.bases)
+            assert np.array_equal(be, obe) and np.array_equal(cum, ocum)
+            if width == 2:
+                w4 = ix.samples_compact(4)                                        # a wider form may always be asked for
+                be, cum = gpu.capi.expand_samples(4, w4[1], w4[2], f.blocks, f.bases)
+                assert np.array_equal(be, obe) and np.array_equal(cum, ocum)
+            else:
+                with pytest.raises(gpu.BwtmError, match="too many positions"):
+                    ix.samples_compact(2)
+        be, cum = ix.samples()
+        assert np.array_equal(be, obe) and np.array_equal(cum, ocum)
+        # through the host-to-host call
+        e = np.zeros(0, dtype=np.uint8)
+        r = gpu.merge_host((f.data, f.sequences, f.bases), (e, 0, 0), samples=2)
+        assert r.out.sample_width == expect_width
+        be, cum = r.expanded_samples()
+        assert np.array_equal(be, obe) and np.array_equal(cum, ocum) and np.array_equal(r.data, f.data)
+        r.free(); ix.free()
+    gpu.trim()
+
+
 def test_host_to_host_empty_inputs(gpu, oracle):
     a = oracle.FMI.from_text(oracle.generate_reads(7, 50, 20))
     e = np.zeros(0, dtype=np.uint8)
