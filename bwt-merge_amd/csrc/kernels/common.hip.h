@@ -35,6 +35,20 @@ __device__ inline u64 wave_incl_sum(u64 v)
   return v;
 }
 
+// Inclusive prefix sum of 32-bit values with DPP row shifts and row broadcasts (no LDS crossbar: seven dependent VALU
+// adds instead of twelve ds_bpermute round trips for a 64-bit shuffle scan).  For counts that fit 32 bits, also packed ones
+// (e.g. two 16-bit fields) as long as no field overflows.
+__device__ inline u32 wave_incl_sum32(u32 v)
+{
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);      // row_shr:1
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);      // row_shr:2
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);      // row_shr:4
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);      // row_shr:8  -> scan inside every row of 16
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);      // row_bcast:15 into rows 1 and 3
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);      // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 __device__ inline u64 wave_incl_max(u64 v)
 {
 #pragma unroll

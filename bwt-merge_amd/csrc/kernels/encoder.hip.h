@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_size(const uint4* recs, u
     if(last > before) { before = last; }
     u32 nev; u64 long_mask;
     tile_event_stats(ti, T << 6, before, nev, long_mask);
-    const u64 ev_incl = wave_incl_sum(nev);
+    const u64 ev_incl = (u64)wave_incl_sum32(nev);
     const u32 chunk_events = (u32)shfl_u64(ev_incl, WAVE - 1);
     // Events shorter than 42 are one byte under every hypothesis; only the long ones are resolved in order.
     u32 last_g = 0;
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
     if(last > before) { before = last; }
     u32 nev; u64 long_mask;
     tile_event_stats(ti, T << 6, before, nev, long_mask);
-    u64 ev_incl = wave_incl_sum(nev);
+    u64 ev_incl = (u64)wave_incl_sum32(nev);
     u64 chunk_events = shfl_u64(ev_incl, WAVE - 1);
     bool slow = (__ballot(long_mask != 0) != 0);
     if(!slow)

@@ -157,7 +157,7 @@ __device__ inline void window32(const u32 (*planes)[IL_WORDS], u64 first_word, u
 __global__ void __launch_bounds__(BLOCK_THREADS) k_interleave(IndexView A, IndexView B, const u64* bits, const u64* chunk_base,
   u64 chunk_first, u64 chunk_end, u64 q_lo, u64 q_hi, const u64* sup_out, uint4* recs_out)
 {
-  __shared__ u64 wave_tot[3][BLOCK_THREADS / WAVE];
+  __shared__ u32 wave_tot[4][BLOCK_THREADS / WAVE];
   __shared__ u64 base_rel[6];
   __shared__ u32 planes_a[3][IL_WORDS], planes_b[3][IL_WORDS];
   const u64 chunk = chunk_first + blockIdx.x;
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_interleave(IndexView A, Index
   const u32 t = threadIdx.x, lane = lane_id(), wave = t >> 6;
   const u64 w = chunk * (2 * CHUNK_WORDS) + t;                     // 32-bit word of the bitvector = 32-position word of the output
   const u32 m = ((const u32*)bits)[w];
-  const u64 ones = (u64)__builtin_popcount(m);
+  const u32 ones = (u32)__builtin_popcount(m);
   // counts at the chunk start, relative to the super table entry of the output (one lane; consumed after the barrier below)
   const u64 b_chunk = chunk_base[chunk];
   const u64 a_chunk = (chunk << (REC_SHIFT + 6)) - b_chunk;
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_interleave(IndexView A, Index
     for(int c = 1; c < 6; c++) { base_rel[c] = ra[c] + rb[c] - sp[c]; }
   }
   // cursors: B symbols before this word
-  const u64 ones_incl = wave_incl_sum(ones);
+  const u32 ones_incl = wave_incl_sum32(ones);
   if(lane == WAVE - 1) { wave_tot[0][wave] = ones_incl; }
   __syncthreads();
   u64 b_off = b_chunk + ones_incl - ones;
@@ -194,22 +194,24 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_interleave(IndexView A, Index
   const u32 o1 = expand32(b1, eb) | expand32(a1, ea);
   const u32 o2 = expand32(b2, eb) | expand32(a2, ea);
 
-  // symbol counts of this word -> prefixes over the chunk (16-bit fields: a chunk has 8192 positions)
-  const u64 c14 = (u64)__builtin_popcount(plane_match(o0, o1, o2, 1)) | ((u64)__builtin_popcount(plane_match(o0, o1, o2, 2)) << 16)
-                | ((u64)__builtin_popcount(plane_match(o0, o1, o2, 3)) << 32) | ((u64)__builtin_popcount(plane_match(o0, o1, o2, 4)) << 48);
-  const u64 c5 = (u64)__builtin_popcount(plane_match(o0, o1, o2, 5));
-  const u64 incl14 = wave_incl_sum(c14), incl5 = wave_incl_sum(c5);
-  if(lane == WAVE - 1) { wave_tot[1][wave] = incl14; wave_tot[2][wave] = incl5; }
+  // symbol counts of this word -> prefixes over the chunk (16-bit fields: a chunk has 8192 positions, and a symbol that fills
+  // it completely would need 8192 + ... < 65536)
+  const u32 c12 = (u32)__builtin_popcount(plane_match(o0, o1, o2, 1)) | ((u32)__builtin_popcount(plane_match(o0, o1, o2, 2)) << 16);
+  const u32 c34 = (u32)__builtin_popcount(plane_match(o0, o1, o2, 3)) | ((u32)__builtin_popcount(plane_match(o0, o1, o2, 4)) << 16);
+  const u32 c5 = (u32)__builtin_popcount(plane_match(o0, o1, o2, 5));
+  const u32 incl12 = wave_incl_sum32(c12), incl34 = wave_incl_sum32(c34), incl5 = wave_incl_sum32(c5);
+  if(lane == WAVE - 1) { wave_tot[1][wave] = incl12; wave_tot[2][wave] = incl34; wave_tot[3][wave] = incl5; }
   __syncthreads();
-  u64 before14 = incl14 - c14, before5 = incl5 - c5;
-  for(u32 k = 0; k < wave; k++) { before14 += wave_tot[1][k]; before5 += wave_tot[2][k]; }
-  // the header belongs to the record: take the prefixes of the quad's first lane
-  const int first = (int)(lane & ~3u);
-  const u64 rec14 = shfl_u64(before14, first), rec5 = shfl_u64(before5, first);
+  u32 before12 = incl12 - c12, before34 = incl34 - c34, before5 = incl5 - c5;
+  for(u32 k = 0; k < wave; k++) { before12 += wave_tot[1][k]; before34 += wave_tot[2][k]; before5 += wave_tot[3][k]; }
+  // the header belongs to the record: take the prefixes of the quad's first lane (quad broadcast of lane 0: DPP quad_perm [0,0,0,0])
+  const u32 rec12 = (u32)__builtin_amdgcn_update_dpp(0, (int)before12, 0x00, 0xF, 0xF, false);
+  const u32 rec34 = (u32)__builtin_amdgcn_update_dpp(0, (int)before34, 0x00, 0xF, 0xF, false);
+  const u32 rec5 = (u32)__builtin_amdgcn_update_dpp(0, (int)before5, 0x00, 0xF, 0xF, false);
   u32 rel[6]; u32 h[4];
   rel[0] = 0;
-  rel[1] = (u32)(base_rel[1] + (rec14 & 0xFFFF)); rel[2] = (u32)(base_rel[2] + ((rec14 >> 16) & 0xFFFF));
-  rel[3] = (u32)(base_rel[3] + ((rec14 >> 32) & 0xFFFF)); rel[4] = (u32)(base_rel[4] + (rec14 >> 48));
+  rel[1] = (u32)(base_rel[1] + (rec12 & 0xFFFF)); rel[2] = (u32)(base_rel[2] + (rec12 >> 16));
+  rel[3] = (u32)(base_rel[3] + (rec34 & 0xFFFF)); rel[4] = (u32)(base_rel[4] + (rec34 >> 16));
   rel[5] = (u32)(base_rel[5] + rec5);
   pack_header(rel, h);
   const u32 k = lane & 3;

@@ -376,9 +376,10 @@ __global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64
     n5 += (u32)__builtin_popcount(plane_match(P0.f, P1.f, P2.f, 5));
     BWTM_COUNT_WORD(x) BWTM_COUNT_WORD(y) BWTM_COUNT_WORD(z) BWTM_COUNT_WORD(w)
 #undef BWTM_COUNT_WORD
-    const u64 own14 = (u64)n1 | ((u64)n2 << 16) | ((u64)n3 << 32) | ((u64)n4 << 48);   // wave totals <= 8192 per field
-    const u64 incl14 = wave_incl_sum(own14), incl5 = wave_incl_sum((u64)n5);
-    const u64 before14 = incl14 - own14, before5 = incl5 - n5;
+    const u32 own12 = n1 | (n2 << 16), own34 = n3 | (n4 << 16);                        // wave totals <= 8192 per field
+    const u32 incl12 = wave_incl_sum32(own12), incl34 = wave_incl_sum32(own34), incl5 = wave_incl_sum32(n5);
+    const u64 own14 = (u64)own12 | ((u64)own34 << 32), incl14 = (u64)incl12 | ((u64)incl34 << 32);
+    const u64 before14 = incl14 - own14, before5 = (u64)(incl5 - n5);
     const u64 q = (ws >> REC_SHIFT) + rr * 64 + lane;
     if(q >= q_lo && q < q_hi)
     {
