@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--no-host", action="store_true", help="skip the host-to-host measurement")
     ap.add_argument("--host-steps", type=int, default=3)
     ap.add_argument("--verify-reads", type=int, default=10000, help="reads extracted from the merged index and compared with the generator")
+    ap.add_argument("--chain", type=int, default=2,
+                    help="number of input sets; more than 2 = chained merge in command-line order (BASELINE config 5: bwt_merge in1 in2 in3 in4 out), "
+                         "intermediate results stay on the device as rank structures, only the last merge encodes")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (process group, caller-owned bitvector, all-reduce, output slices) even with one rank: "
                          "a smoke test of that path on a 1-GPU box")
@@ -96,9 +99,11 @@ def main():
     # library holds nothing of the inputs when a step starts.
     t_gen = time.time()
     wargs = ({"coverage": args.coverage, "error_percent": args.error_percent} if args.workload == "genome" else {})
-    reads_per_set = (args.reads_a or args.reads, args.reads)
+    nsets = max(2, args.chain)
+    reads_per_set = [args.reads_a or args.reads] + [args.reads] * (nsets - 1)
+    seeds = [1001 + k for k in range(nsets)]
     host_in, dev_in, meta = [], [], []
-    for k, seed in enumerate((1001, 1002)):
+    for k, seed in enumerate(seeds):
         def progress(done, total, k=k):
             if rank == 0 and (done == total or (done // args.leaf_reads) % 64 == 0):
                 log("input%d: %d / %d reads (%.0f s)" % (k + 1, done, total, time.time() - t_gen))
@@ -121,24 +126,34 @@ def main():
     n_a, n_b = meta[0]["bases"], meta[1]["bases"]
     m_a, m_b = meta[0]["sequences"], meta[1]["sequences"]
     bytes_a, bytes_b = meta[0]["nbytes"], meta[1]["nbytes"]
+    # bases that pass through merges in one step: (input1 + input2) for a single merge; the running total + the increment for every merge of a chain
+    merged_bases, acc = 0, n_a
+    for k in range(1, nsets):
+        acc += meta[k]["bases"]; merged_bases += acc
+    searched_bases = sum(mt["bases"] for mt in meta[1:])
     if rank == 0:
-        log("inputs ready in %.0f s: %d + %d bases, %.3f + %.3f GB native (%.3f bytes/base)" %
-            (time.time() - t_gen, n_a, n_b, bytes_a / 1e9, bytes_b / 1e9, (bytes_a + bytes_b) / (n_a + n_b)))
+        log("inputs ready in %.0f s: %s bases, %s GB native (%.3f bytes/base)" %
+            (time.time() - t_gen, " + ".join(str(mt["bases"]) for mt in meta), " + ".join("%.3f" % (mt["nbytes"] / 1e9) for mt in meta),
+             sum(mt["nbytes"] for mt in meta) / sum(mt["bases"] for mt in meta)))
 
     # shard of input2's sequences for this rank (getBounds, utils.cpp:169-187)
     from bwt_merge_amd.dist import shard_range, merge_sharded
     seq_first, seq_last = shard_range(m_b, rank, world)
 
+    def load_input(k):
+        # BWT::load of an input: the resident native bytes are read in place (no second copy in HBM)
+        return pkg.Index.from_device(dev_in[k].data_ptr(), meta[k]["nbytes"], meta[k]["sequences"], meta[k]["bases"], borrow=True)
+
     def load_inputs():
-        # BWT::load of both inputs: the resident native bytes are read in place (no second copy in HBM)
-        A = pkg.Index.from_device(dev_in[0].data_ptr(), bytes_a, m_a, n_a, borrow=True)
-        B = pkg.Index.from_device(dev_in[1].data_ptr(), bytes_b, m_b, n_b, borrow=True)
-        return A, B
+        return load_input(0), load_input(1)
 
     # ---------------------------------------------------------------- one step
     def step(keep=False):
         A, B = load_inputs()
         if not sharded:
+            for k in range(2, nsets):            # a chain: the running result is a device rank structure, the next increment is loaded
+                A = synth.merge_indexes(pkg, A, B)
+                B = load_input(k)
             M = pkg.merge_consume(A, B)          # "merges a and b, destroying them": their records are released after the interleave
         else:
             M = merge_sharded(pkg, A, B, rank, world, dist, torch, dev)      # this rank's slice of the result
@@ -169,7 +184,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     sec_per_step = elapsed / max(1, args.steps)
-    value = (n_a + n_b) / 1e9 / sec_per_step
+    value = merged_bases / 1e9 / sec_per_step
 
     # ---------------------------------------------------------------- roofline of the dominant kernel
     # The search kernel: k_frontier_step (one launch per LF step of the level-synchronous search) or,
@@ -178,7 +193,7 @@ def main():
     dom = "frontier_step" if "frontier_step" in prof else "lf_walk"
     dom_ms, dom_launches = prof.get(dom, (0.0, 0))
     searches = max(1, args.steps)
-    units_per_search = (seq_last - seq_first + 1) / max(1, m_b) * n_b if seq_first <= seq_last else 0
+    units_per_search = ((seq_last - seq_first + 1) / max(1, m_b) * n_b if seq_first <= seq_last else 0) if nsets == 2 else searched_bases
     launches_per_search = dom_launches / searches if dom_launches else 0
     avg_launch_s = (dom_ms / 1e3 / dom_launches) if dom_launches else float("nan")
     units_per_launch = units_per_search / launches_per_search if launches_per_search else 0
@@ -206,7 +221,7 @@ def main():
     kernel_ms = {name: round(ms / max(1, args.steps), 3) for name, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0])}
     # whole-job algorithmic bytes W = 176 n_B + |A| + |B| + 2 |Out|
     out_bytes = last.total_nbytes if last is not None else 0
-    W = 176 * n_b + bytes_a + bytes_b + 2 * out_bytes
+    W = 176 * searched_bases + sum(mt["nbytes"] for mt in meta) + 2 * out_bytes
     job = {"algorithmic_bytes": W, "achieved_GBs": round(W / sec_per_step / 1e9, 1), "frac": round(W / sec_per_step / 1e9 / HBM_PEAK_GBS, 4)}
 
     # ---------------------------------------------------------------- verification at full size
@@ -230,7 +245,7 @@ def main():
     host = None
     dev_in.clear()                                   # the device copies of the inputs are not needed any more
     torch.cuda.empty_cache()
-    if rank == 0 and world == 1 and not args.no_host:
+    if rank == 0 and world == 1 and not args.no_host and nsets == 2:
         host = host_to_host(pkg, np, torch, dev, host_in, meta, args)
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N == 1)
@@ -247,10 +262,11 @@ def main():
             "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(sec_per_step * 1e3, 2), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%.3g + %.3g Gbase synthetic %d bp read sets (%s), native format, inputs resident in HBM" %
-                       (n_a / 1e9, n_b / 1e9, args.readlen, wname),
+            "config": {"workload": "%s Gbase synthetic %d bp read sets (%s)%s, native format, inputs resident in HBM" %
+                       (" + ".join("%.3g" % (mt["bases"] / 1e9) for mt in meta), args.readlen, wname,
+                        ", chained merge in command-line order (value = bases through all merges / time)" if nsets > 2 else ""),
                        "reads_per_set": args.reads, "reads_input1": reads_per_set[0], "read_length": args.readlen,
-                       "bases": [n_a, n_b], "native_bytes": [bytes_a, bytes_b, out_bytes],
+                       "bases": [mt["bases"] for mt in meta], "native_bytes": [mt["nbytes"] for mt in meta] + [out_bytes],
                        "parallelism": "sequence blocks of input2 sharded over %d GPU(s)%s" %
                        (world, ", RCCL all-reduce of the rank-array bitvector, result sharded by output range" if sharded else "")},
             "roofline": roofline, "job_roofline": job, "kernel_ms_per_step": kernel_ms,
@@ -268,21 +284,20 @@ def verify_full_size(pkg, synth, np, last, meta, args, wargs, load_inputs):
     index by LF walk == the generator's, the emitted stream decodes back to the same index, and -- two implementations of the
     search against each other -- the rank array of the level-synchronous frontier search == that of the per-chain walk."""
     checks = {}
-    C = meta[0]["C"] + meta[1]["C"]
-    m_a = meta[0]["sequences"]
-    checks["header_and_C"] = bool(np.array_equal(last.C, C) and last.bases == meta[0]["bases"] + meta[1]["bases"]
-                                  and last.sequences == m_a + meta[1]["sequences"])
+    C = sum(mt["C"] for mt in meta)
+    checks["header_and_C"] = bool(np.array_equal(last.C, C) and last.bases == sum(mt["bases"] for mt in meta)
+                                  and last.sequences == sum(mt["sequences"] for mt in meta))
     rng = np.random.default_rng(12345)
     ids = np.sort(rng.integers(0, last.sequences, args.verify_reads))
     maxlen = (150 if args.workload == "mixed" else args.readlen)
     got = synth.extract_sequences_matrix(last, ids, max_len=maxlen + 2)
     ok = True
-    reads_per_set = (args.reads_a or args.reads, args.reads)
-    for which, seed in ((0, 1001), (1, 1002)):
-        sel = (ids < m_a) if which == 0 else (ids >= m_a)
-        idx = ids[sel] - (0 if which == 0 else m_a)
-        ref = synth.reads_matrix(args.workload, seed, idx, args.readlen, reads_per_set[which], maxlen + 2, **wargs)
+    first_seq = 0
+    for which, mt in enumerate(meta):                    # sequences of the merged collection are the inputs' sequences in command-line order
+        sel = (ids >= first_seq) & (ids < first_seq + mt["sequences"])
+        ref = synth.reads_matrix(args.workload, 1001 + which, ids[sel] - first_seq, args.readlen, mt["sequences"], maxlen + 2, **wargs)
         ok = ok and bool(np.array_equal(got[sel], ref))
+        first_seq += mt["sequences"]
     checks["extracted_reads"] = ok
     checks["extracted_reads_count"] = int(ids.size)
     # the emitted native stream must decode back to the merged index (header check in upload)
@@ -292,7 +307,7 @@ def verify_full_size(pkg, synth, np, last, meta, args, wargs, load_inputs):
     cnt = min(1 << 20, last.bases)
     checks["stream_decodes_back"] = bool(np.array_equal(R.extract(w0, cnt), last.extract(w0, cnt)))
     R.free()
-    if meta[1]["bases"] <= 2e10:
+    if meta[1]["bases"] <= 2e10 and len(meta) == 2:
         A, B = load_inputs()
         bits = []
         for algo in (2, 1):

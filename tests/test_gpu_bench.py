@@ -42,3 +42,13 @@ def test_bench_distributed_path_on_one_rank(bwtm):
                    "--master-port", "29517", "bench.py", "--gpus", "1", "--force-dist", "--reads", "200000", "--steps", "2", "--warmup", "1",
                    "--no-cpu-baseline"])
     assert d["value"] > 0 and d["config"]["native_bytes"][2] > 0 and d["verified"] is True
+
+
+def test_bench_chained_merge_of_four_sets(bwtm):
+    """BASELINE config 5's shape: four sets of mixed 100 / 150 bp reads merged in command-line order, intermediate results
+    device-resident; reads extracted from the final index equal the four generators'."""
+    d = run_bench([sys.executable, "bench.py", "--chain", "4", "--workload", "mixed", "--reads", "60000", "--steps", "1", "--warmup", "1",
+                   "--no-cpu-baseline", "--verify-reads", "4000"])
+    assert d["verified"] is True and len(d["config"]["bases"]) == 4 and d["host_to_host"] is None
+    n = d["config"]["bases"][0]
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] * 1e6 - 9 * n) < 0.01 * 9 * n      # (2 + 3 + 4) n bases pass through the merges
