@@ -126,8 +126,17 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
     if(k < (u32)FR_SEGS) { phys = s_phys[k] + (g - s_prefix[k]); }
     else
     {
-      u64 sgm = first_seg + FR_SEGS;                                 // rare: more segments than staged
-      while(f.seg_prefix[sgm + 1] <= g) { sgm++; }
+      // Rare: the element lies beyond the staged entries.  Binary search of seg_prefix (non-decreasing) for the segment
+      // with prefix <= g < next prefix: when many chains end at once (reads of mixed lengths), the blocks of every class
+      // beyond the shrunken frontier are empty segments, tens of thousands in a row between two classes, and a linear
+      // walk over them by the few lanes that straddle a class boundary made the whole launch 10 x slower (measured).
+      u64 lo_s = first_seg + FR_SEGS, hi_s = nseg;                   // seg_prefix[lo_s] <= g < seg_prefix[hi_s] = N
+      while(hi_s - lo_s > 1)
+      {
+        const u64 mid = (lo_s + hi_s) >> 1;
+        if(f.seg_prefix[mid] <= g) { lo_s = mid; } else { hi_s = mid; }
+      }
+      const u64 sgm = lo_s;
       phys = f.seg_phys[sgm] + (g - f.seg_prefix[sgm]);
     }
     uint2 l = f.lo[phys]; u32 h = f.hi[phys];

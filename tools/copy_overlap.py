@@ -62,11 +62,11 @@ def main():
             continue
         t_search = inits[which]
         t_next = (inits[which + 1] if which + 1 < 0 else float("inf"))
-        # its upload: the H2D chunks before the search, walking back while the gaps stay below 5 ms
+        # its upload: the H2D chunks before the search, walking back while the gaps stay below 20 ms
         ups = sorted([c for c in h2d if c[1] <= t_search], key=lambda c: c[0])
         mine = []
         for c in reversed(ups):
-            if mine and mine[-1][0] - c[1] > 5e6:
+            if mine and mine[-1][0] - c[1] > 2e7:
                 break
             mine.append(c)
         mine.reverse()
