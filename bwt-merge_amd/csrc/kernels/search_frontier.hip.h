@@ -74,6 +74,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_init(uint2* lo, unsi
 // per search at config 2.)
 struct RecordFetch { uint4 v[4]; };
 
+// (Loads with the non-temporal hint are 33 - 40 % slower here, on thin frontiers too: profiles/r02_shard_search_time.log.)
 __device__ inline RecordFetch record_issue(const uint4* recs, u64 nrecs, u64 rec)
 {
   RecordFetch rf;
@@ -175,7 +176,7 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
     u32 wb[16];
     const u64 rec_b = (active ? i : li) >> REC_SHIFT, rec_a = (active ? r : lr) >> REC_SHIFT;
     RecordFetch fb = record_issue(B.recs, B.nrecs, rec_b);
-    RecordFetch fa = record_issue(A.recs, A.nrecs, rec_a);         // in flight while B's record is used
+    RecordFetch fa = record_issue(A.recs, A.nrecs, rec_a);     // in flight while B's record is used
     const u64 sup_b0 = shfl_u64(i, 0) >> SUPER_SHIFT, sup_a0 = shfl_u64(r, 0) >> SUPER_SHIFT;   // lane 0 is always active here
     const u64* row_b = B.sup + sup_b0 * SUP_STRIDE;                // wave-uniform addresses
     const u64* row_a = A.sup + sup_a0 * SUP_STRIDE;
