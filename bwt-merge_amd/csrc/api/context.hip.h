@@ -60,7 +60,7 @@ struct bwtm_context
 
   // small page-locked scratch for results read back by the host (a pageable destination would make
   // hipMemcpyAsync stage and block)
-  u64* host_scratch = nullptr;             // 64 u64
+  u64* host_scratch = nullptr;             // 128 u64: [0, 32) call results, [32, 64) upload / encode / slices, [64, 96) the search's size ring
 };
 
 namespace
@@ -115,7 +115,7 @@ int context_setup(bwtm_context* c, int device)
   c->device = device;
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-  HIP_TRY(hipHostMalloc((void**)&c->host_scratch, 64 * sizeof(u64), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&c->host_scratch, 128 * sizeof(u64), hipHostMallocDefault));
   vmm_setup(c);
   // Kernels that take more than the default 64 KiB of dynamic LDS (a per-device attribute).
   HIP_TRY(hipFuncSetAttribute((const void*)k_part_scatter_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));

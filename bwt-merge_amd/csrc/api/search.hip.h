@@ -251,9 +251,16 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   }
   TRY(seg_prefix.alloc((nseg + 1) * sizeof(u64)));
   DevBuf first_seg; TRY(first_seg.alloc((nb_max + 1) * sizeof(u32)));
-  // The host looks at the frontier size every few steps: a dead step costs little for a small frontier, a
-  // synchronisation costs little next to a large one.
-  const u64 check_every = (count >= (1ull << 20) ? 8 : 32);
+  // The host learns the frontier size with a delay of LOOK steps and never drains the stream for it: the size of step t travels
+  // to page-locked memory behind step t's scan, and the host waits for it only before it queues step t + LOOK.  The frontier only
+  // shrinks, so a stale size is a valid upper bound; the price is LOOK dead steps at the end (an empty step costs ~20 us).
+  const u32 LOOK = (count >= (1ull << 20) ? 8 : 32);
+  struct Events
+  {
+    hipEvent_t ev[32]; u32 n = 0;
+    ~Events() { for(u32 k = 0; k < n; k++) { (void)hipEventDestroy(ev[k]); } }
+  } events;
+  for(u32 k = 0; k < LOOK; k++) { HIP_TRY(hipEventCreateWithFlags(&events.ev[k], hipEventDisableTiming)); events.n = k + 1; }
   const u64 scan_tiles = div_up(nseg + 1, (u64)SCAN_TILE);
   DevBuf scan_partial; TRY(scan_partial.alloc(scan_tiles * sizeof(u64)));
   TRY(emit16.alloc(emit_cap * sizeof(unsigned short)));
@@ -285,12 +292,16 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
       LAUNCH("frontier_prep", k_frontier_prep, div_up(nseg, BLOCK_THREADS), BLOCK_THREADS, seg_prefix.as<const u64>(), nseg, first_seg.as<u32>(),
         emit_base.as<u64>(), in_epoch);
     }
-    if(t % check_every == 0)
     {
-      TRY(fetch_u64(seg_prefix.as<u64>() + nseg, 0));
-      HIP_TRY(hipStreamSynchronize(CTX.stream));
-      alive_bound = CTX.host_scratch[0];
-      if(alive_bound == 0) { break; }
+      const u32 slot = (u32)(t % LOOK);
+      if(t >= LOOK)
+      {
+        HIP_TRY(hipEventSynchronize(events.ev[slot]));            // step t - LOOK has been scanned
+        alive_bound = CTX.host_scratch[64 + slot];
+        if(alive_bound == 0) { break; }
+      }
+      TRY(fetch_u64(seg_prefix.as<u64>() + nseg, 64 + slot));
+      HIP_TRY(hipEventRecord(events.ev[slot], CTX.stream));
     }
     FrontierView f;
     f.lo = lo[cur].as<const uint2>(); f.hi = hi[cur].as<const unsigned short>();
