@@ -40,6 +40,7 @@ struct bwtm_context
   hipStream_t copy_stream = nullptr;       // H2D / D2H
   std::recursive_mutex mu;                 // calls on one context are serialized
   bool is_default = false;
+  std::atomic<long long> live_handles{0};  // indexes, rank arrays and slices that live in this context
 
   // per-kernel profiling (bwtm_profile_*)
   bool profiling = false;
@@ -567,6 +568,12 @@ extern "C" void bwtm_context_destroy(bwtm_context* context)
 {
   if(!context || context->is_default) { return; }
   if(t_bound == context) { t_bound = nullptr; }
+  if(context->live_handles.load() > 0)
+  {
+    // its handles would dangle: leave the context (and their memory) alone rather than free it under them
+    fail(BWTM_EINVAL, "bwtm_context_destroy: %lld handles of the context are still alive; context not destroyed", context->live_handles.load());
+    return;
+  }
   context_teardown(context);
   delete context;
 }

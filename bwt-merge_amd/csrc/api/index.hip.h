@@ -10,6 +10,9 @@
 struct bwtm_index
 {
   bwtm_context* ctx = nullptr;
+  bwtm_index() : ctx(t_ctx) { if(ctx) { ctx->live_handles++; } }     // handles are created inside a Scope: t_ctx is their context
+  ~bwtm_index() { if(ctx) { ctx->live_handles--; } }
+  bwtm_index(const bwtm_index&) = delete; bwtm_index& operator=(const bwtm_index&) = delete;
   u64 n = 0, m = 0;
   u64 C[8] = {};
   DevBuf recs; u64 nrecs = 0;        // device rank structure

@@ -8,6 +8,9 @@
 struct bwtm_ra
 {
   bwtm_context* ctx = nullptr;
+  bwtm_ra() : ctx(t_ctx) { if(ctx) { ctx->live_handles++; } }     // handles are created inside a Scope: t_ctx is their context
+  ~bwtm_ra() { if(ctx) { ctx->live_handles--; } }
+  bwtm_ra(const bwtm_ra&) = delete; bwtm_ra& operator=(const bwtm_ra&) = delete;
   u64 na = 0, nb = 0, n_out = 0;
   u64 nrecs_out = 0, nchunks = 0;
   DevBuf owned_bits;                  // nchunks * CHUNK_WORDS u64 words (unless caller-owned)

@@ -17,6 +17,9 @@
 struct bwtm_slice
 {
   bwtm_context* ctx = nullptr;
+  bwtm_slice() : ctx(t_ctx) { if(ctx) { ctx->live_handles++; } }     // handles are created inside a Scope: t_ctx is their context
+  ~bwtm_slice() { if(ctx) { ctx->live_handles--; } }
+  bwtm_slice(const bwtm_slice&) = delete; bwtm_slice& operator=(const bwtm_slice&) = delete;
   u64 n = 0, m = 0;                    // the WHOLE merged index
   u64 C[8] = {};
   u64 nrecs_total = 0;

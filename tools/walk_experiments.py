@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Diagnostic: prices the parts of the search kernel on config-2-sized inputs (GPU only).
+"""NEEDS A DIAGNOSTICS BUILD: bash tools/build_variant.sh diag "" -DBWTM_DIAGNOSTICS; BWTM_LIB=bwt-merge_amd/_variants/diag.so python tools/walk_experiments.py
+(the timing-only kernel variants and their bwtm_tune keys are not part of the product library).
+Diagnostic: prices the parts of the search kernel on config-2-sized inputs (GPU only).
 Usage: python tools/walk_experiments.py [reads_per_set]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
