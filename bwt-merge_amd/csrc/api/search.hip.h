@@ -246,10 +246,12 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   const u64 bound_budget = 2ull << 30;
   if(EPOCH * (ntiles + 1) * sizeof(u32) > bound_budget) { EPOCH = std::max<u64>(1, bound_budget / ((ntiles + 1) * sizeof(u32))); }
 
+  // r may equal n_a and LF results stay below n: 32 bits hold every coordinate when both indexes are below 2^32 positions
+  const bool wide = (a->n >= (1ull << 32) || b->n >= (1ull << 32));
   DevBuf lo[2], hi[2], seg_len[2], seg_phys[2], seg_prefix, emit16, emit_base, bound;
   for(int k = 0; k < 2; k++)
   {
-    TRY(lo[k].alloc(fcap * 8)); TRY(hi[k].alloc(fcap * 2));
+    TRY(lo[k].alloc(fcap * 8)); if(wide) { TRY(hi[k].alloc(fcap * 2)); }
     TRY(seg_len[k].alloc((nseg + 1) * sizeof(u64), true)); TRY(seg_phys[k].alloc((nseg + 1) * sizeof(u64), true));
   }
   TRY(seg_prefix.alloc((nseg + 1) * sizeof(u64)));
@@ -315,10 +317,12 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
     f.emit16 = emit16.as<unsigned short>(); f.emit_base = emit_base.as<const u64>(); f.emit_cap = emit_cap; f.bits32 = ra->bits_as<u32>();
     f.bound_row = bound.as<u32>() + in_epoch * (ntiles + 1); f.step = in_epoch;
 #ifdef BWTM_DIAGNOSTICS
-    if(g_tune.walk_emit == 1) { LAUNCH("frontier_step_noemit", k_frontier_step<1>, nb_max, FR_BLOCK, a->view(), b->view(), f); }
+    if(g_tune.walk_emit == 1 && wide) { LAUNCH("frontier_step_noemit", (k_frontier_step<1, true>), nb_max, FR_BLOCK, a->view(), b->view(), f); }
+    else if(g_tune.walk_emit == 1) { LAUNCH("frontier_step_noemit", (k_frontier_step<1, false>), nb_max, FR_BLOCK, a->view(), b->view(), f); }
     else
 #endif
-    { LAUNCH("frontier_step", k_frontier_step<0>, nb_max, FR_BLOCK, a->view(), b->view(), f); }
+    if(wide) { LAUNCH("frontier_step", (k_frontier_step<0, true>), nb_max, FR_BLOCK, a->view(), b->view(), f); }
+    else { LAUNCH("frontier_step", (k_frontier_step<0, false>), nb_max, FR_BLOCK, a->view(), b->view(), f); }
     cur = 1 - cur;
     in_epoch++; epoch_used += alive_bound;
     // The epoch ends when the table is full or the next step might not fit (l1_cap: the tests want the overflow).

@@ -54,7 +54,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_init(uint2* lo, unsi
   if(g < count)
   {
     u64 i = seq_first + g;                                                // fmi.cpp:286: trie root "$"
-    lo[g] = make_uint2((u32)i, (u32)m_a); hi[g] = (unsigned short)(((i >> 32) & 0xFF) | (((m_a >> 32) & 0xFF) << 8));
+    lo[g] = make_uint2((u32)i, (u32)m_a);
+    if(hi) { hi[g] = (unsigned short)(((i >> 32) & 0xFF) | (((m_a >> 32) & 0xFF) << 8)); }      // no high bytes when both indexes are below 2^32 positions
   }
   if(g < 5 * nb_max)
   {
@@ -89,7 +90,8 @@ __device__ inline void record_words(const RecordFetch& rf, u32 w[16])
   for(int k = 0; k < 4; k++) { w[4 * k] = rf.v[k].x; w[4 * k + 1] = rf.v[k].y; w[4 * k + 2] = rf.v[k].z; w[4 * k + 3] = rf.v[k].w; }
 }
 
-template<int EMIT>
+// HI: the coordinates have high bytes (an index of 2^32 positions or more); otherwise the 2-byte array is neither read nor written.
+template<int EMIT, bool HI>
 __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, IndexView B, FrontierView f)
 {
   __shared__ u32 wave_cnt[FR_BLOCK / WAVE][6];
@@ -140,7 +142,7 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
       const u64 sgm = lo_s;
       phys = f.seg_phys[sgm] + (g - f.seg_prefix[sgm]);
     }
-    uint2 l = f.lo[phys]; u32 h = f.hi[phys];
+    uint2 l = f.lo[phys]; u32 h = (HI ? (u32)f.hi[phys] : 0u);
     i = (u64)l.x | ((u64)(h & 0xFF) << 32);
     r = (u64)l.y | ((u64)(h >> 8) << 32);
   }
@@ -247,7 +249,7 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
   {
     u64 dst = g0 + class_base + before_waves + my_rank;
     f.lo_next[dst] = make_uint2((u32)ni, (u32)nr);
-    f.hi_next[dst] = (unsigned short)(((ni >> 32) & 0xFF) | (((nr >> 32) & 0xFF) << 8));
+    if(HI) { f.hi_next[dst] = (unsigned short)(((ni >> 32) & 0xFF) | (((nr >> 32) & 0xFF) << 8)); }
   }
 }
 
