@@ -204,8 +204,9 @@ def main():
             t = json.load(f)
         if (t["kernel"] == dom and t["config"]["reads_per_set"] == args.reads and not args.reads_a and t["config"]["read_length"] == args.readlen
                 and args.workload == "iid" and world == 1):
+            # per launch that does work: a search ends with a few empty launches (the host learns the frontier size with a delay)
             traffic, traffic_source = t["hbm_bytes_per_launch"], t["source"]
-            traffic_gbs = traffic / avg_launch_s / 1e9
+            traffic_gbs = t["hbm_bytes_per_search"] / (dom_ms / searches / 1e3) / 1e9
     except (OSError, KeyError, ValueError):
         pass
     # `achieved` / `frac` follow the contract: ALGORITHMIC bytes per launch / measured duration.  The frontier search shares cache
