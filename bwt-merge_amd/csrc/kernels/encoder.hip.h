@@ -296,6 +296,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
         // carried in from the tiles before.  The tile is walked as two 32-bit halves.
         const u64 tb = T << 6;
         const u32 phase = (u32)((off - a) & (RLE_BLOCK - 1));            // byte (off - a + idx) opens a block iff ((phase + idx) & 63) == 0
+        // a tile emits at most 64 bytes, so at most one of them opens a block: its index is known before the walk
+        const u32 opens = idx + ((0u - (phase + idx)) & (u32)(RLE_BLOCK - 1));
         const u32 b0 = (u32)__builtin_ctzll(ti.H);
         u64 h = ti.H;
         int prev_bit; u32 run_sym;
@@ -311,7 +313,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
             const u32 bb = (u32)__builtin_ctz(hh); hh &= hh - 1;
             const int bit = (int)bb + 32 * half;
             const u32 len = (u32)(bit - prev_bit);
-            if(((phase + idx) & (u32)(RLE_BLOCK - 1)) == 0) { block_start[(off - a + idx) >> 6] = tb + (u64)(long long)prev_bit; }   // this run opens a block
+            if(idx == opens) { block_start[(off - a + idx) >> 6] = tb + (u64)(long long)prev_bit; }   // this run opens a block
             lds[idx++] = (u8)(run_sym + 6 * (len - 1));                  // Run::encodeBasic, support.h:231-234
             run_sym = ((q0 >> bb) & 1u) | (((q1 >> bb) & 1u) << 1) | (((q2 >> bb) & 1u) << 2);
             prev_bit = bit;

@@ -112,10 +112,19 @@ __device__ inline void for_each_run(const u32* row, u32 valid, FS&& on_short, FL
 // blen[b] = positions encoded by block b; gcount[c * gstride + g] = occurrences of c in group g.
 // flags bit 0: a block other than the last one encodes fewer than 64 positions.
 // The launch covers the groups [group_first, group_end): the pipelined upload runs one launch per H2D chunk.
+// One-byte runs (the common case) are counted through a 256-entry LDS table: entry of byte v < 246 = (v / 6 + 1) << (10 (v % 6)),
+// six 10-bit fields, one per symbol; a lane adds the entries of up to 16 bytes (16 x 41 < 1024) before it unpacks the fields.
+// (The kernel was VALU-bound at ~12 instructions per byte; the table leaves ~5.)
 __global__ void __launch_bounds__(BLOCK_THREADS) k_block_len(const u8* data, u64 nbytes, u64 nblocks, u64 group_first, u64 group_end,
   u64* blen, u64* gcount, u64 gstride, u32* flags)
 {
   __shared__ u32 stage[BLOCK_THREADS / WAVE][STAGE_ROWS * STAGE_WORDS];
+  __shared__ u64 tab[256];
+  {
+    const u32 v = threadIdx.x, q = (v * 171u) >> 10;
+    tab[v] = (v < 246 ? (u64)(q + 1) << (10 * (v - 6 * q)) : 0ull);
+  }
+  __syncthreads();
   const u32 lane = lane_id(), wave = threadIdx.x >> 6;
   const u64 g = group_first + (u64)blockIdx.x * (BLOCK_THREADS / WAVE) + wave;
   if(g >= group_end) { return; }
@@ -124,28 +133,57 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_block_len(const u8* data, u64
   u32* rows = stage[wave];
   if(nb > 0) { stage_blocks(data, nbytes, first, nb, rows); }
   wave_sync_lds();
-  // Short runs (< 42) are counted in packed 16-bit fields (at most 64 * 41 per block), long ones in 64 bits.
-  u64 packed03 = 0; u32 packed45 = 0;
   u64 l0 = 0, l1 = 0, l2 = 0, l3 = 0, l4 = 0, l5 = 0;
   const u64 b = first + lane;
   if(lane < nb)
   {
-    u64 begin = b * RLE_BLOCK;
-    u32 valid = (nbytes - begin >= RLE_BLOCK ? (u32)RLE_BLOCK : (u32)(nbytes - begin));
-    for_each_run<true>(rows + lane * STAGE_WORDS, valid,
-      [&](u32 sym, u32 l)
+    const u64 begin = b * RLE_BLOCK;
+    const u32 valid = (nbytes - begin >= RLE_BLOCK ? (u32)RLE_BLOCK : (u32)(nbytes - begin));
+    const u32* row = rows + lane * STAGE_WORDS;
+    u64 acc = 0;
+    u32 sym = 0, shift = 0; u64 len = 0; bool cont = false;
+    auto add_long = [&](u32 s, u64 n)
+    {
+      l0 += (s == 0 ? n : 0); l1 += (s == 1 ? n : 0); l2 += (s == 2 ? n : 0);
+      l3 += (s == 3 ? n : 0); l4 += (s == 4 ? n : 0); l5 += (s == 5 ? n : 0);
+    };
+    auto unpack = [&]()
+    {
+      l0 += acc & 1023; l1 += (acc >> 10) & 1023; l2 += (acc >> 20) & 1023;
+      l3 += (acc >> 30) & 1023; l4 += (acc >> 40) & 1023; l5 += (acc >> 50) & 1023;
+      acc = 0;
+    };
+#pragma unroll 1
+    for(int w = 0; w < 16; w++)
+    {
+      const u32 word = row[w];
+      // bytes >= 246 (heads of runs with a varint extension): high bit set and low 7 bits >= 0x76
+      const u32 long_heads = ((word & 0x7F7F7F7Fu) + 0x0A0A0A0Au) & word & 0x80808080u;
+      if(!cont && long_heads == 0 && (u32)(4 * w + 3) < valid)
       {
-        const u64 add = (u64)l << (16 * (sym & 3));                    // symbols 4 and 5 use fields 0 and 1 of packed45
-        packed03 += (sym < 4 ? add : 0ull); packed45 += (sym < 4 ? 0u : (u32)add);
-      },
-      [&](u32 sym, u64 len)
+        acc += tab[word & 0xFF] + tab[(word >> 8) & 0xFF] + tab[(word >> 16) & 0xFF] + tab[word >> 24];
+      }
+      else
       {
-        l0 += (sym == 0 ? len : 0); l1 += (sym == 1 ? len : 0); l2 += (sym == 2 ? len : 0);
-        l3 += (sym == 3 ? len : 0); l4 += (sym == 4 ? len : 0); l5 += (sym == 5 ? len : 0);
-      });
-    l0 += packed03 & 0xFFFF; l1 += (packed03 >> 16) & 0xFFFF; l2 += (packed03 >> 32) & 0xFFFF; l3 += packed03 >> 48;
-    l4 += packed45 & 0xFFFF; l5 += packed45 >> 16;
-    u64 total = l0 + l1 + l2 + l3 + l4 + l5;
+#pragma unroll
+        for(int k = 0; k < 4; k++)
+        {
+          if((u32)(4 * w + k) < valid)
+          {
+            const u32 byte = (word >> (8 * k)) & 0xFF;
+            if(cont)
+            {
+              len += (u64)(byte & 0x7F) << shift; shift += 7; cont = (byte & 0x80) != 0;
+              if(!cont) { add_long(sym, len); }
+            }
+            else if(byte >= 246) { sym = byte - 6 * ((byte * 171u) >> 10); len = MAX_RUN; shift = 0; cont = true; }
+            else { acc += tab[byte]; }
+          }
+        }
+      }
+      if((w & 3) == 3) { unpack(); }
+    }
+    const u64 total = l0 + l1 + l2 + l3 + l4 + l5;
     blen[b] = total;
     if(total < RLE_BLOCK && b + 1 < nblocks) { atomicOr(flags, 1u); }
   }
