@@ -181,6 +181,13 @@ inline FMI::FMI(FMI& a, FMI& b, MergeParameters parameters)
     std::cerr << "FMI::FMI(): Cannot merge BWTs with different alphabets" << std::endl;
     std::exit(EXIT_FAILURE);
   }
+#ifdef VERBOSE_STATUS_INFO
+  // the reference's progress lines on stderr (fmi.cpp:344-364, bwt.cpp:300-313), with the device's phases behind them
+  std::cerr << "bwt_merge: " << a.sequences() << " sequences of total length " << a.size() << std::endl;
+  std::cerr << "bwt_merge: Adding " << b.sequences() << " sequences of total length " << b.size() << std::endl;
+  std::cerr << "bwt_merge: Memory usage before merging: " << inGigabytes(memoryUsage()) << " GB" << std::endl;
+  double verbose_start = readTimer();
+#endif
   Alphabet merged = a.alpha;
   for(size_type c = 0; c <= merged.sigma; c++) { merged.C[c] += b.alpha.C[c]; }
   this->bwt.header.sequences = a.sequences() + b.sequences();
@@ -194,10 +201,18 @@ inline FMI::FMI(FMI& a, FMI& b, MergeParameters parameters)
     gpuCheck(bwtm_ra_create(A, B, &ra), "FMI::FMI()");
     if(b.sequences() > 0) { gpuCheck(bwtm_search(A, B, 0, b.sequences() - 1, ra), "FMI::FMI()"); }
     gpuCheck(bwtm_ra_finalize(ra), "FMI::FMI()");
+#ifdef VERBOSE_STATUS_INFO
+    double verbose_mid = readTimer();
+    std::cerr << "bwt_merge: RA built in " << (verbose_mid - verbose_start) << " seconds" << std::endl;
+#endif
     gpuCheck(bwtm_interleave(A, B, ra, &M), "FMI::FMI()");
     bwtm_ra_free(ra);
     a.bwt.clear(); b.bwt.clear();
     this->bwt.adopt(M);
+#ifdef VERBOSE_STATUS_INFO
+    gpuCheck(bwtm_synchronize(), "FMI::FMI()");
+    std::cerr << "bwt_merge: BWTs merged in " << (readTimer() - verbose_mid) << " seconds (the result stays on the device)" << std::endl;
+#endif
   }
   else
   {
@@ -221,6 +236,11 @@ inline FMI::FMI(FMI& a, FMI& b, MergeParameters parameters)
     }
     this->bwt.adoptHost(kept, out.blocks, out.sample_width);
     a.bwt.clear(); b.bwt.clear();
+#ifdef VERBOSE_STATUS_INFO
+    std::cerr << "bwt_merge: RA built in " << (out.ms_upload + out.ms_search) / 1000.0 << " seconds" << std::endl;
+    std::cerr << "bwt_merge: BWTs merged in " << (out.ms_interleave + out.ms_encode_download) / 1000.0 << " seconds" << std::endl;
+    std::cerr << "bwt_merge: rank/select built in " << out.ms_samples / 1000.0 << " seconds" << std::endl;
+#endif
   }
   this->alpha = merged;
 }
