@@ -24,6 +24,14 @@ def test_facade_builds(bwtm):
     assert out.returncode == 0 and "Usage: bwt_merge [options] input1 input2 [input3 ...] output" in out.stderr
 
 
+def test_facade_logic_without_gpu(bwtm):
+    """CPU check: the facade's codecs and its queries on both forms of the samples (full arrays / the compact form a merge
+    downloads), expansion and native round trip (csrc/host/host_cpu_test.cpp)."""
+    build_host()
+    out = subprocess.run([os.path.join(HOST, "host_cpu_test")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
 def write_plain(path, fmi):
     CHARS[fmi.symbols].tofile(path)
 
