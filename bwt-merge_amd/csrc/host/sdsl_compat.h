@@ -82,8 +82,14 @@ struct SelectMCL
   {
     const size_type SUPER = 4096;
     size_type n = bits.bit_size();
+    // positions of the selected bits, word by word (width-1 vector: bit i of the vector is bit i % 64 of word i / 64)
     std::vector<size_type> args;
-    for(size_type i = 0; i < n; i++) { if((bits.get(i) != 0) == select_ones) { args.push_back(i); } }
+    for(size_type w = 0; w * 64 < n; w++)
+    {
+      std::uint64_t word = (select_ones ? bits.words[w] : ~bits.words[w]);
+      if((w + 1) * 64 > n) { word &= (~(std::uint64_t)0) >> (64 - (n - w * 64)); }
+      while(word != 0) { args.push_back(w * 64 + (size_type)__builtin_ctzll(word)); word &= word - 1; }
+    }
     size_type arg_cnt = args.size();
     write_member(arg_cnt, out);
     if(arg_cnt == 0) { return; }
@@ -168,9 +174,15 @@ struct SDVector
     SelectMCL::skip(in); SelectMCL::skip(in);
     ones.clear(); ones.reserve(low.count);
     size_type k = 0, nbits = high.bit_size();
-    for(size_type pos = 0; pos < nbits && k < low.count; pos++)
+    for(size_type w = 0; w * 64 < nbits && k < low.count; w++)
     {
-      if(high.get(pos)) { ones.push_back(((pos - k) << wl) | low.get(k)); k++; }
+      std::uint64_t word = high.words[w];
+      while(word != 0 && k < low.count)
+      {
+        const size_type pos = w * 64 + (size_type)__builtin_ctzll(word); word &= word - 1;
+        if(pos >= nbits) { break; }
+        ones.push_back(((pos - k) << wl) | low.get(k)); k++;
+      }
     }
   }
 };
