@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--reads-a", type=int, default=0, help="reads of input1 when it differs from input2 (BASELINE config 4: asymmetric insert)")
     ap.add_argument("--readlen", type=int, default=100)
     ap.add_argument("--leaf-reads", type=int, default=1 << 19)
+    ap.add_argument("--torch-leaves", action="store_true", help="build the inputs' leaves with tensor ops instead of the library's builder (cross-check)")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="reads per set for the CPU baseline sample (0 = auto)")
     ap.add_argument("--workload", choices=("iid", "genome", "mixed"), default="iid",
                     help="iid = the headline distribution; genome = reads from a shared random genome, 30x coverage, 1 %% substitutions "
@@ -108,7 +109,7 @@ def main():
             if rank == 0 and (done == total or (done // args.leaf_reads) % 64 == 0):
                 log("input%d: %d / %d reads (%.0f s)" % (k + 1, done, total, time.time() - t_gen))
         ix = synth.build_index(pkg, seed, reads_per_set[k], args.readlen, leaf_reads=args.leaf_reads, device=dev, progress=progress,
-                               workload=args.workload, **wargs)
+                               workload=args.workload, native=not args.torch_leaves, **wargs)
         ix.encode()
         hb = pkg.HostBuffer(ix.nbytes)
         ix.download_into(hb.array)

@@ -101,6 +101,11 @@ SYMBOLS = [
     ("bwtm_ra_download_bits", C.c_int, [vp, p_u64, u64]),
     ("bwtm_interleave", C.c_int, [vp, vp, vp, C.POINTER(vp)]),
     ("bwtm_merge", C.c_int, [vp, vp, C.POINTER(vp)]),
+    ("bwtm_builder_create", C.c_int, [u64, C.POINTER(vp)]),
+    ("bwtm_builder_add", C.c_int, [vp, vp, u64, C.c_uint32, u64, vp, C.c_int]),
+    ("bwtm_builder_reads", u64, [vp]),
+    ("bwtm_builder_finish", C.c_int, [vp, C.POINTER(vp)]),
+    ("bwtm_builder_free", None, [vp]),
     ("bwtm_profile_enable", C.c_int, [C.c_int]),
     ("bwtm_profile_reset", C.c_int, []),
     ("bwtm_profile_read", C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), p_u64, C.c_int]),
@@ -618,6 +623,51 @@ def merge_consume(a, b):
     a.h = None; b.h = None
     check(lib().bwtm_merge_consume(ha, hb, C.byref(out)))
     return Index(out)
+
+
+class Builder:
+    """Reads -> index on the GPU (bwtm_builder_*): leaves by suffix sort, grown by the merger itself."""
+
+    def __init__(self, leaf_reads=0):
+        out = vp()
+        check(lib().bwtm_builder_create(leaf_reads, C.byref(out)))
+        self.h = out
+
+    def add(self, reads, lengths=None):
+        """reads: [n, width] uint8 numpy array of comp values 1..5 (host); lengths: optional uint32 [n]."""
+        reads = np.ascontiguousarray(reads, dtype=np.uint8)
+        n, width = reads.shape
+        lp = None
+        if lengths is not None:
+            lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+            assert lengths.shape == (n,)
+            lp = vp(lengths.ctypes.data)
+        check(lib().bwtm_builder_add(self.h, vp(reads.ctypes.data), n, width, width, lp, 0))
+
+    def add_device(self, ptr, nreads, width, stride=None, lengths_ptr=None):
+        """The same for rows already on the device (lengths_ptr: device uint32 [nreads] or None)."""
+        check(lib().bwtm_builder_add(self.h, vp(ptr), nreads, width, width if stride is None else stride,
+                                     vp(lengths_ptr) if lengths_ptr else None, 1))
+
+    reads = property(lambda s: int(lib().bwtm_builder_reads(s.h)))
+
+    def finish(self):
+        out = vp()
+        h = self.h
+        self.h = None
+        check(lib().bwtm_builder_finish(h, C.byref(out)))
+        return Index(out)
+
+    def free(self):
+        if self.h:
+            lib().bwtm_builder_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def profile_enable(on=True):

@@ -468,35 +468,42 @@ extern "C" int bwtm_index_from_device_borrowed(const void* device_data, uint64_t
   return BWTM_OK;
 }
 
+namespace
+{
+
+// Plain symbols on the device (one byte per position, 0 = endmarker) -> records.  Synchronizes the compute stream.
+int index_from_symbols(const u8* device_symbols, u64 bases, bwtm_index* x)
+{
+  x->n = bases;
+  x->nrecs = num_records(bases); x->nsup = num_supers(bases);
+  u64 stride = x->nrecs + 1;
+  DevBuf cnt; TRY(cnt.alloc(6 * stride * sizeof(u64), true));
+  LAUNCH("sym_counts", k_sym_counts, div_up(x->nrecs, BLOCK_THREADS), BLOCK_THREADS,
+    device_symbols, bases, x->nrecs, cnt.as<u64>(), stride);
+  TRY(device_scan_multi<0>(cnt.as<u64>(), cnt.as<u64>(), stride, 6, stride));
+  for(u32 c = 0; c < 6; c++) { TRY(fetch_u64(cnt.as<u64>() + c * stride + x->nrecs, c)); }
+  HIP_TRY(hipStreamSynchronize(CTX.stream));
+  const u64* totals = CTX.host_scratch;
+  x->m = totals[0];
+  x->C[0] = 0; for(int c = 0; c < 6; c++) { x->C[c + 1] = x->C[c] + totals[c]; } x->C[7] = x->C[6];
+  TRY(x->recs.alloc(x->nrecs * 64));
+  TRY(x->sup.alloc(x->nsup * SUP_STRIDE * sizeof(u64)));
+  LAUNCH("sym_sup", k_sym_sup, div_up(x->nsup, BLOCK_THREADS), BLOCK_THREADS, cnt.as<const u64>(), stride, x->nrecs, x->sup.as<u64>(), x->nsup);
+  LAUNCH("sym_recs", k_sym_recs, div_up(x->nrecs, BLOCK_THREADS), BLOCK_THREADS,
+    device_symbols, bases, cnt.as<const u64>(), stride, x->sup.as<const u64>(), x->recs.as<uint4>(), x->nrecs);
+  HIP_TRY(hipStreamSynchronize(CTX.stream));     // the caller may release `device_symbols` on return
+  return BWTM_OK;
+}
+
+} // namespace
+
 extern "C" int bwtm_index_from_symbols_device(const void* device_symbols, uint64_t bases, bwtm_index** out)
 {
   ENTER(nullptr);
   if(!out || (bases > 0 && !device_symbols)) { return fail(BWTM_EINVAL, "bwtm_index_from_symbols_device: null argument"); }
   bwtm_index* x = new bwtm_index();
   x->ctx = t_ctx;
-  auto body = [&]() -> int
-  {
-    x->n = bases;
-    x->nrecs = num_records(bases); x->nsup = num_supers(bases);
-    u64 stride = x->nrecs + 1;
-    DevBuf cnt; TRY(cnt.alloc(6 * stride * sizeof(u64), true));
-    LAUNCH("sym_counts", k_sym_counts, div_up(x->nrecs, BLOCK_THREADS), BLOCK_THREADS,
-      (const u8*)device_symbols, bases, x->nrecs, cnt.as<u64>(), stride);
-    TRY(device_scan_multi<0>(cnt.as<u64>(), cnt.as<u64>(), stride, 6, stride));
-    for(u32 c = 0; c < 6; c++) { TRY(fetch_u64(cnt.as<u64>() + c * stride + x->nrecs, c)); }
-    HIP_TRY(hipStreamSynchronize(CTX.stream));
-    const u64* totals = CTX.host_scratch;
-    x->m = totals[0];
-    x->C[0] = 0; for(int c = 0; c < 6; c++) { x->C[c + 1] = x->C[c] + totals[c]; } x->C[7] = x->C[6];
-    TRY(x->recs.alloc(x->nrecs * 64));
-    TRY(x->sup.alloc(x->nsup * SUP_STRIDE * sizeof(u64)));
-    LAUNCH("sym_sup", k_sym_sup, div_up(x->nsup, BLOCK_THREADS), BLOCK_THREADS, cnt.as<const u64>(), stride, x->nrecs, x->sup.as<u64>(), x->nsup);
-    LAUNCH("sym_recs", k_sym_recs, div_up(x->nrecs, BLOCK_THREADS), BLOCK_THREADS,
-      (const u8*)device_symbols, bases, cnt.as<const u64>(), stride, x->sup.as<const u64>(), x->recs.as<uint4>(), x->nrecs);
-    HIP_TRY(hipStreamSynchronize(CTX.stream));     // the caller may release `device_symbols` on return
-    return BWTM_OK;
-  };
-  int rc = body();
+  int rc = index_from_symbols((const u8*)device_symbols, bases, x);
   if(rc != BWTM_OK) { (void)hipStreamSynchronize(CTX.stream); delete x; return rc; }
   *out = x;
   return BWTM_OK;

@@ -34,3 +34,4 @@ using namespace bwtm;
 #include "api/search.hip.h"
 #include "api/merge.hip.h"
 #include "api/slices.hip.h"
+#include "api/ingest.hip.h"

@@ -7,6 +7,7 @@
     k_build_sup/recs   native blocks -> device records ("transcode at upload", BWT::load)
     k_block_cum        samples[c] at the block starts               bwt.cpp:489-511
     k_sym_*            plain symbols -> device records (input tooling)
+    k_ingest_*         reads -> BWT symbols of a leaf (suffix radix sort; SURVEY 8(f1), no counterpart in the reference)
     k_frontier_*       buildRA + BWT::inverse_select + BWT::rank, level-synchronous form (product)
                                                                     fmi.cpp:272-334, bwt.cpp:318-341, 445-464
     k_bound_suffix_min, k_tile_build_frontier
@@ -55,5 +56,6 @@ struct IndexView
 #include "kernels/search_frontier.hip.h"
 #include "kernels/interleave.hip.h"
 #include "kernels/encoder.hip.h"
+#include "kernels/ingest.hip.h"
 
 } // namespace bwtm

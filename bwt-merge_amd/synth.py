@@ -2,11 +2,13 @@
 reads (it relies on RopeBWT / SGA, README.md:5,20), so benchmark inputs are made here:
 
   generate_reads   counter-based splitmix64 reads, identical to oracle/bwtm_oracle.cpp
-  leaf_bwt         multi-string BWT of a batch of reads by LSD radix sort of the suffixes
-  build_index      leaves grown into one index by a merge tree that uses the GPU merger itself
+  leaf_bwt         multi-string BWT of a batch of reads by LSD radix sort of the suffixes (tensor ops; the CPU suite
+                   pins it to the oracle, the GPU suite pins the library's builder to it and to the oracle)
+  build_index      reads -> index: on a GPU through the library's builder (bwtm_builder_*: suffix-sorted leaves grown
+                   by a merge tree that uses the merger itself); native=False drives the same tree from here
 
-This is input tooling, not the hot path: it uses PyTorch tensor ops (device agnostic, so the
-CPU test-suite checks it against the oracle) and hands device pointers to the C ABI.
+The generators are input tooling, not the hot path: PyTorch tensor ops (device agnostic, so the
+CPU test-suite checks them against the oracle) that hand device pointers to the C ABI.
 """
 import numpy as np
 import torch
@@ -169,8 +171,25 @@ def merge_indexes(pkg, a, b, free_inputs=True):
     return out
 
 
-def build_index(pkg, seed, nreads, readlen=100, leaf_reads=1 << 19, device="cuda", progress=None, workload="iid", **workload_args):
-    """Index of the synthetic set `seed` (reads 0 .. nreads-1 in generation order)."""
+def build_index(pkg, seed, nreads, readlen=100, leaf_reads=1 << 19, device="cuda", progress=None, workload="iid", native=True,
+                **workload_args):
+    """Index of the synthetic set `seed` (reads 0 .. nreads-1 in generation order).  native=True: the library's builder
+    (bwtm_builder_*: suffix-sorted leaves + merge tree inside the library); native=False: the tensor-op leaves below with
+    the same merge tree driven from here (what the CPU suite checks against the oracle; kept as a cross-check)."""
+    if native and str(device).startswith("cuda"):
+        builder = pkg.Builder(leaf_reads)
+        for first in range(0, nreads, leaf_reads):
+            count = min(leaf_reads, nreads - first)
+            reads = make_reads(workload, seed, first, count, readlen, nreads, device=device, **workload_args).contiguous()
+            lengths = read_lengths(workload, first, count, readlen, device)
+            if lengths is not None:
+                lengths = lengths.to(torch.int32).contiguous()
+            torch.cuda.synchronize()
+            builder.add_device(reads.data_ptr(), count, reads.shape[1], lengths_ptr=None if lengths is None else lengths.data_ptr())
+            del reads, lengths
+            if progress:
+                progress(first + count, nreads)
+        return builder.finish()
     stack = []                               # (level, index); adjacent entries are adjacent read ranges
     for first in range(0, nreads, leaf_reads):
         count = min(leaf_reads, nreads - first)

@@ -275,6 +275,27 @@ int bwtm_slice_download_samples(bwtm_slice* slice, uint64_t next_block_start, ui
 /* Plain symbols of positions inside the slice. */
 int bwtm_slice_extract(bwtm_slice* slice, uint64_t first, uint64_t count, uint8_t* out);
 
+/* --- ingest: reads -> index ---------------------------------------------------
+   The reference merges BWTs that other tools built (RopeBWT / SGA, README.md:5,20; PlainData::read, formats.cpp:133-161,
+   is the text form of such a collection).  The builder stands in for them on the GPU: reads arrive in batches, in
+   collection order; every `leaf_reads` reads become a leaf BWT by suffix sort (equal suffixes in read order, the order
+   bwt_merge produces), and leaves are combined by the merger itself (bwtm_search + bwtm_interleave on device records),
+   level by level like a binary counter.  The result is what merging the per-read BWTs in order would give. */
+
+typedef struct bwtm_builder bwtm_builder;
+
+/* leaf_reads = 0: default (2^19); a leaf is also capped so that leaf_reads * (width + 1) < 2^32. */
+int bwtm_builder_create(uint64_t leaf_reads, bwtm_builder** out);
+/* `nreads` rows of `stride` bytes, comp values 1..5 (Alphabet, support.h:167-169); row k holds lengths[k] <= width
+   symbols (lengths == NULL: every row holds `width`).  Pointers are device pointers when on_device != 0, host pointers
+   otherwise.  Returns when the batch has been consumed. */
+int bwtm_builder_add(bwtm_builder* builder, const uint8_t* reads, uint64_t nreads, uint32_t width, uint64_t stride,
+                     const uint32_t* lengths, int on_device);
+uint64_t bwtm_builder_reads(const bwtm_builder* builder);
+/* Merges what is left and hands the index over (records only, like bwtm_interleave's result); frees the builder. */
+int bwtm_builder_finish(bwtm_builder* builder, bwtm_index** out);
+void bwtm_builder_free(bwtm_builder* builder);
+
 /* --- measurement ----------------------------------------------------------------------------- */
 
 /* When enabled, every kernel launch is bracketed by HIP events on the context's compute stream. */

@@ -125,3 +125,38 @@ def test_cli_errors_like_reference(bwtm, tmp_path):
     assert out.returncode != 0 and "bwt_merge: Output file not specified" in out.stderr
     out = subprocess.run([exe, str(tmp_path / "missing1"), str(tmp_path / "missing2"), str(tmp_path / "out")], capture_output=True, text=True)
     assert out.returncode != 0 and "Cannot open input file" in out.stderr
+
+
+@pytest.mark.gpu
+def test_cli_ingest_reads_then_merge(bwtm, oracle, tmp_path):
+    """bwt_ingest: reads (text, one per line, ragged) -> BWT; against the oracle's brute-force BWT, and the merge of two
+    ingested halves against the ingest of the whole."""
+    build_host()
+    rng = np.random.default_rng(11)
+    reads = []
+    for k in range(900):
+        n = int(rng.integers(0, 140)) if k % 9 else 100
+        reads.append(bytes(CHARS[1 + rng.integers(0, 5, size=n)]).decode())
+    reads[5] = reads[4]; reads[17] = "acgtnacgtX"                       # a duplicate; lower case and a foreign character
+    halves = (reads[:400], reads[400:])
+    for name, part in (("a", halves[0]), ("b", halves[1]), ("all", reads)):
+        (tmp_path / (name + ".txt")).write_text("\n".join(part) + "\n")
+    ingest = os.path.join(HOST, "bwt_ingest")
+    for name, leaf in (("a", 150), ("b", 524288), ("all", 256)):
+        out = subprocess.run([ingest, "-l", str(leaf), str(tmp_path / (name + ".txt")), str(tmp_path / (name + ".bwt"))], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "Read %d reads of total length %d" % (len(open(tmp_path / (name + ".txt")).read().splitlines()),
+                                                      sum(len(r) for r in (halves[0] if name == "a" else halves[1] if name == "b" else reads))) in out.stdout
+    out = subprocess.run([os.path.join(HOST, "bwt_merge"), str(tmp_path / "a.bwt"), str(tmp_path / "b.bwt"), str(tmp_path / "ab.bwt")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert (tmp_path / "ab.bwt").read_bytes() == (tmp_path / "all.bwt").read_bytes()
+    # the oracle's BWT of the same collection, through the plain format
+    out = subprocess.run([os.path.join(HOST, "bwt_convert"), "-i", "native", "-o", "plain_default", str(tmp_path / "all.bwt"), str(tmp_path / "all.plain")],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    comp = np.full(256, 5, dtype=np.uint8)
+    for ch, c in zip(b"ACGTacgt", [1, 2, 3, 4, 1, 2, 3, 4]):
+        comp[ch] = c
+    text = np.concatenate([np.concatenate([comp[np.frombuffer(r.encode(), dtype=np.uint8)], np.zeros(1, dtype=np.uint8)]) for r in reads])
+    ref = oracle.FMI.from_text(text)
+    assert (tmp_path / "all.plain").read_bytes() == CHARS[ref.symbols].tobytes()

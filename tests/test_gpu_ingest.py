@@ -1,0 +1,116 @@
+"""Reads -> index on the GPU (bwtm_builder_*): the BWT of the collection must equal the oracle's
+brute-force BWT (suffixes compared symbol by symbol, endmarkers smallest, equal suffixes in read order -- the order a
+chain of bwt_merge runs over single-read BWTs produces), for one leaf and for every shape of the merge tree."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(bwtm):
+    bwtm.init(0)
+    return bwtm
+
+
+def text_of(reads, lengths=None):
+    """Rows -> the oracle's text: every read followed by an endmarker."""
+    parts = []
+    for k, row in enumerate(reads):
+        n = reads.shape[1] if lengths is None else int(lengths[k])
+        parts.append(row[:n]); parts.append(np.zeros(1, dtype=np.uint8))
+    return np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
+
+
+def built(gpu, reads, lengths=None, leaf_reads=0, batches=1, device=False):
+    b = gpu.Builder(leaf_reads)
+    edges = np.linspace(0, reads.shape[0], batches + 1).astype(int)
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        if device:
+            import torch
+            t = torch.from_numpy(np.ascontiguousarray(reads[lo:hi])).cuda()
+            tl = None if lengths is None else torch.from_numpy(np.ascontiguousarray(lengths[lo:hi]).astype(np.int32)).cuda()
+            torch.cuda.synchronize()
+            b.add_device(t.data_ptr(), hi - lo, reads.shape[1], lengths_ptr=None if tl is None else tl.data_ptr())
+        else:
+            b.add(reads[lo:hi], None if lengths is None else lengths[lo:hi])
+    assert b.reads == reads.shape[0]
+    return b.finish()
+
+
+def check_against_oracle(gpu, oracle, reads, lengths=None, **kw):
+    ref = oracle.FMI.from_text(text_of(reads, lengths))
+    x = built(gpu, reads, lengths, **kw)
+    assert x.bases == ref.bases and x.sequences == ref.sequences
+    assert np.array_equal(x.C, ref.C)
+    assert np.array_equal(x.extract(0, x.bases), ref.symbols)
+    # and the native form the encoder makes of it is the canonical one
+    x.encode()
+    assert np.array_equal(x.data(), ref.data)
+    x.free()
+
+
+@pytest.mark.parametrize("n,L,leaf", [(1, 5, 0), (7, 1, 0), (300, 30, 0), (300, 30, 64), (1000, 100, 128), (257, 64, 1), (4000, 100, 1000)])
+def test_iid_reads_match_brute_force(gpu, oracle, n, L, leaf):
+    reads = oracle.generate_reads(4242 + n, n, L).reshape(n, L + 1)[:, :L].copy()
+    check_against_oracle(gpu, oracle, reads, leaf_reads=leaf)
+
+
+def test_batches_and_device_pointers(gpu, oracle):
+    reads = oracle.generate_reads(99, 1500, 75).reshape(1500, 76)[:, :75].copy()
+    check_against_oracle(gpu, oracle, reads, leaf_reads=200, batches=4)
+    check_against_oracle(gpu, oracle, reads, leaf_reads=512, batches=3, device=True)
+
+
+def test_ragged_duplicate_and_empty_reads(gpu, oracle):
+    rng = np.random.default_rng(5)
+    n, W = 600, 150
+    reads = oracle.generate_reads(31, n, W).reshape(n, W + 1)[:, :W].copy()
+    lengths = rng.integers(0, W + 1, size=n).astype(np.uint32)
+    lengths[::7] = 100; lengths[3] = 0; lengths[4] = 0; lengths[-1] = W
+    reads[10:20] = reads[0:10]; lengths[10:20] = lengths[0:10]            # exact duplicates: ordered by read index
+    reads[20, :40] = reads[21, 5:45]                                       # one read is a substring of another
+    for k in range(n):
+        reads[k, lengths[k]:] = 0
+    check_against_oracle(gpu, oracle, reads, lengths, leaf_reads=0)
+    check_against_oracle(gpu, oracle, reads, lengths, leaf_reads=100, batches=3)
+    check_against_oracle(gpu, oracle, reads, lengths, leaf_reads=64, batches=2, device=True)
+
+
+def test_low_entropy_reads_need_every_key_word(gpu, oracle):
+    """Reads over a 3-letter repeat: suffixes agree for long stretches, so every 21-symbol word of the key decides."""
+    n, L = 400, 130
+    k = np.arange(L)[None, :] + (np.arange(n)[:, None] % 3)
+    reads = (1 + (k % 3)).astype(np.uint8)
+    reads[::5, 77] = 4
+    check_against_oracle(gpu, oracle, reads, leaf_reads=0)
+    check_against_oracle(gpu, oracle, reads, leaf_reads=90)
+
+
+def test_builder_equals_torch_tooling_and_chained_merges(gpu, oracle):
+    """A 2^15-read leaf against the tensor-op builder the CPU suite pins to the oracle, and leaves of other sizes against it."""
+    from bwt_merge_amd import synth
+    n, L = 1 << 15, 100
+    reads = synth.generate_reads(77, 0, n, L).numpy()
+    ref = synth.leaf_bwt(synth.generate_reads(77, 0, n, L)).numpy()
+    for leaf in (0, 5000):
+        x = built(gpu, reads, leaf_reads=leaf)
+        assert x.bases == ref.size and x.sequences == n
+        assert np.array_equal(x.extract(0, x.bases), ref)
+        x.free()
+
+
+def test_rejects_bad_input(gpu):
+    reads = np.full((10, 8), 2, dtype=np.uint8)
+    reads[4, 3] = 0
+    b = gpu.Builder()
+    with pytest.raises(gpu.BwtmError):
+        b.add(reads)
+    b.free()
+    b = gpu.Builder()
+    with pytest.raises(gpu.BwtmError):
+        b.add(np.full((4, 8), 1, dtype=np.uint8), np.array([8, 9, 1, 2], dtype=np.uint32))
+    b.free()
+    e = gpu.Builder().finish()
+    assert e.bases == 0 and e.sequences == 0
+    e.free()
