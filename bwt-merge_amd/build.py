@@ -7,10 +7,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbwtm.so")
 SOURCES = ["bwtm_api.hip"]
-KERNELS = ["common", "transcode", "queries", "search_walk", "search_frontier", "interleave", "encoder", "diagnostics"]
-API = ["context", "index", "search", "merge", "slices"]
+import glob
 DEPS = (["bwtm_api.hip", "bwtm_kernels.hip.h", "bwtm_device.h", os.path.join("..", "..", "include", "bwtm.h")]
-        + [os.path.join("kernels", k + ".hip.h") for k in KERNELS] + [os.path.join("api", k + ".hip.h") for k in API])
+        + [os.path.relpath(f, CSRC) for f in sorted(glob.glob(os.path.join(CSRC, "kernels", "*.hip.h")) + glob.glob(os.path.join(CSRC, "api", "*.hip.h")))])
 
 
 def hipcc():

@@ -80,6 +80,7 @@ struct Tuning
   long long eager_cum_budget = 16ll << 30; // bwtm_index_encode materializes the samples' cumulative counts when they take at most this many bytes
   long long upload_chunk = 64ll << 20;    // bytes per H2D chunk of the pipelined upload
   long long download_chunk = 128ll << 20; // approximate bytes per D2H chunk of the pipelined download
+  long long ingest_verify = 0;            // 1 = the builder checks every leaf's suffix order against the reads (one extra pass of gathers per leaf)
 #ifdef BWTM_DIAGNOSTICS
   long long walk_emit = 0;       // 0 = real emit; 1 / 2 timing-only variants of the emit (see diagnostics.hip.h)
   long long walk_blocks = 0;     // grid size override for the walk kernels (0 = default)
@@ -591,6 +592,7 @@ extern "C" int bwtm_tune(const char* key, long long value)
   else if(k == "round_emits") { g_tune.round_emits = (value > 0 ? value : 1); }
   else if(k == "emit_budget") { g_tune.emit_budget = (value > 0 ? value : (16ll << 30)); }
   else if(k == "frontier_epoch") { g_tune.frontier_epoch = (value > 0 ? value : 512); }
+  else if(k == "ingest_verify") { g_tune.ingest_verify = (value != 0); }
   else if(k == "eager_cum_budget") { g_tune.eager_cum_budget = (value > 0 ? value : (16ll << 30)); }
   else if(k == "upload_chunk") { g_tune.upload_chunk = (value > 0 ? value : (64ll << 20)); }
   else if(k == "download_chunk") { g_tune.download_chunk = (value > 0 ? value : (128ll << 20)); }

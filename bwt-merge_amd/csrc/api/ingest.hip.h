@@ -69,6 +69,13 @@ int leaf_from_reads(const u8* reads, u64 m, u32 width, u64 stride, const u32* le
       cur ^= 1;
     }
   }
+  DevBuf bad;
+  if(g_tune.ingest_verify && n > 1)
+  {
+    TRY(bad.alloc(sizeof(u64), true));
+    LAUNCH("ingest_verify", k_ingest_verify, div_up(n, BLOCK_THREADS), BLOCK_THREADS, reads, stride, lengths, width, ids[cur].as<const u32>(), n, bad.as<unsigned long long>());
+    TRY(fetch_u64(bad.as<u64>(), 9));
+  }
   DevBuf sym; TRY(sym.alloc(n));
   if(n > 0) { LAUNCH("ingest_symbols", k_ingest_symbols, div_up(n, BLOCK_THREADS), BLOCK_THREADS, reads, stride, width, ids[cur].as<const u32>(), n, sym.as<u8>()); }
   HIP_TRY(hipMemcpyAsync(CTX.host_scratch + 8, flags.p, sizeof(u32), hipMemcpyDeviceToHost, CTX.stream));
@@ -81,6 +88,7 @@ int leaf_from_reads(const u8* reads, u64 m, u32 width, u64 stride, const u32* le
     if(f & 1u) { rc = fail(BWTM_EINVAL, "ingest: a read holds a value outside 1..5"); }
     else if(f & 2u) { rc = fail(BWTM_EINVAL, "ingest: a read is longer than the row width %u", width); }
     else if(x->m != m) { rc = fail(BWTM_EINVAL, "ingest: built %llu sequences from %llu reads", (unsigned long long)x->m, (unsigned long long)m); }
+    else if(bad.p && CTX.host_scratch[9] != 0) { rc = fail(BWTM_ENODEV, "ingest: the suffix sort left %llu adjacent pairs out of order", (unsigned long long)CTX.host_scratch[9]); }
   }
   if(rc != BWTM_OK) { (void)hipStreamSynchronize(CTX.stream); delete x; return rc; }
   *out = x;

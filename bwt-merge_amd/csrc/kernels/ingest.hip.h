@@ -68,6 +68,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_ingest_pack(const u8* reads, 
 }
 
 // keys[i] = word `word` of the suffix ids[i]: symbol j of the word in bits [3 (20 - j), 3 (20 - j) + 3).
+// Both packed words come in ONE 16-byte load (8-byte aligned).  The obvious form -- two 8-byte loads, the second one under
+// `if(r != 0)` -- compiled to `global_load_dwordx2 v[4:5], v[4:5], off offset:8` (destination = its own address registers,
+// issued while the first load from the same registers was in flight) and returned a garbled second word for about 2 of
+// 5.3e7 lanes per launch on gfx950 / ROCm 7.2, in 15 of 25 leaf builds (found by k_ingest_verify; memory was intact before
+// and after).  This form and a byte-wise gather never failed; see DESIGN.md section 7.
 __global__ void __launch_bounds__(BLOCK_THREADS) k_ingest_keys(const u64* packed, u32 row_words, u32 width,
   const u32* ids, u64 n, u32 word, u64* keys)
 {
@@ -76,10 +81,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_ingest_keys(const u64* packed
   const u32 w1 = width + 1, id = ids[i];
   const u32 s = id / w1, o = id - s * w1;
   const u32 bit = 3 * (o + word * ING_SYMS);
-  const u64* row = packed + (u64)s * row_words + (bit >> 6);
+  const u32* w = (const u32*)(packed + (u64)s * row_words + (bit >> 6));
   const u32 r = bit & 63u;
-  const u64 hi = row[0], lo = row[1];
-  const u64 v = (r == 0 ? hi : (hi << r) | (lo >> (64 - r)));
+  const u32 a = w[1], b = w[0], c = w[3], d = w[2];
+  const u64 hi = ((u64)a << 32) | b, lo = ((u64)c << 32) | d;
+  const u64 v = (hi << r) | ((lo >> 1) >> (63 - r));                   // r = 0: the second term is 0
   keys[i] = v >> 1;
 }
 
@@ -145,4 +151,27 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_ingest_symbols(const u8* read
   const u32 w1 = width + 1, id = ids[i];
   const u32 s = id / w1, o = id - s * w1;
   sym[i] = (o > 0 ? reads[(u64)s * stride + o - 1] : (u8)0);
+}
+
+// Verification (bwtm_tune("ingest_verify", 1); the GPU tests run with it): adjacent suffixes of the final order compared
+// symbol by symbol from the reads themselves; bad[0] += pairs that are out of order or equal.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_ingest_verify(const u8* reads, u64 stride, const u32* lengths, u32 width, const u32* ids, u64 n,
+  unsigned long long* bad)
+{
+  const u64 i = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(i + 1 >= n) { return; }
+  const u32 w1 = width + 1;
+  const u32 a = ids[i], b = ids[i + 1];
+  const u32 sa = a / w1, oa = a - sa * w1, sb = b / w1, ob = b - sb * w1;
+  const u32 la = (lengths ? (lengths[sa] < width ? lengths[sa] : width) : width), lb = (lengths ? (lengths[sb] < width ? lengths[sb] : width) : width);
+  const u8* ra = reads + (u64)sa * stride; const u8* rb = reads + (u64)sb * stride;
+  int cmp = 0;
+  for(u32 k = 0; k <= width && cmp == 0; k++)
+  {
+    const u32 ca = (oa + k < la ? ra[oa + k] : 0), cb = (ob + k < lb ? rb[ob + k] : 0);
+    if(ca != cb) { cmp = (ca < cb ? -1 : 1); }
+    else if(ca == 0) { break; }
+  }
+  if(cmp == 0) { cmp = (a < b ? -1 : 1); }                             // equal suffixes: read order
+  if(cmp > 0) { atomicAdd(&bad[0], 1ull); }
 }

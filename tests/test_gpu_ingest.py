@@ -10,7 +10,9 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def gpu(bwtm):
     bwtm.init(0)
-    return bwtm
+    bwtm.tune("ingest_verify", 1)            # every leaf's suffix order is checked against the reads on the device
+    yield bwtm
+    bwtm.tune("ingest_verify", 0)
 
 
 def text_of(reads, lengths=None):
@@ -98,6 +100,35 @@ def test_builder_equals_torch_tooling_and_chained_merges(gpu, oracle):
         assert x.bases == ref.size and x.sequences == n
         assert np.array_equal(x.extract(0, x.bases), ref)
         x.free()
+
+
+def test_large_leaves_repeatedly(gpu):
+    """Leaves of 2^19 reads, built again and again with the device-side order check on, merged, and compared with the
+    tensor-op builder: a key gather that returned a garbled word for ~2 of 5e7 lanes in most launches
+    passed every small test and failed here."""
+    import torch
+    from bwt_merge_amd import synth
+    leaf, L = 1 << 19, 100
+    reads = synth.generate_reads(1001, 0, 2 * leaf, L, device="cuda").contiguous()
+    refs = [synth.leaf_bwt(reads[k * leaf:(k + 1) * leaf]).cpu().numpy() for k in range(2)]
+    torch.cuda.synchronize()
+    first = None
+    for rep in range(6):
+        for k in range(2):
+            b = gpu.Builder(leaf)
+            b.add_device(reads.data_ptr() + k * leaf * L, leaf, L)
+            x = b.finish()
+            assert np.array_equal(x.extract(0, x.bases), refs[k]), "rep %d leaf %d" % (rep, k)
+            x.free()
+        b = gpu.Builder(leaf)
+        b.add_device(reads.data_ptr(), 2 * leaf, L)
+        x = b.finish()
+        sym = x.extract(0, x.bases)
+        x.free()
+        if first is None:
+            first = sym
+        assert np.array_equal(sym, first)
+    del reads
 
 
 def test_rejects_bad_input(gpu):
