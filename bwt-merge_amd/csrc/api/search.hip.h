@@ -216,7 +216,10 @@ int search_partitioned(const bwtm_index* a, const bwtm_index* b, u64 seq_first, 
 int frontier_flush(bwtm_ra* ra, DevBuf& emit16, u64 emit_cap, DevBuf& emit_base, DevBuf& bound, u64 ntiles, u64 nsteps)
 {
   if(nsteps == 0) { return BWTM_OK; }
-  LAUNCH("bound_suffix_min", k_bound_suffix_min, nsteps, BLOCK_THREADS, bound.as<u32>(), ntiles, emit_base.as<const u64>(), nsteps);
+  const u64 nsegs = div_up(ntiles, BOUND_SEG);
+  DevBuf segmin; TRY(segmin.alloc(nsteps * nsegs * sizeof(u32)));
+  LAUNCH2D("bound_seg_min", k_bound_seg_min, nsegs, nsteps, BLOCK_THREADS, bound.as<const u32>(), ntiles, nsegs, segmin.as<u32>());
+  LAUNCH2D("bound_suffix_min", k_bound_suffix_min, nsegs, nsteps, BLOCK_THREADS, bound.as<u32>(), ntiles, nsegs, segmin.as<const u32>(), emit_base.as<const u64>());
   LAUNCH("tile_build", k_tile_build_frontier, ntiles, BLOCK_THREADS, emit16.as<const unsigned short>(), emit_base.as<const u64>(), emit_cap, bound.as<const u32>(),
     ntiles, nsteps, ra->bits_as<u64>(), ra->nchunks * CHUNK_WORDS);
   return BWTM_OK;
