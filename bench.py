@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-host", action="store_true", help="skip the host-to-host measurement")
     ap.add_argument("--host-steps", type=int, default=3)
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="bwtm_tune knobs for experiments (product knobs never change results)")
     ap.add_argument("--verify-reads", type=int, default=10000, help="reads extracted from the merged index and compared with the generator")
     ap.add_argument("--chain", type=int, default=2,
                     help="number of input sets; more than 2 = chained merge in command-line order (BASELINE config 5: bwt_merge in1 in2 in3 in4 out), "
@@ -87,6 +88,10 @@ def main():
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
+
+    for kv in args.tune:
+        key, _, value = kv.partition("=")
+        pkg.tune(key, int(value))
 
     def barrier():
         pkg.synchronize()
