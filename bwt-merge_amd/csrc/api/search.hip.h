@@ -271,7 +271,7 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   for(u32 k = 0; k < LOOK; k++) { HIP_TRY(hipEventCreateWithFlags(&events.ev[k], hipEventDisableTiming)); events.n = k + 1; }
   const u64 scan_tiles = div_up(nseg + 1, (u64)SCAN_TILE);
   DevBuf scan_partial; TRY(scan_partial.alloc(scan_tiles * sizeof(u64)));
-  TRY(emit16.alloc(emit_cap * sizeof(unsigned short)));
+  TRY(emit16.alloc((emit_cap + 16) * sizeof(unsigned short)));     // k_tile_build_frontier reads 16-byte chunks
   TRY(emit_base.alloc((EPOCH + 1) * sizeof(u64), true));
   TRY(bound.alloc(EPOCH * (ntiles + 1) * sizeof(u32)));
   HIP_TRY(hipMemsetAsync(bound.p, 0xFF, EPOCH * (ntiles + 1) * sizeof(u32), CTX.stream));

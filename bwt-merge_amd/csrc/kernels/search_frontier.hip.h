@@ -405,37 +405,71 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_tile_build_frontier(const uns
     }
     const u64 left = (nsteps - t0 + NW - 1) / NW;                  // steps of this wave from t0 on
     const u32 cnt = (left < (u64)WAVE ? (u32)left : (u32)WAVE);
-    // Software pipeline over the runs: the offsets of run j + 1 (the first 8 x 64 of them: a run of config 2 has ~330) are in
-    // flight while the bits of run j are set, so the wave always has dependent-load latency to hide behind LDS atomics.
-    constexpr u32 UN = 8;
-    u32 cur[UN], nxt[UN];
-    auto fetch = [&](u32 j, u32* off, u32& lo_out, u32& hi_out, u64& base_out)
+    // Software pipeline over the runs.  A run (~330 offsets at config 2) is ONE 16-byte load per lane: lane l takes the eight
+    // offsets from the even element at or below the run's start + 8 l on (4-byte aligned; lanes past the end re-read the run's
+    // last chunk, so no extra lines are fetched and no load is predicated).  The loads of run j + 1 are in flight while the
+    // bits of run j are set: with unconditional loads and two alternating register sets the compiler counts them
+    // (s_waitcnt vmcnt(1)) instead of draining right after the prefetch was issued, which the first version -- eight predicated
+    // 2-byte loads per lane and run -- made it do.
+    struct Run { u32 lo, hi; u64 base; };
+    auto params = [&](u32 j) -> Run
     {
-      lo_out = (u32)__shfl((int)my_lo, (int)j, WAVE); hi_out = (u32)__shfl((int)my_hi, (int)j, WAVE);
-      base_out = shfl_u64(my_base, (int)j);
+      Run r;
+      r.lo = (u32)__shfl((int)my_lo, (int)j, WAVE); r.hi = (u32)__shfl((int)my_hi, (int)j, WAVE);
+      r.base = shfl_u64(my_base, (int)j);
+      return r;
+    };
+    const u32* emit32 = (const u32*)emit16;
+    auto issue = [&](const Run& r, u32* v)
+    {
+      u64 A = (r.base + r.lo) & ~1ull;                                     // even element index: a dword boundary
+      u64 last = r.base + r.hi; if(last > emit_cap) { last = emit_cap; }   // slots past the capacity took the fallback and are never read
+      if(A > emit_cap) { A = emit_cap & ~1ull; }                           // (the buffer has 16 entries of padding)
+      const u64 span = (r.hi > r.lo && last > A ? last - A : 1);           // elements from A to the end of the run
+      const u64 cmax = (span - 1) >> 3;                                    // last 8-element chunk that holds a valid offset
+      const u64 c = ((u64)lane < cmax ? (u64)lane : cmax);
+      const u32* p = emit32 + (A >> 1) + 4 * c;
+      v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3];
+    };
+    auto deposit = [&](const Run& r, const u32* v)
+    {
+      const u64 A = (r.base + r.lo) & ~1ull;
+      const u64 first = r.base + r.lo;
+      u64 last = r.base + r.hi; if(last > emit_cap) { last = emit_cap; }   // slots past the capacity took the fallback
+      const u64 e0 = A + 8 * (u64)lane;
 #pragma unroll
-      for(u32 u = 0; u < UN; u++)
+      for(u32 q = 0; q < 8; q++)
       {
-        const u64 kk = (u64)lo_out + lane + u * WAVE;
-        off[u] = (kk < hi_out && base_out + kk < emit_cap ? (u32)emit16[base_out + kk] : 0xFFFFFFFFu);
+        const u64 e = e0 + q;
+        const u32 o = (q & 1 ? v[q >> 1] >> 16 : v[q >> 1] & 0xFFFFu);
+        if(e >= first && e < last) { atomicOr(&tile[o >> 5], 1u << (o & 31)); }
       }
     };
-    u32 lo = 0, hi = 0, nlo = 0, nhi = 0; u64 base = 0, nbase = 0;
-    if(cnt > 0) { fetch(0, cur, lo, hi, base); }
-    for(u32 j = 0; j < cnt; j++)
+    auto rest = [&](const Run& r)                                          // a long run: offsets beyond the 512 elements from A on
     {
-      if(j + 1 < cnt) { fetch(j + 1, nxt, nlo, nhi, nbase); }
-      seen |= (hi > lo);
-#pragma unroll
-      for(u32 u = 0; u < UN; u++) { if(cur[u] != 0xFFFFFFFFu) { atomicOr(&tile[cur[u] >> 5], 1u << (cur[u] & 31)); } }
-      // the rest of a long run (more than 512 emits of one step in one tile)
-      for(u64 k = (u64)lo + lane + UN * WAVE; k < hi; k += WAVE)
+      const u64 A = (r.base + r.lo) & ~1ull;
+      u64 last = r.base + r.hi; if(last > emit_cap) { last = emit_cap; }
+      for(u64 e = A + 8 * WAVE + lane; e < last; e += WAVE) { const u32 o = emit16[e]; atomicOr(&tile[o >> 5], 1u << (o & 31)); }
+    };
+    if(cnt > 0)
+    {
+      u32 va[4], vb[4];
+      Run ra = params(0);
+      issue(ra, va);
+      for(u32 j = 0; j < cnt; j += 2)
       {
-        if(base + k < emit_cap) { const u32 o = emit16[base + k]; atomicOr(&tile[o >> 5], 1u << (o & 31)); }
+        const Run rb = params(j + 1 < cnt ? j + 1 : cnt - 1);
+        issue(rb, vb);
+        seen |= (ra.hi > ra.lo);
+        deposit(ra, va);
+        const bool long_a = (ra.hi - ra.lo > 8 * WAVE - 2);
+        const Run ra_done = ra;
+        ra = params(j + 2 < cnt ? j + 2 : cnt - 1);
+        issue(ra, va);
+        if(j + 1 < cnt) { seen |= (rb.hi > rb.lo); deposit(rb, vb); }
+        if(long_a) { rest(ra_done); }
+        if(j + 1 < cnt && rb.hi - rb.lo > 8 * WAVE - 2) { rest(rb); }
       }
-#pragma unroll
-      for(u32 u = 0; u < UN; u++) { cur[u] = nxt[u]; }
-      lo = nlo; hi = nhi; base = nbase;
     }
   }
   if(seen && lane == 0) { any = 1; }
