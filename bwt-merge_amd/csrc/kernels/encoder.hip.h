@@ -264,10 +264,45 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
   u64 last = prevhead[seg];
   if(head_carry > last) { last = head_carry; }
   u64 off = seg_base[seg];           // wave-uniform byte offset
+  u32 seg_head = (u32)(off & 15);    // bytes before the segment's first byte in its 16-byte group: they belong to the segment before
   for(int k = 0; k < SEG_CHUNKS; k++)
   {
     u64 ft = first + (u64)k * 64;
     if(ft >= ntiles) { break; }
+    // The bytes of a chunk leave as 16-byte stores at the 16-byte phase of their destination.  The group the chunk ends in is
+    // completed by the next chunk of the same wave, so its bytes stay in LDS (moved to the front) instead of being stored one
+    // by one and the next chunk's first group is whole; only the first group of a segment (shared with the segment before)
+    // and the last one (shared with the next) are written bytewise.  (Per-chunk edge stores were ~10 % of the kernel's instructions.)
+    const bool last_chunk = (k == SEG_CHUNKS - 1 || ft + 64 >= ntiles);
+    auto flush_chunk = [&](u8* lds, u32 a, u32 total, u64 origin)      // lds[0, total) belongs at out + origin (16-byte aligned); [0, a) precedes this chunk
+    {
+      (void)a;
+      __builtin_amdgcn_wave_barrier();
+      u8* base = out + origin;
+      const u32 head = seg_head;                                       // bytes of group 0 that are not this segment's (until group 0 has left)
+      const u32 whole = (last_chunk ? total : (total & ~15u));         // bytes that leave now
+      if(whole != 0) { seg_head = 0; }
+      for(u32 j = lane_id(); j * 16 < whole; j += WAVE)
+      {
+        u32 lo = 16 * j, hi = lo + 16;
+        if(lo >= head && hi <= whole) { *(uint4*)(base + lo) = *(const uint4*)(lds + lo); }
+        else
+        {
+          u32 from = (lo > head ? lo : head), to = (hi < whole ? hi : whole);
+          for(u32 t = from; t < to; t++) { base[t] = lds[t]; }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if(!last_chunk && whole != 0)
+      {
+        const u32 r = total - whole;                                   // 0 .. 15 bytes stay for the next chunk
+        u8 keep = 0;
+        if(lane_id() < r) { keep = lds[whole + lane_id()]; }
+        __builtin_amdgcn_wave_barrier();
+        if(lane_id() < r) { lds[lane_id()] = keep; }
+        __builtin_amdgcn_wave_barrier();
+      }
+    };
     TileInfo ti;
     carry = chunk_tiles(recs, nrecs, ft, n, carry, ti);
     u64 T = ft + lane_id();
@@ -320,20 +355,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
           }
         }
       }
-      __builtin_amdgcn_wave_barrier();
-      const u32 total = a + (u32)chunk_events;
-      u8* base = out + (off - a);                                      // 16-byte aligned
-      for(u32 j = lane_id(); j * 16 < total; j += WAVE)
-      {
-        u32 lo = 16 * j, hi = lo + 16;
-        if(lo >= a && hi <= total) { *(uint4*)(base + lo) = *(const uint4*)(lds + lo); }
-        else
-        {
-          u32 from = (lo > a ? lo : a), to = (hi < total ? hi : total);
-          for(u32 t = from; t < to; t++) { base[t] = lds[t]; }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
+      flush_chunk(lds, a, a + (u32)chunk_events, off - a);
       off += chunk_events;
     }
     else
@@ -379,20 +401,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
           prev1 = pos + 1;
         }
       }
-      __builtin_amdgcn_wave_barrier();
-      const u32 total = a + (u32)chunk_events + extra;
-      u8* base = out + origin;                                         // 16-byte aligned
-      for(u32 j = lane_id(); j * 16 < total; j += WAVE)
-      {
-        u32 lo = 16 * j, hi = lo + 16;
-        if(lo >= a && hi <= total) { *(uint4*)(base + lo) = *(const uint4*)(lds + lo); }
-        else
-        {
-          u32 from = (lo > a ? lo : a), to = (hi < total ? hi : total);
-          for(u32 t = from; t < to; t++) { base[t] = lds[t]; }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
+      flush_chunk(lds, a, a + (u32)chunk_events + extra, origin);
       off += chunk_events + extra;
     }
     u64 m = shfl_u64(incl, WAVE - 1);
