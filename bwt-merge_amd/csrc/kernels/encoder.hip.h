@@ -338,6 +338,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
         int prev_bit; u32 run_sym;
         if(tb + b0 == 0) { h &= h - 1; prev_bit = 0; run_sym = (u32)(ti.p0 & 1) | ((u32)(ti.p1 & 1) << 1) | ((u32)(ti.p2 & 1) << 2); }   // position 0 is a head without an event
         else { prev_bit = (int)b0 - (int)(u32)(tb + b0 + 1 - before); run_sym = event_symbol(ti, b0); }
+        // The loop body is kept free of branches and 64-bit arithmetic (it runs ~48 times per lane and the kernel is
+        // VALU-bound): the run that opens a block is remembered with a select and stored after the walk, the byte is a 24-bit mad.
+        constexpr int NO_OPEN = -0x40000000;
+        int open_prev = NO_OPEN;                                         // start (in-tile, may be negative) of the run that opens a block
 #pragma unroll
         for(int half = 0; half < 2; half++)
         {
@@ -347,13 +351,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
           {
             const u32 bb = (u32)__builtin_ctz(hh); hh &= hh - 1;
             const int bit = (int)bb + 32 * half;
-            const u32 len = (u32)(bit - prev_bit);
-            if(idx == opens) { block_start[(off - a + idx) >> 6] = tb + (u64)(long long)prev_bit; }   // this run opens a block
-            lds[idx++] = (u8)(run_sym + 6 * (len - 1));                  // Run::encodeBasic, support.h:231-234
-            run_sym = ((q0 >> bb) & 1u) | (((q1 >> bb) & 1u) << 1) | (((q2 >> bb) & 1u) << 2);
+            const u32 len1 = (u32)(bit - prev_bit - 1);                  // length - 1 <= 40
+            open_prev = (idx == opens ? prev_bit : open_prev);
+            u32 byte;                                                     // run_sym + 6 (length - 1): Run::encodeBasic, support.h:231-234
+            asm("v_mad_u32_u24 %0, %1, 6, %2" : "=v"(byte) : "v"(len1), "v"(run_sym));   // (the compiler picks the quarter-rate v_mad_u64_u32 here)
+            lds[idx++] = (u8)byte;
+            run_sym = __builtin_amdgcn_ubfe(q0, bb, 1u) | (__builtin_amdgcn_ubfe(q1, bb, 1u) << 1) | (__builtin_amdgcn_ubfe(q2, bb, 1u) << 2);
             prev_bit = bit;
           }
         }
+        if(open_prev != NO_OPEN) { block_start[(off - a + opens) >> 6] = tb + (u64)(long long)open_prev; }
       }
       flush_chunk(lds, a, a + (u32)chunk_events, off - a);
       off += chunk_events;
