@@ -318,39 +318,87 @@ __global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64
     if(inside)
     {
       // The block lies inside the LDS window (the common case): its runs are appended to three bit
-      // streams, one per plane, through 64-bit shift accumulators that release a word whenever 32 bits
-      // are complete.  No clipping: bits past the last owned record are never read.
-      u64 acc0 = 0, acc1 = 0, acc2 = 0;
+      // streams, one per plane, through a pair of 32-bit accumulators per plane (current word, spill-over) that release a
+      // word whenever 32 bits are complete.  No clipping: bits past the last owned record are never read.
+      // All arithmetic of the loop is 32-bit: the first version kept 64-bit accumulators, and its two v_lshlrev_b64 per byte
+      // (quarter rate) and the select / or pairs on register pairs were half of the ~40 instructions per byte.
+      u32 lo0 = 0, lo1 = 0, lo2 = 0, hi0 = 0, hi1 = 0, hi2 = 0;
       u32 fill = (u32)(bstart - ws) & 31u, wi = (u32)(bstart - ws) >> 5;
+      auto flush = [&]()
+      {
+        atomicOr(&pl[wi], lo0); atomicOr(&pl[PW + wi], lo1); atomicOr(&pl[2 * PW + wi], lo2);   // edge words are shared with the neighbours
+        lo0 = hi0; lo1 = hi1; lo2 = hi2; hi0 = 0; hi1 = 0; hi2 = 0; fill -= 32; wi++;
+      };
       auto append = [&](u32 sym, u32 take)                      // 1 <= take <= 32, fill < 32
       {
-        const u64 v = ((1ull << take) - 1ull) << fill;
-        acc0 |= (sym & 1 ? v : 0ull); acc1 |= (sym & 2 ? v : 0ull); acc2 |= (sym & 4 ? v : 0ull);
+        const u32 mask = (take >= 32 ? ~0u : (1u << take) - 1u);
+        const u32 mlo = mask << fill, mhi = (mask >> 1) >> (31 - fill);
+        const u32 s0 = 0u - (sym & 1u), s1 = 0u - ((sym >> 1) & 1u), s2 = 0u - ((sym >> 2) & 1u);
+        lo0 |= s0 & mlo; lo1 |= s1 & mlo; lo2 |= s2 & mlo;
+        hi0 |= s0 & mhi; hi1 |= s1 & mhi; hi2 |= s2 & mhi;
         fill += take;
-        if(fill >= 32)
-        {
-          atomicOr(&pl[wi], (u32)acc0); atomicOr(&pl[PW + wi], (u32)acc1); atomicOr(&pl[2 * PW + wi], (u32)acc2);   // edge words are shared with the neighbours
-          acc0 >>= 32; acc1 >>= 32; acc2 >>= 32; fill -= 32; wi++;
-        }
+        if(fill >= 32) { flush(); }
       };
-      for_each_run<false>(rows + lane * STAGE_WORDS, valid,
-        [&](u32 sym, u32 l) { append(sym, (l < 32 ? l : 32u)); if(l > 32) { append(sym, l - 32); } },
-        [&](u32 sym, u64 len)
+      auto on_long = [&](u32 sym, u64 len)
+      {
+        u32 l = (u32)len;
+        if(FILL)
         {
-          u32 l = (u32)len;
-          if(FILL)
+          if(fill != 0) { const u32 take = (l < 32 - fill ? l : 32 - fill); append(sym, take); l -= take; }   // completes the current word
+          if(l >= 128)                                          // fill == 0 here: whole words follow
           {
-            if(fill != 0) { const u32 take = (l < 32 - fill ? l : 32 - fill); append(sym, take); l -= take; }   // completes the current word
-            if(l >= 128)                                          // fill == 0 here: whole words follow
-            {
-              const u32 nfull = l >> 5;
-              const u32 taken = (sym == 0 ? nfull : queue_fill(sym, wi, nfull));                     // endmarker runs leave the planes zero
-              wi += taken; l -= 32 * taken;
-            }
+            const u32 nfull = l >> 5;
+            const u32 taken = (sym == 0 ? nfull : queue_fill(sym, wi, nfull));                     // endmarker runs leave the planes zero
+            wi += taken; l -= 32 * taken;
           }
-          while(l > 0) { const u32 take = (l < 32 ? l : 32u); append(sym, take); l -= take; }
-        });
-      if(fill > 0 && wi < BR_WINDOW / 32) { atomicOr(&pl[wi], (u32)acc0); atomicOr(&pl[PW + wi], (u32)acc1); atomicOr(&pl[2 * PW + wi], (u32)acc2); }
+        }
+        while(l > 0) { const u32 take = (l < 32 ? l : 32u); append(sym, take); l -= take; }
+      };
+      const u32* row = rows + lane * STAGE_WORDS;
+      u32 rsym = 0, rshift = 0; u64 rlen = 0; bool cont = false;
+#pragma unroll 1
+      for(int w = 0; w < 16; w++)
+      {
+        const u32 word = row[w];
+        // bytes >= 186 (runs of 32 and more, heads of runs with a varint extension): high bit set and low 7 bits >= 0x3A
+        const u32 big = ((word & 0x7F7F7F7Fu) + 0x46464646u) & word & 0x80808080u;
+        if(!cont && big == 0)
+        {
+          // four one-byte runs of 1 .. 31: straight-line, no per-byte checks
+#pragma unroll
+          for(int k = 0; k < 4; k++)
+          {
+            const u32 byte = (word >> (8 * k)) & 0xFF;
+            const u32 q = (byte * 171u) >> 10;                           // byte / 6, exact for byte < 256
+            const u32 sym = byte - 6 * q, len = q + 1;
+            const u32 mask = (1u << len) - 1u;
+            const u32 mlo = mask << fill, mhi = (mask >> 1) >> (31 - fill);
+            const u32 s0 = 0u - (sym & 1u), s1 = 0u - ((sym >> 1) & 1u), s2 = 0u - ((sym >> 2) & 1u);
+            lo0 |= s0 & mlo; lo1 |= s1 & mlo; lo2 |= s2 & mlo;
+            hi0 |= s0 & mhi; hi1 |= s1 & mhi; hi2 |= s2 & mhi;
+            fill += len;
+            if(fill >= 32) { flush(); }
+          }
+          continue;
+        }
+#pragma unroll
+        for(int k = 0; k < 4; k++)
+        {
+          const u32 byte = (word >> (8 * k)) & 0xFF;
+          if(cont)
+          {
+            rlen += (u64)(byte & 0x7F) << rshift; rshift += 7; cont = (byte & 0x80) != 0;
+            if(!cont) { on_long(rsym, rlen); }
+          }
+          else
+          {
+            const u32 q = (byte * 171u) >> 10; rsym = byte - 6 * q;
+            if(q + 1 >= MAX_RUN) { rlen = q + 1; rshift = 0; cont = true; }
+            else { const u32 l = q + 1; append(rsym, (l < 32 ? l : 32u)); if(l > 32) { append(rsym, l - 32); } }
+          }
+        }
+      }
+      if(fill > 0 && wi < BR_WINDOW / 32) { atomicOr(&pl[wi], lo0); atomicOr(&pl[PW + wi], lo1); atomicOr(&pl[2 * PW + wi], lo2); }
     }
     else if(have && bstart < we && bend > ws)
     {
