@@ -25,7 +25,7 @@
 // of ranks.
 
 constexpr int FR_BLOCK = 256;                  // elements (= threads) per block
-constexpr int FR_SEGS = 31;                    // segment-table entries staged per block
+constexpr int FR_SEGS = 31;                    // segment-table entries staged per block (a power of two minus one: k_frontier_step searches them in five steps)
 
 struct FrontierView
 {
@@ -124,8 +124,12 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
   if(active)
   {
     u64 phys;
+    // the staged entry that holds g: the largest k with s_prefix[k] <= g (empty segments repeat their neighbour's prefix).  Five
+    // steps of a binary search: the linear walk was unrolled by the compiler into 31 compare-select steps on 64-bit values,
+    // ~190 of the kernel's ~470 VALU instructions per wave.
     u32 k = 0;
-    while(k < (u32)FR_SEGS && s_prefix[k + 1] <= g) { k++; }       // skips empty segments
+#pragma unroll
+    for(u32 step = 16; step != 0; step >>= 1) { if(s_prefix[k + step] <= g) { k += step; } }     // k + step <= 31 = FR_SEGS: inside the FR_SEGS + 1 staged entries
     if(k < (u32)FR_SEGS) { phys = s_phys[k] + (g - s_prefix[k]); }
     else
     {
@@ -143,6 +147,7 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
       phys = f.seg_phys[sgm] + (g - f.seg_prefix[sgm]);
     }
     uint2 l = f.lo[phys]; u32 h = (HI ? (u32)f.hi[phys] : 0u);
+    __builtin_amdgcn_sched_barrier(0);      // both loads are issued before either is used (the scheduler otherwise waits for the high bytes before it issues the other load: one more round trip per wave)
     i = (u64)l.x | ((u64)(h & 0xFF) << 32);
     r = (u64)l.y | ((u64)(h >> 8) << 32);
   }
@@ -227,8 +232,13 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  if(EMIT == 0 && lane == 0 && active && (wave == 0 || wave_cnt[wave - 1][0] != tile_first)) { atomicMin(&f.bound_row[tile_first], (u32)g); }
+  // lane 0's tile marker is issued last: an atomic here would make the wave wait for it (vmcnt(0)) as soon as a register it reads is reused below
+  const bool mark_first = (EMIT == 0 && lane == 0 && active && (wave == 0 || wave_cnt[wave - 1][0] != tile_first));
+  // Positions inside the block: totals per class (all waves read the same LDS words), then the element's own store first;
+  // the segment entries of the block are written by five lanes of wave 0 afterwards, behind a wave-uniform branch, so that the
+  // other waves retire without passing any store inside divergent control flow (where the compiler waits for vmcnt(0)).
   u32 class_base = 0, before_waves = 0;
+  u32 tot_k[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
   for(u32 k = 1; k < 6; k++)
   {
@@ -236,21 +246,28 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
     for(u32 w2 = 0; w2 < FR_BLOCK / WAVE; w2++) { u32 v = wave_cnt[w2][k]; if(w2 < wave) { bw += v; } tot += v; }
     if(k < c) { class_base += tot; }
     if(k == c) { before_waves = bw; }
-    if(threadIdx.x == k - 1)
-    {
-      u32 base_k = 0;
-      for(u32 k2 = 1; k2 < k; k2++) { for(u32 w2 = 0; w2 < FR_BLOCK / WAVE; w2++) { base_k += wave_cnt[w2][k2]; } }
-      f.seg_len_next[(u64)(k - 1) * f.nb_max + blockIdx.x] = tot;
-      f.seg_phys_next[(u64)(k - 1) * f.nb_max + blockIdx.x] = g0 + base_k;
-    }
+    tot_k[k] = tot;
   }
-  if(blockIdx.x == 0 && threadIdx.x == 5) { f.seg_len_next[nseg] = 0; }
   if(active && c != 0)
   {
     u64 dst = g0 + class_base + before_waves + my_rank;
     f.lo_next[dst] = make_uint2((u32)ni, (u32)nr);
     if(HI) { f.hi_next[dst] = (unsigned short)(((ni >> 32) & 0xFF) | (((nr >> 32) & 0xFF) << 8)); }
   }
+  if(wave == 0)
+  {
+    const u32 kk = threadIdx.x + 1;                                   // class of lanes 0 .. 4
+    u32 tot = 0, base_k = 0;
+#pragma unroll
+    for(u32 k = 1; k < 6; k++) { if(k == kk) { tot = tot_k[k]; } if(k < kk) { base_k += tot_k[k]; } }
+    if(kk < 6)
+    {
+      f.seg_len_next[(u64)(kk - 1) * f.nb_max + blockIdx.x] = tot;
+      f.seg_phys_next[(u64)(kk - 1) * f.nb_max + blockIdx.x] = g0 + base_k;
+    }
+    if(blockIdx.x == 0 && threadIdx.x == 5) { f.seg_len_next[nseg] = 0; }
+  }
+  if(mark_first) { atomicMin(&f.bound_row[tile_first], (u32)g); }
 }
 
 // Per-step bookkeeping.  first_seg[b] = the segment that holds logical element b * FR_BLOCK: a segment
