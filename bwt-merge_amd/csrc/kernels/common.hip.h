@@ -142,8 +142,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_scan_reduce(const u64* in, u6
   __shared__ u64 lds[BLOCK_THREADS / WAVE];
   in += (u64)blockIdx.y * stride; partial += (u64)blockIdx.y * partial_stride;
   u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+  // unconditional loads from clamped indexes (a predicated load becomes a branch and the compiler then waits for every load
+  // before it issues the next one: eight memory round trips in a row in a kernel that is launched once per LF step)
+  u64 item[SCAN_ITEMS];
+#pragma unroll
+  for(int k = 0; k < SCAN_ITEMS; k++) { item[k] = in[base + k < n ? base + k : n - 1]; }
   u64 acc = 0;
-  for(int k = 0; k < SCAN_ITEMS; k++) { if(base + k < n) { acc = scan_op<OP>(acc, in[base + k]); } }
+#pragma unroll
+  for(int k = 0; k < SCAN_ITEMS; k++) { if(base + k < n) { acc = scan_op<OP>(acc, item[k]); } }
   u64 total = block_reduce<OP>(acc, lds);
   if(threadIdx.x == 0) { partial[blockIdx.x] = total; }
 }
@@ -158,9 +164,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_scan_apply(const u64* in, u64
   u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
   u64 item[SCAN_ITEMS];
   u64 acc = 0;
+#pragma unroll
+  for(int k = 0; k < SCAN_ITEMS; k++) { item[k] = in[base + k < n ? base + k : n - 1]; }          // see k_scan_reduce
+#pragma unroll
   for(int k = 0; k < SCAN_ITEMS; k++)
   {
-    item[k] = (base + k < n ? in[base + k] : 0);
+    if(base + k >= n) { item[k] = 0; }
     acc = scan_op<OP>(acc, item[k]);
   }
   u64 incl = (OP == 0 ? wave_incl_sum(acc) : wave_incl_max(acc));

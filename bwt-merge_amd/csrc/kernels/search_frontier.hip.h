@@ -301,7 +301,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_scan(const u64* seg_
   const u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
   u64 item[SCAN_ITEMS];
   u64 acc = 0;
-  for(int k = 0; k < SCAN_ITEMS; k++) { item[k] = (base + k < n ? seg_len[base + k] : 0); acc += item[k]; }
+#pragma unroll
+  for(int k = 0; k < SCAN_ITEMS; k++) { item[k] = seg_len[base + k < n ? base + k : n - 1]; }      // unconditional: see k_scan_reduce
+#pragma unroll
+  for(int k = 0; k < SCAN_ITEMS; k++) { if(base + k >= n) { item[k] = 0; } acc += item[k]; }
   const u64 incl = wave_incl_sum(acc);
   const u64 wave_total = shfl_u64(incl, WAVE - 1);
   u64 excl = shfl_up_u64(incl, 1);
