@@ -135,14 +135,31 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_interleave_sup(IndexView A, I
 // the 32-bit windows at its two cursors from there.
 constexpr u32 IL_WORDS = 2 * CHUNK_WORDS + 8;            // 264 staged words per plane
 
-__device__ inline void stage_planes(const IndexView& x, u64 first_word, u32 (*planes)[IL_WORDS])
+// The staged words of one source: every thread takes word t and (threads 0 .. 7 really, the others re-read the last one) word
+// 256 + t.  The loads are unconditional, from clamped indexes, and issued for BOTH sources before anything is written to LDS:
+// written as a loop with a predicated load per source, the compiler put a full wait after each of them -- three memory round
+// trips in a row at the start of every workgroup.
+struct StagedLoad { uint4 v0, v1; bool z0, z1; };
+
+__device__ inline StagedLoad stage_issue(const IndexView& x, u64 first_word)
 {
-  const u64 last = 4 * x.nrecs;
-  for(u32 k = threadIdx.x; k < IL_WORDS; k += BLOCK_THREADS)
+  const u64 last = 4 * x.nrecs;                                       // > 0: an index has at least one record
+  const u32 k1 = (threadIdx.x + BLOCK_THREADS < IL_WORDS ? threadIdx.x + BLOCK_THREADS : IL_WORDS - 1);
+  const u64 w0 = first_word + threadIdx.x, w1 = first_word + k1;
+  StagedLoad s;
+  s.z0 = (w0 >= last); s.z1 = (w1 >= last);
+  s.v0 = x.recs[s.z0 ? last - 1 : w0];
+  s.v1 = x.recs[s.z1 ? last - 1 : w1];
+  return s;
+}
+
+__device__ inline void stage_store(const StagedLoad& s, u32 (*planes)[IL_WORDS])
+{
+  const u32 t = threadIdx.x;
+  planes[0][t] = (s.z0 ? 0u : s.v0.x); planes[1][t] = (s.z0 ? 0u : s.v0.y); planes[2][t] = (s.z0 ? 0u : s.v0.z);
+  if(t + BLOCK_THREADS < IL_WORDS)
   {
-    const u64 wi = first_word + k;
-    const uint4 v = (wi < last ? x.recs[wi] : make_uint4(0, 0, 0, 0));
-    planes[0][k] = v.x; planes[1][k] = v.y; planes[2][k] = v.z;
+    planes[0][t + BLOCK_THREADS] = (s.z1 ? 0u : s.v1.x); planes[1][t + BLOCK_THREADS] = (s.z1 ? 0u : s.v1.y); planes[2][t + BLOCK_THREADS] = (s.z1 ? 0u : s.v1.z);
   }
 }
 
@@ -170,7 +187,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_interleave(IndexView A, Index
   const u64 b_chunk = chunk_base[chunk];
   const u64 a_chunk = (chunk << (REC_SHIFT + 6)) - b_chunk;
   const u64 wa0 = a_chunk >> 5, wb0 = b_chunk >> 5;
-  stage_planes(A, wa0, planes_a); stage_planes(B, wb0, planes_b);
+  const StagedLoad sa = stage_issue(A, wa0), sb = stage_issue(B, wb0);
+  __builtin_amdgcn_sched_barrier(0);                              // all four loads leave before the first LDS write
+  stage_store(sa, planes_a); stage_store(sb, planes_b);
   if(t == 0)
   {
     u64 ra[6], rb[6];
