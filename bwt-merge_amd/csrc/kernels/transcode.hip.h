@@ -33,29 +33,39 @@ __device__ inline void wave_sync_lds()
 
 // Stages blocks [first, first + count), count <= 64, into rows of STAGE_WORDS words (coalesced 16-byte loads).
 // Bytes past the end of the stream are staged as zeros (= runs of one endmarker, which deposit no bits).
+// The four loads of a lane are unconditional (from clamped chunk indexes) and leave together; with a predicate per load the
+// compiler waited for each before it issued the next: four memory round trips in a row at the start of every wave.
 __device__ inline void stage_blocks(const u8* data, u64 nbytes, u64 first, u32 count, u32* rows)
 {
   const u32 lane = lane_id();
   const uint4* src = (const uint4*)(data + first * RLE_BLOCK);
-  const u64 left = nbytes - first * RLE_BLOCK;                        // bytes of the stream from `first` on
+  const u64 left = nbytes - first * RLE_BLOCK;                        // bytes of the stream from `first` on (> 0: the caller has blocks)
   const u64 chunks_avail = (left + 15) / 16;                          // the buffer is readable up to the next multiple of 16
+  uint4 v[4];
 #pragma unroll
   for(int k = 0; k < 4; k++)
   {
-    u32 g = (u32)k * 64 + lane;
+    const u64 g = (u64)k * 64 + lane;
+    v[k] = src[g < chunks_avail ? g : chunks_avail - 1];
+  }
+#pragma unroll
+  for(int k = 0; k < 4; k++)
+  {
+    const u32 g = (u32)k * 64 + lane;
     if(g < 4 * count)
     {
-      uint4 v = (g < chunks_avail ? src[g] : make_uint4(0, 0, 0, 0));
-      if((u64)16 * g + 16 > left && g < chunks_avail)                 // the chunk that holds the last byte
+      uint4 x = v[k];
+      if(g >= chunks_avail) { x = make_uint4(0, 0, 0, 0); }
+      else if((u64)16 * g + 16 > left)                                // the chunk that holds the last byte
       {
-        u32 keep = (u32)(left - (u64)16 * g);                          // 1..15 bytes
+        const u32 keep = (u32)(left - (u64)16 * g);                    // 1..15 bytes
         u32 m[4];
 #pragma unroll
         for(u32 j = 0; j < 4; j++) { m[j] = (keep >= 4 * j + 4 ? ~0u : (keep <= 4 * j ? 0u : (1u << (8 * (keep - 4 * j))) - 1u)); }
-        v.x &= m[0]; v.y &= m[1]; v.z &= m[2]; v.w &= m[3];
+        x.x &= m[0]; x.y &= m[1]; x.z &= m[2]; x.w &= m[3];
       }
       u32* dst = rows + (g >> 2) * STAGE_WORDS + (g & 3) * 4;
-      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+      dst[0] = x.x; dst[1] = x.y; dst[2] = x.z; dst[3] = x.w;
     }
   }
 }
