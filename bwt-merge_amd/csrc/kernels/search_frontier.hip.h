@@ -495,11 +495,19 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_tile_build_frontier(const uns
   if(seen && lane == 0) { any = 1; }
   __syncthreads();
   if(any == 0) { return; }
-  u64 w0 = T << (TILE_SHIFT - 6);
-  for(u32 k = threadIdx.x; k < (1u << (TILE_SHIFT - 6)); k += BLOCK_THREADS)
+  // the tile is ORed into the bitvector: the four words of a thread are read together (unconditionally, from clamped indexes)
+  // and then written -- as a loop of predicated read-modify-writes they were four memory round trips in a row
+  const u64 w0 = T << (TILE_SHIFT - 6);
+  constexpr u32 PER_THREAD = (1u << (TILE_SHIFT - 6)) / BLOCK_THREADS;
+  u64 old[PER_THREAD];
+#pragma unroll
+  for(u32 r = 0; r < PER_THREAD; r++) { const u64 w = w0 + threadIdx.x + r * BLOCK_THREADS; old[r] = bits[w < nwords ? w : nwords - 1]; }
+#pragma unroll
+  for(u32 r = 0; r < PER_THREAD; r++)
   {
-    u64 w = w0 + k;
-    u64 v = (u64)tile[2 * k] | ((u64)tile[2 * k + 1] << 32);
-    if(w < nwords && v != 0) { bits[w] |= v; }
+    const u32 k = threadIdx.x + r * BLOCK_THREADS;
+    const u64 w = w0 + k;
+    const u64 v = (u64)tile[2 * k] | ((u64)tile[2 * k + 1] << 32);
+    if(w < nwords && v != 0) { bits[w] = old[r] | v; }
   }
 }
