@@ -347,9 +347,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
         {
           u32 hh = (u32)(h >> (32 * half));
           const u32 q0 = (u32)(ti.p0 >> (32 * half)), q1 = (u32)(ti.p1 >> (32 * half)), q2 = (u32)(ti.p2 >> (32 * half));
-          while(hh)
+          auto event = [&](u32 bb)
           {
-            const u32 bb = (u32)__builtin_ctz(hh); hh &= hh - 1;
             const int bit = (int)bb + 32 * half;
             const u32 len1 = (u32)(bit - prev_bit - 1);                  // length - 1 <= 40
             open_prev = (idx == opens ? prev_bit : open_prev);
@@ -358,6 +357,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
             lds[idx++] = (u8)byte;
             run_sym = __builtin_amdgcn_ubfe(q0, bb, 1u) | (__builtin_amdgcn_ubfe(q1, bb, 1u) << 1) | (__builtin_amdgcn_ubfe(q2, bb, 1u) << 2);
             prev_bit = bit;
+          };
+          // two events per trip of the (divergent) loop
+          while(hh)
+          {
+            event((u32)__builtin_ctz(hh)); hh &= hh - 1;
+            if(hh) { event((u32)__builtin_ctz(hh)); hh &= hh - 1; }
           }
         }
         if(open_prev != NO_OPEN) { block_start[(off - a + opens) >> 6] = tb + (u64)(long long)open_prev; }
