@@ -61,6 +61,25 @@ __device__ inline u64 wave_incl_max(u64 v)
 }
 
 __device__ inline u64 wave_sum(u64 v)   { return shfl_u64(wave_incl_sum(v), WAVE - 1); }
+
+// Inclusive "last nonzero so far" over the wave for values that increase with the lane wherever they are nonzero (positions
+// of heads): lane L receives the value of the highest lane <= L that has one, 0 if none -- a ballot, a count of leading zeros
+// and ONE 64-bit shuffle instead of the six shuffle-and-max steps of a generic inclusive max scan.
+__device__ inline u64 wave_incl_last(u64 v)
+{
+  const u64 have = __ballot(v != 0) & ((2ull << lane_id()) - 1ull);        // lanes 0 .. L with a value
+  const int src = 63 - (int)__builtin_clzll(have | 1ull);
+  const u64 got = shfl_u64(v, src);
+  return (have != 0 ? got : 0ull);
+}
+
+// Sum over the wave of values that are usually small: when every lane's value is below 2^25 (wave-uniform test) the sum fits
+// 32 bits and takes the DPP scan (7 VALU instructions) instead of twelve ds_bpermute round trips for a 64-bit shuffle scan.
+__device__ inline u64 wave_sum_mostly_small(u64 v)
+{
+  if(__ballot((v >> 25) != 0) == 0) { return (u64)(u32)__builtin_amdgcn_readlane((int)wave_incl_sum32((u32)v), WAVE - 1); }
+  return wave_sum(v);
+}
 __device__ inline u64 wave_max(u64 v)   { return shfl_u64(wave_incl_max(v), WAVE - 1); }
 
 //------------------------------------------------------------------------------

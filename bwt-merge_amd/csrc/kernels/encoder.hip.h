@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_lasthead(const uint4* rec
     carry = chunk_tiles(recs, nrecs, ft, n, carry, ti);
     u64 T = ft + lane_id();
     u64 mine = (ti.H != 0 && T < ntiles ? (T << 6) + (63 - (u64)__builtin_clzll(ti.H)) + 1 : NONE);
-    u64 m = wave_max(mine);
+    u64 m = shfl_u64(wave_incl_last(mine), WAVE - 1);                // the last head of the chunk
     if(m > best) { best = m; }
   }
   if(lane_id() == 0) { lasthead[seg] = best; }
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_size(const uint4* recs, u
     u64 T = ft + lane_id();
     if(T >= ntiles) { ti.H = 0; ti.E = 0; }
     u64 lh = (ti.H != 0 ? (T << 6) + (63 - (u64)__builtin_clzll(ti.H)) + 1 : NONE);
-    u64 incl = wave_incl_max(lh);
+    u64 incl = wave_incl_last(lh);                                   // lh grows with the lane where it is set: the inclusive maximum is the last one so far
     u64 before = shfl_up_u64(incl, 1);
     if(lane_id() == 0) { before = NONE; }
     if(last > before) { before = last; }
@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
     u64 T = ft + lane_id();
     if(T >= ntiles) { ti.H = 0; ti.E = 0; }
     u64 lh = (ti.H != 0 ? (T << 6) + (63 - (u64)__builtin_clzll(ti.H)) + 1 : NONE);
-    u64 incl = wave_incl_max(lh);
+    u64 incl = wave_incl_last(lh);                                   // lh grows with the lane where it is set: the inclusive maximum is the last one so far
     u64 before = shfl_up_u64(incl, 1);
     if(lane_id() == 0) { before = NONE; }
     if(last > before) { before = last; }

@@ -197,7 +197,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_block_len(const u8* data, u64
     blen[b] = total;
     if(total < RLE_BLOCK && b + 1 < nblocks) { atomicOr(flags, 1u); }
   }
-  u64 t0 = wave_sum(l0), t1 = wave_sum(l1), t2 = wave_sum(l2), t3 = wave_sum(l3), t4 = wave_sum(l4), t5 = wave_sum(l5);
+  // per-lane counts are at most 64 x 41 unless the block holds a long run: the DPP path almost always
+  u64 t0 = wave_sum_mostly_small(l0), t1 = wave_sum_mostly_small(l1), t2 = wave_sum_mostly_small(l2), t3 = wave_sum_mostly_small(l3), t4 = wave_sum_mostly_small(l4), t5 = wave_sum_mostly_small(l5);
   if(lane == 0)
   {
     gcount[0 * gstride + g] = t0; gcount[1 * gstride + g] = t1; gcount[2 * gstride + g] = t2;
