@@ -90,6 +90,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_ingest_keys(const u64* packed
 }
 
 // hist[d * ntiles + t] = number of keys of tile t whose digit (bits [shift, shift + 8)) is d.
+// The keys of ING_BATCH rounds are loaded together, unconditionally (clamped index): a predicated load per round made every
+// round a full memory round trip (64 in a row per wave).
+constexpr int ING_BATCH = 8;
+
 __global__ void __launch_bounds__(WAVE) k_ingest_hist(const u64* keys, u64 n, u32 shift, u64 ntiles, u64* hist)
 {
   __shared__ u32 cnt[256];
@@ -98,10 +102,17 @@ __global__ void __launch_bounds__(WAVE) k_ingest_hist(const u64* keys, u64 n, u3
   for(u32 k = 0; k < 4; k++) { cnt[k * 64 + lane] = 0; }
   wave_sync_lds();
   const u64 base = (u64)blockIdx.x * ING_TILE;
-  for(int r = 0; r < ING_ROUNDS && base + (u64)r * WAVE < n; r++)
+  for(int r0 = 0; r0 < ING_ROUNDS && base + (u64)r0 * WAVE < n; r0 += ING_BATCH)
   {
-    const u64 i = base + (u64)r * WAVE + lane;
-    if(i < n) { atomicAdd(&cnt[(u32)(keys[i] >> shift) & 255u], 1u); }
+    u64 key[ING_BATCH];
+#pragma unroll
+    for(int j = 0; j < ING_BATCH; j++) { const u64 i = base + (u64)(r0 + j) * WAVE + lane; key[j] = keys[i < n ? i : n - 1]; }
+#pragma unroll
+    for(int j = 0; j < ING_BATCH; j++)
+    {
+      const u64 i = base + (u64)(r0 + j) * WAVE + lane;
+      if(i < n) { atomicAdd(&cnt[(u32)(key[j] >> shift) & 255u], 1u); }
+    }
   }
   wave_sync_lds();
 #pragma unroll
@@ -119,27 +130,38 @@ __global__ void __launch_bounds__(WAVE) k_ingest_scatter(const u64* keys_in, con
   wave_sync_lds();
   const u64 base = (u64)blockIdx.x * ING_TILE;
   const u64 below = (1ull << lane) - 1ull;
-  for(int r = 0; r < ING_ROUNDS && base + (u64)r * WAVE < n; r++)
+  for(int r0 = 0; r0 < ING_ROUNDS && base + (u64)r0 * WAVE < n; r0 += ING_BATCH)
   {
-    const u64 i = base + (u64)r * WAVE + lane;
-    const bool valid = (i < n);
-    const u64 key = (valid ? keys_in[i] : 0ull);
-    const u32 id = (valid ? ids_in[i] : 0u);
-    const u32 d = (valid ? (u32)(key >> shift) & 255u : 256u);       // lanes past the end form a group of their own
-    u64 same = ~0ull;
+    u64 kbuf[ING_BATCH]; u32 ibuf[ING_BATCH];
 #pragma unroll
-    for(u32 b = 0; b < 9; b++)
+    for(int j = 0; j < ING_BATCH; j++)
     {
-      const bool bit = ((d >> b) & 1u) != 0;
-      const u64 bal = __ballot(bit);
-      same &= (bit ? bal : ~bal);
+      const u64 i = base + (u64)(r0 + j) * WAVE + lane;
+      const u64 ic = (i < n ? i : n - 1);
+      kbuf[j] = keys_in[ic]; ibuf[j] = ids_in[ic];
     }
-    const u32 rank = (u32)__popcll(same & below), total = (u32)__popcll(same);
-    const u32 slot = (valid ? next[d] + rank : 0u);
-    wave_sync_lds();                                                  // every lane has read its counter
-    if(valid && rank + 1 == total) { next[d] += total; }
-    wave_sync_lds();
-    if(valid) { keys_out[slot] = key; ids_out[slot] = id; }
+#pragma unroll
+    for(int j = 0; j < ING_BATCH; j++)
+    {
+      const u64 i = base + (u64)(r0 + j) * WAVE + lane;
+      const bool valid = (i < n);
+      const u64 key = kbuf[j];
+      const u32 d = (valid ? (u32)(key >> shift) & 255u : 256u);     // lanes past the end form a group of their own
+      u64 same = ~0ull;
+#pragma unroll
+      for(u32 b = 0; b < 9; b++)
+      {
+        const bool bit = ((d >> b) & 1u) != 0;
+        const u64 bal = __ballot(bit);
+        same &= (bit ? bal : ~bal);
+      }
+      const u32 rank = (u32)__popcll(same & below), total = (u32)__popcll(same);
+      const u32 slot = (valid ? next[d] + rank : 0u);
+      wave_sync_lds();                                                // every lane has read its counter
+      if(valid && rank + 1 == total) { next[d] += total; }
+      wave_sync_lds();
+      if(valid) { keys_out[slot] = key; ids_out[slot] = ibuf[j]; }
+    }
   }
 }
 
