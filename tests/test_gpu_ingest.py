@@ -145,3 +145,21 @@ def test_rejects_bad_input(gpu):
     e = gpu.Builder().finish()
     assert e.bases == 0 and e.sequences == 0
     e.free()
+
+
+def test_random_small_collections(gpu, oracle):
+    """Forty random shapes: widths around the 21-symbol key-word boundaries, ragged and uniform, leaves of every size, low and
+    full alphabets -- each against the oracle's brute-force BWT."""
+    rng = np.random.default_rng(20261003)
+    for case in range(40):
+        n = int(rng.integers(1, 160))
+        W = int(rng.choice([1, 2, 19, 20, 21, 22, 41, 42, 43, 63, 64, 65, 84, 85, 100, 127]))
+        sigma = int(rng.choice([1, 2, 4, 5]))
+        reads = (1 + rng.integers(0, sigma, size=(n, W))).astype(np.uint8)
+        lengths = None
+        if case % 2:
+            lengths = rng.integers(0, W + 1, size=n).astype(np.uint32)
+            for k in range(n):
+                reads[k, lengths[k]:] = 0
+        leaf = int(rng.choice([0, 1, 3, 17, 64]))
+        check_against_oracle(gpu, oracle, reads, lengths, leaf_reads=leaf, batches=int(rng.integers(1, 4)), device=bool(case % 3 == 0))
