@@ -221,6 +221,8 @@ def main():
     # `traffic_frac` say how busy the memory system actually is.
     roofline = {"bound": "hbm", "kernel": "k_" + dom + ("_binned" if dom == "lf_walk" else ""), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_basis": "algorithmic bytes (SURVEY 8(d): 160 B per LF step)",
+                "note": "the algorithmic count charges every LF step its own 160 bytes; in the sorted frontier neighbouring elements share 128-byte lines, so "
+                        "`frac` overstates the HBM utilisation and can pass 1.0 -- `traffic_GBs` / `traffic_frac` (PMC bytes / the same time) are the real figure",
                 "traffic": traffic, "traffic_source": traffic_source,
                 "traffic_GBs": (round(traffic_gbs, 1) if traffic_gbs else None), "traffic_frac": (round(traffic_gbs / HBM_PEAK_GBS, 4) if traffic_gbs else None),
                 "launches_per_step": round(launches_per_search, 2), "avg_launch_ms": round(avg_launch_s * 1e3, 4),
