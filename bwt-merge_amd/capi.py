@@ -107,6 +107,7 @@ SYMBOLS = [
     ("bwtm_builder_finish", C.c_int, [vp, C.POINTER(vp)]),
     ("bwtm_builder_free", None, [vp]),
     ("bwtm_profile_enable", C.c_int, [C.c_int]),
+    ("bwtm_profile_only", C.c_int, [C.c_char_p]),
     ("bwtm_profile_reset", C.c_int, []),
     ("bwtm_profile_read", C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), p_u64, C.c_int]),
 ]
@@ -672,6 +673,10 @@ class Builder:
 
 def profile_enable(on=True):
     check(lib().bwtm_profile_enable(1 if on else 0))
+
+
+def profile_only(name=None):
+    check(lib().bwtm_profile_only(name.encode() if name else None))
 
 
 def profile_reset():

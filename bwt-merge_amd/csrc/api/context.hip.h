@@ -44,6 +44,8 @@ struct bwtm_context
 
   // per-kernel profiling (bwtm_profile_*)
   bool profiling = false;
+  std::string profile_only;                // when not empty: only launches of this name are bracketed (bwtm_profile_only)
+  bool profile_open = false;               // the launch in progress is bracketed
   struct Pending { const char* name; hipEvent_t start, stop; };
   std::vector<Pending> pending;
   std::map<std::string, std::pair<double, uint64_t>> totals;
@@ -190,7 +192,8 @@ struct Scope
 
 void profile_begin(const char* name)
 {
-  if(!CTX.profiling) { return; }
+  CTX.profile_open = (CTX.profiling && (CTX.profile_only.empty() || CTX.profile_only.find(std::string(",") + name + ",") != std::string::npos));
+  if(!CTX.profile_open) { return; }
   bwtm_context::Pending p; p.name = name;
   (void)hipEventCreate(&p.start); (void)hipEventCreate(&p.stop);
   (void)hipEventRecord(p.start, CTX.stream);
@@ -199,7 +202,7 @@ void profile_begin(const char* name)
 
 void profile_end()
 {
-  if(!CTX.profiling) { return; }
+  if(!CTX.profile_open) { return; }
   (void)hipEventRecord(CTX.pending.back().stop, CTX.stream);
 }
 
@@ -654,6 +657,14 @@ extern "C" int bwtm_profile_enable(int on)
   ENTER(nullptr);
   profile_collect();
   CTX.profiling = (on != 0);
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_profile_only(const char* name)
+{
+  ENTER(nullptr);
+  profile_collect();
+  CTX.profile_only = (name && name[0] ? std::string(",") + name + "," : std::string());     // a comma-separated list of names
   return BWTM_OK;
 }
 

@@ -61,10 +61,26 @@ int alloc_native(DevBuf& buf, u64 nbytes)
   return BWTM_OK;
 }
 
-// Step 1.  Allocates the sample arrays and queues the first decode pass (k_block_len) over the stream.
-// With `host_src` the bytes are first copied into x->data in chunks on the copy stream, and the pass over chunk k runs on
-// the compute stream while chunk k + 1 is in flight.
-int upload_queue(bwtm_index* x, const u8* host_src)
+// Step 1.  Three parts, so that a caller can queue the copies of several inputs before any decode pass (bwtm_merge_host):
+//   upload_prepare   allocates the sample arrays
+//   upload_copies    (host sources only) copies the bytes into x->data in chunks on the copy stream, one event per chunk
+//   upload_decode    queues the first decode pass (k_block_len) chunk by chunk on the compute stream; the pass over chunk k waits
+//                    for chunk k's event only, so it runs while chunk k + 1 is in flight
+struct UploadEvents
+{
+  std::vector<hipEvent_t> ev;
+  UploadEvents() {}
+  UploadEvents(const UploadEvents&) = delete; UploadEvents& operator=(const UploadEvents&) = delete;
+  ~UploadEvents() { for(hipEvent_t e : ev) { (void)hipEventDestroy(e); } }
+};
+
+u64 upload_groups_per_chunk(const bwtm_index* x, bool from_host)
+{
+  const u64 group_bytes = (u64)GROUP * RLE_BLOCK;
+  return (from_host ? std::max<u64>(1, (u64)g_tune.upload_chunk / group_bytes) : x->ngroups);
+}
+
+int upload_prepare(bwtm_index* x)
 {
   x->nblocks = div_up(x->nbytes, RLE_BLOCK);
   x->ngroups = std::max<u64>(1, div_up(x->nblocks, (u64)GROUP));
@@ -77,34 +93,56 @@ int upload_queue(bwtm_index* x, const u8* host_src)
   HIP_TRY(hipMemsetAsync(x->block_start.as<u64>() + x->nblocks, 0, sizeof(u64), CTX.stream));
   // (plain 1-D calls: the 2-D memset / memcpy entry points of the runtime reject the pool's mapped blocks)
   for(u64 c = 0; c < 6; c++) { HIP_TRY(hipMemsetAsync(x->gcum.as<u64>() + c * gstride + x->ngroups, 0, sizeof(u64), CTX.stream)); }
+  return BWTM_OK;
+}
+
+// The caller has forked the copy stream (fork_copy_stream: x->data may be a recycled block with queued users).
+int upload_copies(bwtm_index* x, const u8* host_src, UploadEvents& events)
+{
   const u64 group_bytes = (u64)GROUP * RLE_BLOCK;
-  u64 groups_per_chunk = (host_src ? std::max<u64>(1, (u64)g_tune.upload_chunk / group_bytes) : x->ngroups);
-  if(host_src) { TRY(fork_copy_stream()); }           // x->data may be a recycled block with queued users
-  hipEvent_t ev = nullptr;
-  if(host_src) { HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); }
-  int rc = BWTM_OK;
-  for(u64 g0 = 0; g0 < x->ngroups && rc == BWTM_OK; g0 += groups_per_chunk)
+  const u64 groups_per_chunk = upload_groups_per_chunk(x, true);
+  for(u64 g0 = 0; g0 < x->ngroups; g0 += groups_per_chunk)
   {
     const u64 g1 = std::min(x->ngroups, g0 + groups_per_chunk);
-    if(host_src)
+    const u64 from = g0 * group_bytes, to = std::min(x->nbytes, g1 * group_bytes);
+    hipEvent_t ev = nullptr;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if(e == hipSuccess) { events.ev.push_back(ev); }
+    if(e == hipSuccess && to > from) { e = hipMemcpyAsync((u8*)x->data.p + from, host_src + from, to - from, hipMemcpyHostToDevice, CTX.copy_stream); }
+    if(e == hipSuccess) { e = hipEventRecord(ev, CTX.copy_stream); }
+    if(e != hipSuccess)
     {
-      const u64 from = g0 * group_bytes, to = std::min(x->nbytes, g1 * group_bytes);
-      hipError_t e = hipSuccess;
-      if(to > from) { e = hipMemcpyAsync((u8*)x->data.p + from, host_src + from, to - from, hipMemcpyHostToDevice, CTX.copy_stream); }
-      if(e == hipSuccess) { e = hipEventRecord(ev, CTX.copy_stream); }
-      if(e == hipSuccess) { e = hipStreamWaitEvent(CTX.stream, ev, 0); }
-      if(e != hipSuccess) { rc = fail(BWTM_ENODEV, "H2D copy failed: %s", hipGetErrorString(e)); break; }
+      (void)hipStreamSynchronize(CTX.copy_stream);                   // the caller's buffer must not be read after the call returns
+      return fail(BWTM_ENODEV, "H2D copy failed: %s", hipGetErrorString(e));
     }
-    auto launch = [&]() -> int
-    {
-      LAUNCH("block_len", k_block_len, div_up(g1 - g0, BLOCK_THREADS / WAVE), BLOCK_THREADS,
-        x->native_bytes(), x->nbytes, x->nblocks, g0, g1, x->block_start.as<u64>(), x->gcum.as<u64>(), gstride, x->flags.as<u32>());
-      return BWTM_OK;
-    };
-    rc = launch();
   }
-  if(ev) { (void)hipEventDestroy(ev); }
-  if(rc != BWTM_OK && host_src) { (void)hipStreamSynchronize(CTX.copy_stream); }     // the caller's buffer must not be read after the call returns
+  return BWTM_OK;
+}
+
+int upload_decode(bwtm_index* x, const UploadEvents* events)
+{
+  const u64 gstride = x->ngroups + 1;
+  const u64 groups_per_chunk = upload_groups_per_chunk(x, events != nullptr);
+  u64 chunk = 0;
+  for(u64 g0 = 0; g0 < x->ngroups; g0 += groups_per_chunk, chunk++)
+  {
+    const u64 g1 = std::min(x->ngroups, g0 + groups_per_chunk);
+    if(events) { HIP_TRY(hipStreamWaitEvent(CTX.stream, events->ev[chunk], 0)); }
+    LAUNCH("block_len", k_block_len, div_up(g1 - g0, BLOCK_THREADS / WAVE), BLOCK_THREADS,
+      x->native_bytes(), x->nbytes, x->nblocks, g0, g1, x->block_start.as<u64>(), x->gcum.as<u64>(), gstride, x->flags.as<u32>());
+  }
+  return BWTM_OK;
+}
+
+int upload_queue(bwtm_index* x, const u8* host_src)
+{
+  TRY(upload_prepare(x));
+  if(!host_src) { return upload_decode(x, nullptr); }
+  UploadEvents events;
+  TRY(fork_copy_stream());
+  TRY(upload_copies(x, host_src, events));
+  int rc = upload_decode(x, &events);
+  if(rc != BWTM_OK) { (void)hipStreamSynchronize(CTX.copy_stream); }
   return rc;
 }
 

@@ -74,17 +74,6 @@ double now_ms()
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// Native bytes of a host input -> device index without its native form, queued without a synchronisation:
-// chunked H2D + first decode pass, scans, transcode.  The header is validated later (upload_validate).
-int host_input_queue(const bwtm_host_input* in, u32 slot, bwtm_index* x)
-{
-  x->ctx = t_ctx; x->nbytes = in->nbytes; x->n = in->bases; x->m = in->sequences;
-  TRY(alloc_native(x->data, in->nbytes));
-  TRY(upload_queue(x, (in->nbytes > 0 ? in->data : nullptr)));
-  TRY(upload_scan(x, slot));
-  return BWTM_OK;
-}
-
 int merge_host_impl(bwtm_index* a_dev, const bwtm_host_input* a_host, const bwtm_host_input* b_host, bwtm_alloc_fn alloc, void* user,
   int want_samples, bwtm_host_output* out, bwtm_index** keep)
 {
@@ -94,17 +83,41 @@ int merge_host_impl(bwtm_index* a_dev, const bwtm_host_input* a_host, const bwtm
   bwtm_index* x = nullptr;
   auto body = [&]() -> int
   {
-    // b first: its scans and transcode run on the compute stream while a's bytes are still arriving on the copy stream.
-    TRY(host_input_queue(b_host, 8, b));
-    TRY(transcode(b));
+    // The copies of both inputs are queued first (copy stream: b's chunks, then a's).  b's decode pass and scans run on the compute
+    // stream while b's later chunks arrive; the host then waits for b's scan results only -- a's bytes are still on the link --
+    // VALIDATES b's header against the stream, and only then queues b's transcode, which sizes its output from the header
+    // (a wrong `bases` or a non-canonical stream must never reach k_build_recs).  a follows the same way.
+    UploadEvents ev_a, ev_b;
+    b->ctx = t_ctx; b->nbytes = b_host->nbytes; b->n = b_host->bases; b->m = b_host->sequences;
+    TRY(alloc_native(b->data, b_host->nbytes));
+    TRY(upload_prepare(b));
     if(a_host)
     {
       a = new bwtm_index();
-      TRY(host_input_queue(a_host, 16, a));
+      a->ctx = t_ctx; a->nbytes = a_host->nbytes; a->n = a_host->bases; a->m = a_host->sequences;
+      TRY(alloc_native(a->data, a_host->nbytes));
+      TRY(upload_prepare(a));
+    }
+    TRY(fork_copy_stream());                                        // recycled blocks may have queued users on the compute stream
+    TRY(upload_copies(b, (b_host->nbytes > 0 ? b_host->data : (const u8*)""), ev_b));
+    if(a_host) { TRY(upload_copies(a, (a_host->nbytes > 0 ? a_host->data : (const u8*)""), ev_a)); }
+    TRY(upload_decode(b, &ev_b));
+    TRY(upload_scan(b, 8));
+    hipEvent_t b_scanned = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&b_scanned, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(b_scanned, CTX.stream);
+    if(e == hipSuccess) { e = hipEventSynchronize(b_scanned); }
+    (void)hipEventDestroy(b_scanned);
+    if(e != hipSuccess) { return fail(BWTM_ENODEV, "upload failed: %s", hipGetErrorString(e)); }
+    TRY(upload_validate(b, b_host->sequences, b_host->bases, b_host->C, 8));
+    TRY(transcode(b));
+    if(a_host)
+    {
+      TRY(upload_decode(a, &ev_a));
+      TRY(upload_scan(a, 16));
     }
     HIP_TRY(hipStreamSynchronize(CTX.copy_stream));
     HIP_TRY(hipStreamSynchronize(CTX.stream));
-    TRY(upload_validate(b, b_host->sequences, b_host->bases, b_host->C, 8));
     if(a_host)
     {
       TRY(upload_validate(a, a_host->sequences, a_host->bases, a_host->C, 16));

@@ -106,7 +106,21 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
     gpuCheck(bwtm_index_drop_native(B), "mergeMultiGPU()");
     if(g == 0) { local.upload = readTimer() - t0; }
 
-    gpuCheck(bwtm_ra_create(A, B, &ra), "mergeMultiGPU()");
+    // Across devices the bitvector is handed to ncclAllReduce, which (all ranks in one process) may let a peer GPU read or write the
+    // buffer directly: the library's pooled blocks are mapped for their own device only, so this buffer comes from hipMalloc.
+    void* shared_bits = nullptr;
+    if(distinct && G > 1)
+    {
+#ifdef BWTM_WITH_RCCL
+      const uint64_t need = bwtm_ra_buffer_bytes(A, B);
+      if(hipSetDevice(devices[g]) != hipSuccess || hipMalloc(&shared_bits, need) != hipSuccess || hipMemset(shared_bits, 0, need) != hipSuccess)
+      {
+        std::cerr << "mergeMultiGPU(): cannot allocate the rank-array bitvector" << std::endl; std::exit(EXIT_FAILURE);
+      }
+      gpuCheck(bwtm_ra_create_on(A, B, shared_bits, need, &ra), "mergeMultiGPU()");
+#endif
+    }
+    else { gpuCheck(bwtm_ra_create(A, B, &ra), "mergeMultiGPU()"); }
     if(g < blocks.size()) { gpuCheck(bwtm_search(A, B, blocks[g].first, blocks[g].second, ra), "mergeMultiGPU()"); }
     gpuCheck(bwtm_ra_device_buffer(ra, &bits[g], &bits_bytes[g]), "mergeMultiGPU()");      // synchronizes: the search is done
     if(g == 0) { local.search = readTimer() - t0 - local.upload; }
@@ -146,6 +160,9 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
     gpuCheck(bwtm_slice_bounds(bwtm_merged_records(A, B), (int)G, (int)g, &rec_first, &rec_last), "mergeMultiGPU()");
     gpuCheck(bwtm_interleave_range(A, B, ra, rec_first, rec_last, &slice), "mergeMultiGPU()");
     bwtm_ra_free(ra); bwtm_index_free(A); bwtm_index_free(B);
+#ifdef BWTM_WITH_RCCL
+    if(shared_bits) { (void)hipFree(shared_bits); }
+#endif
     gpuCheck(bwtm_slice_lasthead(slice, &heads[g]), "mergeMultiGPU()");
     barrier.wait();
     uint64_t before = 0;

@@ -300,6 +300,10 @@ void bwtm_builder_free(bwtm_builder* builder);
 
 /* When enabled, every kernel launch is bracketed by HIP events on the context's compute stream. */
 int bwtm_profile_enable(int on);
+/* Restricts the bracketing to launches of the named kernels (a comma-separated list of the names bwtm_profile_read reports,
+   e.g. "frontier_step,lf_walk"); NULL or "" = all kernels.  Two event records per launch cost a few microseconds each on the stream: a timed region that only needs the
+   dominant kernel's durations brackets only that kernel. */
+int bwtm_profile_only(const char* name);
 int bwtm_profile_reset(void);
 /* Per-kernel totals since the last reset: returns the number of distinct kernels; fills up to
    `capacity` entries.  names[k] points to a static string. */

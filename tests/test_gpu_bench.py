@@ -52,3 +52,26 @@ def test_bench_chained_merge_of_four_sets(bwtm):
     assert d["verified"] is True and len(d["config"]["bases"]) == 4 and d["host_to_host"] is None
     n = d["config"]["bases"][0]
     assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] * 1e6 - 9 * n) < 0.01 * 9 * n      # (2 + 3 + 4) n bases pass through the merges
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()                 # does not initialise the GPU in this process
+
+
+def test_bench_two_gpus_self_launched(bwtm):
+    """`python bench.py --gpus 2` without a launcher: bench.py starts the two ranks itself (before any GPU call), RCCL reports two
+    ranks, every rank's output slice equals the same bytes of the single-GPU stream.  Runs wherever two GPUs are visible."""
+    if _gpus() < 2:
+        pytest.skip("needs two GPUs")
+    d = run_bench([sys.executable, "bench.py", "--gpus", "2", "--reads", "4000000", "--steps", "2", "--warmup", "1"])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["verified"] is True and d["value"] > 0
+    assert d["verification"]["slices"] == 2 and d["cpu_baseline"] is None and d["host_to_host"] is None
+
+
+def test_bench_self_launch_reports_a_failing_rank(bwtm):
+    """The self-launcher must not print a line or exit 0 when a rank dies: --gpus larger than the number of devices."""
+    n = _gpus() + 1
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--reads", "100000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-host"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]

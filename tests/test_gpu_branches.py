@@ -199,6 +199,23 @@ def test_host_to_host_merge(gpu, oracle, chunks):
         # a header that does not match the stream is refused after the pipeline has drained
         with pytest.raises(gpu.BwtmError, match="header says"):
             gpu.merge_host((pinned[0].array, fm[0].sequences + 1, fm[0].bases), (pinned[1].array, fm[1].sequences, fm[1].bases))
+        # ... and so is a header that UNDERSTATES the bases of input2: its transcode sizes the record array from the header, so the
+        # header must be checked against the stream before that kernel is queued (it used to run first)
+        for wrong in (fm[1].bases // 2, 128, fm[1].bases + 4096):
+            with pytest.raises(gpu.BwtmError, match="header says"):
+                gpu.merge_host((pinned[0].array, fm[0].sequences, fm[0].bases), (pinned[1].array, fm[1].sequences, wrong))
+        with pytest.raises(gpu.BwtmError, match="header says"):
+            gpu.merge_host((pinned[0].array, fm[0].sequences, fm[0].bases // 3), (pinned[1].array, fm[1].sequences, fm[1].bases))
+        # a stream that no Run::write produced (a full block of one-position runs of alternating symbols decodes to 64 positions: fine;
+        # extension bytes >= 0x80 forever: not canonical) is refused as well, whatever its header says
+        bad = gpu.HostBuffer(4096)
+        bad.array[:] = 0xFB                                   # run heads with basic length 42 whose extension never ends inside a block
+        with pytest.raises(gpu.BwtmError):
+            gpu.merge_host((pinned[0].array, fm[0].sequences, fm[0].bases), (bad.array, 1, 64))
+        bad.free()
+        r = gpu.merge_host((pinned[0].array, fm[0].sequences, fm[0].bases), (pinned[1].array, fm[1].sequences, fm[1].bases))
+        assert np.array_equal(r.data, m01.data)                 # the context is still healthy after the refused calls
+        r.free()
         # pageable inputs work too (slower copies)
         r = gpu.merge_host((fm[0].data, fm[0].sequences, fm[0].bases), (fm[1].data, fm[1].sequences, fm[1].bases))
         assert np.array_equal(r.data, m01.data)

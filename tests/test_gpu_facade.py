@@ -116,6 +116,29 @@ def test_cli_one_thread_per_gpu(bwtm, oracle, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_two_distinct_gpus(bwtm, oracle, tmp_path):
+    """bwt_merge -g 0,1: two host threads on two DEVICES, the rank-array shards combined by ncclAllReduce (the branch that
+    contexts of one GPU never take).  Runs wherever two GPUs are visible; the file must equal the single-GPU one."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    build_host()
+    sets = [oracle.generate_reads(4200 + k, 3000 + 500 * k, 100) for k in range(3)]
+    names = []
+    for k, t in enumerate(sets):
+        names.append(str(tmp_path / ("in%d.plain" % k)))
+        write_plain(names[-1], oracle.FMI.from_text(t))
+    exe = os.path.join(HOST, "bwt_merge")
+    outs = {}
+    for label, g in (("one", "0"), ("two", "0,1")):
+        out = subprocess.run([exe, "-g", g, "-i", "plain_default", names[0], names[1], names[2], str(tmp_path / (label + ".native"))],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        outs[label] = np.fromfile(tmp_path / (label + ".native"), dtype=np.uint8)
+    assert np.array_equal(outs["one"], outs["two"])
+
+
+@pytest.mark.gpu
 def test_cli_errors_like_reference(bwtm, tmp_path):
     build_host()
     exe = os.path.join(HOST, "bwt_merge")
