@@ -225,11 +225,88 @@ int frontier_flush(bwtm_ra* ra, DevBuf& emit16, u64 emit_cap, DevBuf& emit_base,
   return BWTM_OK;
 }
 
+// The first levels of the search on trie NODES (k_range_*, fmi.cpp:286-323 as it is written): level t is the sorted list of
+// (sp, count, r); a level is processed -- its runs of bits set, its children produced -- while it has at most `limit` nodes.
+// Returns with N = 0 when every chain has ended (the whole search was done on nodes: collections of repeated reads), otherwise
+// with the first level that was NOT processed in nodes[cur], to be expanded into frontier elements.
+struct RangeLevels
+{
+  DevBuf sp[2], r[2], cnt[2], flags, pieces, npieces;
+  u64 N = 0, alive = 0, levels = 0;
+  u32 piece_cap = 0;
+  int cur = 0;
+};
+
+int range_phase(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64 count, bwtm_ra* ra, u64 limit, RangeLevels& L)
+{
+  const u64 cap = std::min<u64>(5 * limit, count) + 1;              // a level's children: at most five per node, at most one per sequence
+  for(int k = 0; k < 2; k++) { TRY(L.sp[k].alloc(cap * sizeof(u64))); TRY(L.r[k].alloc(cap * sizeof(u64))); TRY(L.cnt[k].alloc(cap * sizeof(u64))); }
+  TRY(L.flags.alloc((5 * limit + 1) * sizeof(u64)));
+  L.piece_cap = (u32)std::min<u64>(count / 16 + 1024, 1ull << 24);
+  TRY(L.pieces.alloc((u64)L.piece_cap * sizeof(RangePiece)));
+  TRY(L.npieces.alloc(sizeof(u32), true));
+  LAUNCH("range_init", k_range_init, 1, BLOCK_THREADS, L.sp[0].as<u64>(), L.r[0].as<u64>(), L.cnt[0].as<u64>(), seq_first, count, a->m);
+  L.N = 1; L.alive = count; L.cur = 0; L.levels = 0;
+  while(L.N > 0 && L.N <= limit)
+  {
+    const int c = L.cur;
+    const u64 N = L.N, grid = div_up(N, BLOCK_THREADS);
+    LAUNCH("range_step", k_range_step<false>, grid, BLOCK_THREADS, a->view(), b->view(), L.sp[c].as<const u64>(), L.r[c].as<const u64>(), L.cnt[c].as<const u64>(), N,
+      L.flags.as<u64>(), (const u64*)nullptr, (u64*)nullptr, (u64*)nullptr, (u64*)nullptr, ra->bits_as<u32>(), L.pieces.as<RangePiece>(), L.npieces.as<u32>(), L.piece_cap);
+    LAUNCH("range_emit", k_range_emit, 2048, BLOCK_THREADS, L.pieces.as<const RangePiece>(), L.npieces.as<const u32>(), L.piece_cap, ra->bits_as<u32>());
+    HIP_TRY(hipMemsetAsync(L.npieces.p, 0, sizeof(u32), CTX.stream));
+    TRY(device_scan<0>(L.flags.as<u64>(), L.flags.as<u64>(), 5 * N + 1));
+    LAUNCH("range_children", k_range_step<true>, grid, BLOCK_THREADS, a->view(), b->view(), L.sp[c].as<const u64>(), L.r[c].as<const u64>(), L.cnt[c].as<const u64>(), N,
+      (u64*)nullptr, L.flags.as<const u64>(), L.sp[1 - c].as<u64>(), L.r[1 - c].as<u64>(), L.cnt[1 - c].as<u64>(), (u32*)nullptr, (RangePiece*)nullptr, (u32*)nullptr, 0u);
+    TRY(fetch_u64(L.flags.as<u64>() + 5 * N, 0));
+    HIP_TRY(hipStreamSynchronize(CTX.stream));
+    L.N = CTX.host_scratch[0];
+    L.cur = 1 - c; L.levels++;
+  }
+  return BWTM_OK;
+}
+
+// Level `L.cur` of the node phase -> frontier elements in lo / hi (sized by the caller from `alive`).
+int range_alive(RangeLevels& L, DevBuf& offsets)
+{
+  TRY(offsets.alloc((L.N + 1) * sizeof(u64)));
+  HIP_TRY(hipMemcpyAsync(offsets.p, L.cnt[L.cur].p, L.N * sizeof(u64), hipMemcpyDeviceToDevice, CTX.stream));
+  HIP_TRY(hipMemsetAsync(offsets.as<u64>() + L.N, 0, sizeof(u64), CTX.stream));
+  TRY(device_scan<0>(offsets.as<u64>(), offsets.as<u64>(), L.N + 1));
+  TRY(fetch_u64(offsets.as<u64>() + L.N, 0));
+  HIP_TRY(hipStreamSynchronize(CTX.stream));
+  L.alive = CTX.host_scratch[0];
+  return BWTM_OK;
+}
+
+int range_expand(RangeLevels& L, const DevBuf& offsets, uint2* lo, unsigned short* hi)
+{
+  const int c = L.cur;
+  LAUNCH("range_expand", k_range_expand, div_up(L.N, BLOCK_THREADS), BLOCK_THREADS, L.sp[c].as<const u64>(), L.r[c].as<const u64>(), L.cnt[c].as<const u64>(),
+    offsets.as<const u64>(), L.N, lo, hi, L.pieces.as<RangePiece>(), L.npieces.as<u32>(), L.piece_cap);
+  LAUNCH("range_expand_pieces", k_range_expand_pieces, 2048, BLOCK_THREADS, L.pieces.as<const RangePiece>(), L.npieces.as<const u32>(), L.piece_cap, lo, hi);
+  return BWTM_OK;
+}
+
 constexpr u64 FRONTIER_MIN_SEQUENCES = 1ull << 21;
 
 int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64 count, bwtm_ra* ra)
 {
   if(a->n >= (1ull << 40) || b->n >= (1ull << 40) || count >= (1ull << 32)) { return search_partitioned(a, b, seq_first, count, ra); }
+  // Node phase (range_ratio > 0): levels of at most count / range_ratio nodes are processed as trie nodes; `count` becomes the
+  // number of sequences still alive at the first level that is not.
+  RangeLevels levels;
+  DevBuf node_offsets;
+  const bool node_phase = (g_tune.range_ratio > 0);
+  if(node_phase)
+  {
+    const u64 limit = std::max<u64>(1, std::min<u64>(count / (u64)g_tune.range_ratio, 1ull << 24));
+    TRY(range_phase(a, b, seq_first, count, ra, limit, levels));
+    if(levels.N == 0) { return BWTM_OK; }
+    TRY(range_alive(levels, node_offsets));
+    count = levels.alive;
+    if(count == 0) { return BWTM_OK; }
+  }
   const u64 ntiles = div_up(ra->n_out + 1, 1ull << TILE_SHIFT);
   const u64 nb_max = div_up(count, FR_BLOCK);
   const u64 nseg = 5 * nb_max;
@@ -276,9 +353,17 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   TRY(bound.alloc(EPOCH * (ntiles + 1) * sizeof(u32)));
   HIP_TRY(hipMemsetAsync(bound.p, 0xFF, EPOCH * (ntiles + 1) * sizeof(u32), CTX.stream));
 
-  u64 init_items = (fcap > nseg + 1 ? fcap : nseg + 1);
-  LAUNCH("frontier_init", k_frontier_init, div_up(init_items, BLOCK_THREADS), BLOCK_THREADS, lo[0].as<uint2>(), hi[0].as<unsigned short>(),
-    seg_len[0].as<u64>(), seg_phys[0].as<u64>(), nb_max, seq_first, count, a->m);
+  if(node_phase)
+  {
+    TRY(range_expand(levels, node_offsets, lo[0].as<uint2>(), hi[0].as<unsigned short>()));
+    LAUNCH("frontier_init", k_frontier_init_tables, div_up(nseg + 1, BLOCK_THREADS), BLOCK_THREADS, seg_len[0].as<u64>(), seg_phys[0].as<u64>(), nb_max, count);
+  }
+  else
+  {
+    u64 init_items = (fcap > nseg + 1 ? fcap : nseg + 1);
+    LAUNCH("frontier_init", k_frontier_init, div_up(init_items, BLOCK_THREADS), BLOCK_THREADS, lo[0].as<uint2>(), hi[0].as<unsigned short>(),
+      seg_len[0].as<u64>(), seg_phys[0].as<u64>(), nb_max, seq_first, count, a->m);
+  }
   int cur = 0;
   u64 in_epoch = 0;
   u64 alive_bound = count, epoch_used = 0;                         // N_t <= alive_bound; emits reserved in this epoch so far

@@ -54,6 +54,7 @@ struct IndexView
 #include "kernels/diagnostics.hip.h"
 #endif
 #include "kernels/search_frontier.hip.h"
+#include "kernels/search_range.hip.h"
 #include "kernels/interleave.hip.h"
 #include "kernels/encoder.hip.h"
 #include "kernels/ingest.hip.h"

@@ -35,15 +35,15 @@ def upload(gpu, f):
     return gpu.Index.upload(f.data, f.sequences, f.bases)
 
 
-def search_runs(gpu, A, B, b, algo):
-    gpu.tune("search_algo", algo)
+def search_runs(gpu, A, B, b, algo, range_ratio=-1):
+    gpu.tune("search_algo", algo); gpu.tune("range_ratio", range_ratio)          # -1 = the default node phase
     gpu.profile_enable(True); gpu.profile_reset()
     ra = gpu.RankArray(A, B)
     ra.search(A, B, 0, b.sequences - 1)
     ra.finalize()
     prof = gpu.profile_read()
     gpu.profile_enable(False)
-    gpu.tune("search_algo", 0)
+    gpu.tune("search_algo", 0); gpu.tune("range_ratio", -1)
     assert ra.values == b.bases
     ranks, counts = ra.runs()
     ra.free()
@@ -60,10 +60,16 @@ def test_coordinates_beyond_32_bits(gpu, oracle):
     assert a.bases > (1 << 32) and b.bases > (1 << 32)
     oranks, ocounts, _ = oracle.search(a, b, capacity=1 << 21, threads=8)
     A, B = upload(gpu, a), upload(gpu, b)
-    for algo, kernel in ((2, "frontier_step"), (1, "lf_walk")):
-        ranks, counts, prof = search_runs(gpu, A, B, b, algo)
+    # the frontier search alone (one element per sequence), the node phase alone (every level of this collection has at most 4096
+    # trie nodes: fmi.cpp:304-322, the reference's own form), five levels of nodes expanded into 4.3e7 elements, and the walk
+    for algo, kernel, ratio, absent in ((2, "frontier_step", 0, "range_step"), (2, "range_step", -1, "frontier_step"), (2, "frontier_step", 71680, None),
+                                        (1, "lf_walk", -1, "range_step")):
+        ranks, counts, prof = search_runs(gpu, A, B, b, algo, ratio)
         assert prof.get(kernel, (0, 0))[1] > 0, (algo, sorted(prof))
-        assert np.array_equal(ranks, oranks) and np.array_equal(counts, ocounts), algo
+        assert absent is None or absent not in prof, (algo, ratio, sorted(prof))
+        if ratio == 71680:
+            assert prof["range_step"][1] == 5 and prof["range_expand"][1] == 1, prof
+        assert np.array_equal(ranks, oranks) and np.array_equal(counts, ocounts), (algo, ratio)
         assert int(ranks.max()) > (1 << 32)
     # the whole path at this size: bytes, C and samples of the oracle's merge
     M = gpu.merge(A, B)
@@ -84,8 +90,8 @@ def test_coordinates_beyond_32_bits(gpu, oracle):
     gpu.trim()
 
 
-@pytest.mark.parametrize("epoch,budget", [(0, 0), (64, 0), (7, 0), (0, 3000)])
-def test_frontier_epoch_rollover(gpu, oracle, epoch, budget):
+@pytest.mark.parametrize("epoch,budget,ratio", [(0, 0, 0), (64, 0, 0), (7, 0, 0), (0, 3000, 0), (7, 0, -1), (64, 0, 2)])
+def test_frontier_epoch_rollover(gpu, oracle, epoch, budget, ratio):
     """Sequences longer than an epoch of the frontier search (512 steps by default; fewer when the dense emits of an
     epoch would exceed the emit budget): tiles are built at every epoch boundary and the search goes on."""
     ta = oracle.generate_reads(61, 300, 400); tb = oracle.generate_reads(62, 250, 1300)
@@ -94,10 +100,10 @@ def test_frontier_epoch_rollover(gpu, oracle, epoch, budget):
     A, B = upload(gpu, a), upload(gpu, b)
     gpu.tune("frontier_epoch", epoch); gpu.tune("emit_budget", budget)
     try:
-        ranks, counts, prof = search_runs(gpu, A, B, b, 2)
+        ranks, counts, prof = search_runs(gpu, A, B, b, 2, ratio)
     finally:
         gpu.tune("frontier_epoch", 0); gpu.tune("emit_budget", 0)
-    assert prof["frontier_step"][1] >= 1300
+    assert prof["frontier_step"][1] + prof.get("range_step", (0, 0))[1] >= 1300 and (ratio == 0) == ("range_step" not in prof)
     assert prof["tile_build"][1] >= (3 if epoch == 0 and budget == 0 else 20)        # one tile build per epoch
     assert np.array_equal(ranks, oranks) and np.array_equal(counts, ocounts)
     M = gpu.merge(A, B)

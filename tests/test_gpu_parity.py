@@ -304,10 +304,14 @@ def test_partitioned_emit_rounds_fallbacks_and_variants(gpu, oracle):
             B = gpu.Index.upload(b.data, b.sequences, b.bases)
             settings = [dict(search_algo=2), dict(search_algo=2, l1_cap=5000), dict(search_algo=2, frontier_unfused=1), dict(search_algo=2, frontier_epoch=9),
                         dict(search_algo=2, emit_budget=4096), dict(search_algo=0), dict(search_algo=1), dict(search_algo=1, round_emits=20000),
-                        dict(search_algo=1, round_emits=3000), dict(emit_path=1), dict(search_algo=1, l1_cap=256)]
+                        dict(search_algo=1, round_emits=3000), dict(emit_path=1), dict(search_algo=1, l1_cap=256),
+                        # the node phase (fmi.cpp:304-322): never, for every level it can take (ratio 1: the whole search on trie nodes when
+                        # no level has more nodes than sequences), a few levels then elements, with short epochs behind it
+                        dict(search_algo=2, range_ratio=0), dict(search_algo=2, range_ratio=1), dict(search_algo=2, range_ratio=40),
+                        dict(search_algo=2, range_ratio=3, frontier_epoch=9), dict(search_algo=2, range_ratio=2, l1_cap=5000)]
             for st in settings:
-                for k in ("round_emits", "emit_path", "l1_cap", "search_algo", "frontier_unfused", "frontier_epoch", "emit_budget"):
-                    gpu.tune(k, {"round_emits": 1 << 33}.get(k, 0))
+                for k in ("round_emits", "emit_path", "l1_cap", "search_algo", "frontier_unfused", "frontier_epoch", "emit_budget", "range_ratio"):
+                    gpu.tune(k, {"round_emits": 1 << 33, "range_ratio": -1}.get(k, 0))
                 for k, v in st.items():
                     gpu.tune(k, v)
                 ra = gpu.RankArray(A, B)
@@ -319,7 +323,7 @@ def test_partitioned_emit_rounds_fallbacks_and_variants(gpu, oracle):
     finally:
         for k in ("emit_path", "l1_cap", "frontier_unfused", "frontier_epoch", "emit_budget"):
             gpu.tune(k, 0)
-        gpu.tune("round_emits", 1 << 33)
+        gpu.tune("round_emits", 1 << 33); gpu.tune("range_ratio", -1)
         gpu.tune("search_algo", 2)
 
 
