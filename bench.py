@@ -294,6 +294,15 @@ def main():
         checks = {"every_slice_equals_the_single_gpu_result": verified, "slices": world}
         if rank == 0:
             log("sharded verification: %s" % verified)
+    chain_tail = None
+    if last is not None and nsets > 2 and not sharded and rank == 0 and not args.no_host and not args.no_verify:
+        # the tail of the device-resident chain's stream (it depends on everything before it): what the host chain must reproduce
+        ptr, nb = last.device_data()
+        ref = np.zeros(min(nb, 1 << 26), dtype=np.uint8)
+        hip = ctypes.CDLL("libamdhip64.so.7")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        if hip.hipMemcpy(ref.ctypes.data, ptr + (nb - ref.size), ref.size, 2) == 0:
+            chain_tail = (nb, ref)
     if last is not None:
         last.free()
 
@@ -303,6 +312,8 @@ def main():
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_host and nsets == 2:
         host = host_to_host(pkg, np, torch, dev, host_in, meta, args)
+    if rank == 0 and world == 1 and not args.no_host and nsets > 2:
+        host = host_chain(pkg, np, torch, host_in, meta, args, chain_tail)
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N == 1)
     cpu = None
@@ -508,6 +519,64 @@ def host_to_host(pkg, np, torch, dev, host_in, meta, args):
     for bfr in buffers.values():
         bfr.free()
     return host
+
+
+def host_chain(pkg, np, torch, host_in, meta, args, chain_tail):
+    """A chained merge from page-locked host inputs to a page-locked host result (bwt_merge in1 in2 ... out, bwt_merge.cpp:167-173):
+    intermediate results stay on the device; the last merge downloads data + compact samples.  Measured twice: every merge uploading
+    its own increment when it starts (`sequential`), and every merge announcing the NEXT increment so that its bytes travel under
+    the search (`pipelined`, bwtm_merge_host_pipelined)."""
+    torch.cuda.empty_cache(); pkg.trim()
+    inp = [(host_in[k].array, meta[k]["sequences"], meta[k]["bases"]) for k in range(len(host_in))]
+    n = len(inp)
+    buffers = {}
+
+    def run(pipelined):
+        t0 = time.perf_counter()
+        phases = []
+        r, pend = pkg.merge_host_pipelined(a=inp[0], b=inp[1], next=(inp[2] if pipelined else None), samples=pkg.RESULT_ON_DEVICE, keep=True, buffers=buffers)
+        phases.append(dict(r.times))
+        kept, r.keep = r.keep, None
+        for k in range(2, n):
+            final = (k == n - 1)
+            nxt = (inp[k + 1] if pipelined and not final else None)
+            if pipelined:
+                r, pend = pkg.merge_host_pipelined(chained=kept, pending=pend, next=nxt, samples=(2 if final else pkg.RESULT_ON_DEVICE), keep=not final, buffers=buffers)
+            else:
+                r, _ = pkg.merge_host_pipelined(chained=kept, b=inp[k], samples=(2 if final else pkg.RESULT_ON_DEVICE), keep=not final, buffers=buffers)
+            phases.append(dict(r.times))
+            if not final:
+                kept, r.keep = r.keep, None
+        return time.perf_counter() - t0, phases, r
+
+    out = {}
+    check = None
+    for name, pipelined in (("sequential", False), ("pipelined", True)):
+        times = []
+        for it in range(2 + max(1, args.host_steps)):                  # two warm-up rounds (page-locked output buffers, the pool, the link)
+            dt, phases, r = run(pipelined)
+            if it >= 2:
+                times.append(dt)
+            log("host chain (%s) round %d: %.1f ms; upload / search per merge: %s" %
+                (name, it, dt * 1e3, [(round(ph["ms_upload"], 1), round(ph["ms_search"], 1)) for ph in phases]))
+        if chain_tail is not None:
+            nb, ref = chain_tail
+            ok = bool(r.out.nbytes == nb and np.array_equal(r.data[nb - ref.size:], ref))
+            check = ok if check is None else (check and ok)
+        sec = sum(times) / len(times)
+        out[name] = {"ms": round(sec * 1e3, 2), "ms_each": [round(t * 1e3, 1) for t in times],
+                     "phases_ms_per_merge": [{k: round(v, 1) for k, v in ph.items()} for ph in phases]}
+    merged_bases, acc = 0, meta[0]["bases"]
+    for k in range(1, n):
+        acc += meta[k]["bases"]; merged_bases += acc
+    out["value"] = round(merged_bases / 1e9 / (out["pipelined"]["ms"] / 1e3), 4)
+    out["unit"] = "Gbases/s (bases through all merges / time, page-locked host inputs -> page-locked host result with compact samples)"
+    out["saved_ms"] = round(out["sequential"]["ms"] - out["pipelined"]["ms"], 2)
+    out["equals_device_chain"] = check
+    out["bytes"] = {"h2d": sum(mt["nbytes"] for mt in meta), "d2h_data": r.out.nbytes}
+    for bfr in buffers.values():
+        bfr.free()
+    return out
 
 
 def cpu_model():

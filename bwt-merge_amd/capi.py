@@ -64,6 +64,11 @@ SYMBOLS = [
     ("bwtm_slice_extract", C.c_int, [vp, u64, u64, p_u8]),
     ("bwtm_merge_host", C.c_int, [C.POINTER(HostInput), C.POINTER(HostInput), ALLOC_FN, vp, C.c_int, C.POINTER(HostOutput), C.POINTER(vp)]),
     ("bwtm_merge_host_chained", C.c_int, [vp, C.POINTER(HostInput), ALLOC_FN, vp, C.c_int, C.POINTER(HostOutput), C.POINTER(vp)]),
+    ("bwtm_merge_host_pipelined", C.c_int, [vp, C.POINTER(HostInput), C.POINTER(HostInput), vp, C.POINTER(HostInput), C.POINTER(vp), ALLOC_FN, vp, C.c_int,
+                                            C.POINTER(HostOutput), C.POINTER(vp)]),
+    ("bwtm_upload_begin", C.c_int, [C.POINTER(HostInput), C.POINTER(vp)]),
+    ("bwtm_upload_finish", C.c_int, [vp, C.POINTER(vp)]),
+    ("bwtm_upload_free", None, [vp]),
     ("bwtm_last_error", C.c_char_p, []),
     ("bwtm_synchronize", C.c_int, []),
     ("bwtm_trim", C.c_int, []),
@@ -238,13 +243,16 @@ class HostMerge:
             return self.block_end, self.cum
         return expand_samples(self.out.sample_width, self.fields, self.anchors, self.out.blocks, self.out.bases)
 
-    fields = property(lambda s: s.buffers[3].array.view(np.uint16 if s.out.sample_width == 2 else np.uint32)[: SIGMA * s.out.blocks].reshape(SIGMA, s.out.blocks))
+    fields = property(lambda s: s.buffers[3].array[: SIGMA * s.out.blocks * s.out.sample_width].view(FIELD_DTYPES[s.out.sample_width]).reshape(SIGMA, s.out.blocks))
     anchors = property(lambda s: s.buffers[4].array.view(np.uint64)[: SIGMA * ((s.out.blocks + 63) // 64)].reshape(SIGMA, (s.out.blocks + 63) // 64))
     data = property(lambda s: s.buffers[0].array[: s.out.nbytes])
     block_end = property(lambda s: s.buffers[1].array.view(np.uint64)[: s.out.blocks])
     cum = property(lambda s: s.buffers[2].array.view(np.uint64)[: SIGMA * (s.out.blocks + 1)].reshape(SIGMA, s.out.blocks + 1))
     C = property(lambda s: np.array(list(s.out.C), dtype=np.uint64))
     times = property(lambda s: {k: getattr(s.out, k) for k in ("ms_upload", "ms_search", "ms_interleave", "ms_encode_download", "ms_samples", "ms_total")})
+
+
+FIELD_DTYPES = {1: np.uint8, 2: np.uint16, 4: np.uint32}
 
 
 def expand_samples(width, fields, anchors, blocks, bases):
@@ -306,6 +314,84 @@ def merge_host(a, b, samples=True, keep=False, chained=None, buffers=None):
     if keep:
         res.keep = Index(kp)
     return res
+
+
+RESULT_ON_DEVICE = -1
+
+
+class Upload:
+    """An input on its way to the device (bwtm_upload): keeps the host array alive until it is consumed."""
+
+    def __init__(self, handle, source):
+        self.h, self.source = handle, source
+
+    def finish(self):
+        """-> Index (bwtm_upload_finish: waits for the copies, decodes, validates, transcodes)."""
+        h, self.h = self.h, None
+        out = vp()
+        check(lib().bwtm_upload_finish(h, C.byref(out)))
+        self.source = None
+        return Index(out)
+
+    def free(self):
+        if self.h is not None:
+            lib().bwtm_upload_free(self.h)
+            self.h = None
+        self.source = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def upload_begin(data, sequences, bases):
+    hi = _host_input(data, sequences, bases)
+    out = vp()
+    check(lib().bwtm_upload_begin(C.byref(hi), C.byref(out)))
+    return Upload(out, data)
+
+
+def merge_host_pipelined(a=None, b=None, chained=None, pending=None, next=None, samples=True, keep=False, buffers=None):
+    """bwtm_merge_host_pipelined: a = (data, sequences, bases) or chained = device Index (consumed); b likewise or pending = Upload
+    (consumed); next = (data, sequences, bases) of the FOLLOWING merge's input, whose copies run under this merge's search.
+    samples = RESULT_ON_DEVICE: nothing is encoded or downloaded (needs keep).  Returns (HostMerge, Upload or None)."""
+    res = HostMerge()
+    if buffers is not None:
+        res.buffers = buffers
+
+    def alloc(user, what, nbytes):
+        buf = res.buffers.get(what)
+        if buf is None or buf.nbytes < nbytes:
+            if buf is not None:
+                buf.free()
+            buf = HostBuffer(nbytes)
+            res.buffers[what] = buf
+        return buf.ptr
+
+    cb = ALLOC_FN(alloc)
+    ha = _host_input(*a) if a is not None else None
+    hb = _host_input(*b) if b is not None else None
+    hn = _host_input(*next) if next is not None else None
+    dev = None
+    if chained is not None:
+        dev, chained.h = chained.h, None
+    pend = None
+    if pending is not None:
+        pend, pending.h = pending.h, None
+    kp, np_ = vp(), vp()
+    rc = lib().bwtm_merge_host_pipelined(dev, C.byref(ha) if ha else None, C.byref(hb) if hb else None, pend, C.byref(hn) if hn else None,
+                                         C.byref(np_) if hn else None, cb, None, int(samples), C.byref(res.out), C.byref(kp) if keep else None)
+    if pending is not None:
+        pending.source = None
+    if rc != 0:
+        if buffers is None:
+            res.free()
+        check(rc)
+    if keep:
+        res.keep = Index(kp)
+    return res, (Upload(np_, next[0]) if hn else None)
 
 
 def _u8(a):
@@ -409,7 +495,7 @@ class Index:
         return be, cum
 
     def samples_compact(self, width=None):
-        """(width, fields [6][blocks] of uint16 / uint32, anchors [6][ceil(blocks / 64)] uint64); see include/bwtm.h."""
+        """(width, fields [6][blocks] of uint8 / uint16 / uint32, anchors [6][ceil(blocks / 64)] uint64); see include/bwtm.h."""
         if width is None:
             w = C.c_int(0)
             check(lib().bwtm_index_samples_width(self.h, C.byref(w)))
@@ -417,7 +503,7 @@ class Index:
         if width == 8:
             return 8, None, None
         nb = self.blocks
-        fields = np.zeros((SIGMA, nb), dtype=(np.uint16 if width == 2 else np.uint32))
+        fields = np.zeros((SIGMA, nb), dtype=FIELD_DTYPES[width])
         anchors = np.zeros((SIGMA, (nb + 63) // 64), dtype=np.uint64)
         check(lib().bwtm_index_download_samples_compact(self.h, width, fields.ctypes.data_as(vp), anchors.ctypes.data_as(p_u64)))
         return width, fields, anchors

@@ -394,11 +394,11 @@ int download_samples(bwtm_index* x, u64* block_end, u64* cum)
   return BWTM_OK;
 }
 
-// Width of the compact sample fields: 2 or 4 bytes when every block encodes fewer than 2^16 - 1 / 2^32 - 1 positions, else 8
+// Width of the compact sample fields: 1, 2 or 4 bytes when every block encodes fewer than 2^8 - 1 / 2^16 - 1 / 2^32 - 1 positions, else 8
 // (= use the full arrays).  Synchronises.
 int samples_width(bwtm_index* x, int* width)
 {
-  *width = 2;
+  *width = 1;
   if(x->nblocks == 0) { return BWTM_OK; }
   DevBuf m; TRY(m.alloc(sizeof(u64), true));
   LAUNCH("block_field_max", k_block_field_max, div_up(x->nblocks, BLOCK_THREADS), BLOCK_THREADS, x->view(), x->block_start.as<const u64>(), x->nblocks,
@@ -406,7 +406,7 @@ int samples_width(bwtm_index* x, int* width)
   TRY(fetch_u64(m.as<u64>(), 0));
   HIP_TRY(hipStreamSynchronize(CTX.stream));
   const u64 mx = CTX.host_scratch[0];
-  *width = (mx < 0xFFFFull ? 2 : (mx < 0xFFFFFFFFull ? 4 : 8));
+  *width = (mx < 0xFFull ? 1 : (mx < 0xFFFFull ? 2 : (mx < 0xFFFFFFFFull ? 4 : 8)));
   return BWTM_OK;
 }
 
@@ -616,8 +616,9 @@ extern "C" int bwtm_index_download_samples_compact(bwtm_index* x, int width, voi
   if(!x->has_native) { return fail(BWTM_EINVAL, "index has no native samples (call bwtm_index_encode first)"); }
   if(x->nblocks > 0 && (!fields || !anchors)) { return fail(BWTM_EINVAL, "bwtm_index_download_samples_compact: null argument"); }
   int need = 0; TRY(samples_width(x, &need));
-  if(width != 2 && width != 4) { return fail(BWTM_EINVAL, "bwtm_index_download_samples_compact: width must be 2 or 4"); }
+  if(width != 1 && width != 2 && width != 4) { return fail(BWTM_EINVAL, "bwtm_index_download_samples_compact: width must be 1, 2 or 4"); }
   if(width < need) { return fail(BWTM_EINVAL, "bwtm_index_download_samples_compact: a block encodes too many positions for %d-byte fields (need %d)", width, need); }
+  if(width == 1) { return download_samples_compact<u8>(x, (u8*)fields, anchors); }
   return (width == 2 ? download_samples_compact<unsigned short>(x, (unsigned short*)fields, anchors) : download_samples_compact<u32>(x, (u32*)fields, anchors));
 }
 

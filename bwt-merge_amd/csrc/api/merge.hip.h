@@ -5,6 +5,24 @@
 */
 #pragma once
 
+// An input whose native bytes are on their way to the device (queued on the copy stream behind the uploads of the merge that
+// was running when it was announced): what bwtm_merge_host_pipelined hands back for the NEXT merge of a chain.
+struct bwtm_upload
+{
+  bwtm_index* x = nullptr;            // native buffer + sample arrays allocated, nothing decoded yet
+  UploadEvents events;                // one per chunk
+  bwtm_host_input host;               // the caller's descriptor (validated when the upload is consumed)
+  u64 C_copy[8] = {};                 // host.C points here when the caller gave an alphabet (the caller's array may be gone by then)
+  void set(const bwtm_host_input& in)
+  {
+    host = in;
+    if(in.C) { for(int c = 0; c <= 6; c++) { C_copy[c] = in.C[c]; } host.C = C_copy; }
+  }
+  bwtm_upload() {}
+  bwtm_upload(const bwtm_upload&) = delete; bwtm_upload& operator=(const bwtm_upload&) = delete;
+  ~bwtm_upload() { delete x; }
+};
+
 namespace
 {
 
@@ -74,23 +92,45 @@ double now_ms()
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-int merge_host_impl(bwtm_index* a_dev, const bwtm_host_input* a_host, const bwtm_host_input* b_host, bwtm_alloc_fn alloc, void* user,
-  int want_samples, bwtm_host_output* out, bwtm_index** keep)
+// b comes from the host (b_host) or is an upload announced during the previous merge (b_pending, consumed).  `next` (optional)
+// announces the input of the merge after this one: its copies are queued on the copy stream right behind this merge's own, so
+// they run under this merge's search, and the pending upload is handed back in *next_out.
+int merge_host_impl(bwtm_index* a_dev, const bwtm_host_input* a_host, const bwtm_host_input* b_host, bwtm_upload* b_pending,
+  const bwtm_host_input* next, bwtm_upload** next_out, bwtm_alloc_fn alloc, void* user, int want_samples, bwtm_host_output* out, bwtm_index** keep)
 {
   const double t0 = now_ms();
   bwtm_index* a = a_dev;
-  bwtm_index* b = new bwtm_index();
+  bwtm_index* b = nullptr;
   bwtm_index* x = nullptr;
+  bwtm_upload* pending_next = nullptr;
+  bwtm_host_input b_desc;
+  if(b_pending) { b = b_pending->x; b_pending->x = nullptr; b_desc = b_pending->host; b_host = &b_desc; }
+  else { b = new bwtm_index(); }
   auto body = [&]() -> int
   {
     // The copies of both inputs are queued first (copy stream: b's chunks, then a's).  b's decode pass and scans run on the compute
     // stream while b's later chunks arrive; the host then waits for b's scan results only -- a's bytes are still on the link --
     // VALIDATES b's header against the stream, and only then queues b's transcode, which sizes its output from the header
     // (a wrong `bases` or a non-canonical stream must never reach k_build_recs).  a follows the same way.
-    UploadEvents ev_a, ev_b;
-    b->ctx = t_ctx; b->nbytes = b_host->nbytes; b->n = b_host->bases; b->m = b_host->sequences;
-    TRY(alloc_native(b->data, b_host->nbytes));
-    TRY(upload_prepare(b));
+    UploadEvents ev_a, ev_b_own;
+    UploadEvents& ev_b = (b_pending ? b_pending->events : ev_b_own);
+    if(!b_pending)
+    {
+      b->ctx = t_ctx; b->nbytes = b_host->nbytes; b->n = b_host->bases; b->m = b_host->sequences;
+      TRY(alloc_native(b->data, b_host->nbytes));
+      TRY(upload_prepare(b));
+    }
+    else if(b->ctx != t_ctx) { return fail(BWTM_EINVAL, "bwtm_merge_host_pipelined: the pending upload lives in another context"); }
+    if(next)
+    {
+      pending_next = new bwtm_upload();
+      pending_next->set(*next);
+      bwtm_index* nx = new bwtm_index();
+      pending_next->x = nx;
+      nx->ctx = t_ctx; nx->nbytes = next->nbytes; nx->n = next->bases; nx->m = next->sequences;
+      TRY(alloc_native(nx->data, next->nbytes));
+      TRY(upload_prepare(nx));
+    }
     if(a_host)
     {
       a = new bwtm_index();
@@ -99,8 +139,9 @@ int merge_host_impl(bwtm_index* a_dev, const bwtm_host_input* a_host, const bwtm
       TRY(upload_prepare(a));
     }
     TRY(fork_copy_stream());                                        // recycled blocks may have queued users on the compute stream
-    TRY(upload_copies(b, (b_host->nbytes > 0 ? b_host->data : (const u8*)""), ev_b));
+    if(!b_pending) { TRY(upload_copies(b, (b_host->nbytes > 0 ? b_host->data : (const u8*)""), ev_b)); }
     if(a_host) { TRY(upload_copies(a, (a_host->nbytes > 0 ? a_host->data : (const u8*)""), ev_a)); }
+    if(next) { TRY(upload_copies(pending_next->x, (next->nbytes > 0 ? next->data : (const u8*)""), pending_next->events)); }   // under this merge's search
     TRY(upload_decode(b, &ev_b));
     TRY(upload_scan(b, 8));
     hipEvent_t b_scanned = nullptr;
@@ -116,7 +157,7 @@ int merge_host_impl(bwtm_index* a_dev, const bwtm_host_input* a_host, const bwtm
       TRY(upload_decode(a, &ev_a));
       TRY(upload_scan(a, 16));
     }
-    HIP_TRY(hipStreamSynchronize(CTX.copy_stream));
+    // (the compute stream has waited for every chunk of a and b; the copy stream itself may still be busy with `next`)
     HIP_TRY(hipStreamSynchronize(CTX.stream));
     if(a_host)
     {
@@ -137,6 +178,13 @@ int merge_host_impl(bwtm_index* a_dev, const bwtm_host_input* a_host, const bwtm
     for(int c = 0; c <= 6; c++) { out->C[c] = x->C[c]; }
     out->data = nullptr; out->nbytes = 0; out->blocks = 0; out->block_end = nullptr; out->cum = nullptr;
     out->sample_width = 0; out->fields = nullptr; out->anchors = nullptr;
+    if(want_samples == BWTM_RESULT_ON_DEVICE)
+    {
+      // an intermediate result of a chain: the next merge's first input, never encoded or downloaded (bwt_merge.cpp:167-173)
+      HIP_TRY(hipStreamSynchronize(CTX.stream));
+      out->ms_interleave = now_ms() - t2; out->ms_encode_download = 0; out->ms_samples = 0; out->ms_total = now_ms() - t0;
+      return BWTM_OK;
+    }
     std::unique_ptr<EncodePlan> plan_holder(new EncodePlan());
     EncodePlan& plan = *plan_holder;
     if(x->n > 0) { TRY(encode_size(x, plan)); }
@@ -169,6 +217,7 @@ int merge_host_impl(bwtm_index* a_dev, const bwtm_host_input* a_host, const bwtm
     const double t4 = now_ms();
     out->ms_encode_download = t4 - t3;
     if(want_samples && width == 8) { TRY(download_samples(x, out->block_end, out->cum)); }
+    else if(want_samples && width == 1) { TRY(download_samples_compact<u8>(x, (u8*)out->fields, out->anchors)); }
     else if(want_samples && width == 2) { TRY(download_samples_compact<unsigned short>(x, (unsigned short*)out->fields, out->anchors)); }
     else if(want_samples) { TRY(download_samples_compact<u32>(x, (u32*)out->fields, out->anchors)); }
     const double t5 = now_ms();
@@ -177,12 +226,14 @@ int merge_host_impl(bwtm_index* a_dev, const bwtm_host_input* a_host, const bwtm
     return BWTM_OK;
   };
   int rc = body();
+  delete b_pending;                                                 // consumed (its index was taken over above)
   if(rc != BWTM_OK)
   {
     (void)hipStreamSynchronize(CTX.copy_stream); (void)hipStreamSynchronize(CTX.stream);   // nothing may touch the caller's buffers after the return
-    delete a; delete b; delete x;
+    delete a; delete b; delete x; delete pending_next;
     return rc;
   }
+  if(next_out) { *next_out = pending_next; }
   if(keep) { rc = bwtm_index_drop_native(x); *keep = x; }
   else { delete x; }
   return rc;
@@ -242,7 +293,7 @@ extern "C" int bwtm_merge_host(const bwtm_host_input* a, const bwtm_host_input* 
 {
   if(!a || !b || !alloc || !out || (a->nbytes > 0 && !a->data) || (b->nbytes > 0 && !b->data)) { return fail(BWTM_EINVAL, "bwtm_merge_host: null argument"); }
   ENTER(nullptr);
-  return merge_host_impl(nullptr, a, b, alloc, user, want_samples, out, keep);
+  return merge_host_impl(nullptr, a, b, nullptr, nullptr, nullptr, alloc, user, want_samples, out, keep);
 }
 
 extern "C" int bwtm_merge_host_chained(bwtm_index* a, const bwtm_host_input* b, bwtm_alloc_fn alloc, void* user,
@@ -250,5 +301,63 @@ extern "C" int bwtm_merge_host_chained(bwtm_index* a, const bwtm_host_input* b, 
 {
   if(!a || !b || !alloc || !out || (b->nbytes > 0 && !b->data)) { bwtm_index_free(a); return fail(BWTM_EINVAL, "bwtm_merge_host_chained: null argument"); }
   ENTER(a->ctx);
-  return merge_host_impl(a, nullptr, b, alloc, user, want_samples, out, keep);
+  return merge_host_impl(a, nullptr, b, nullptr, nullptr, nullptr, alloc, user, want_samples, out, keep);
+}
+
+extern "C" int bwtm_merge_host_pipelined(bwtm_index* a_device, const bwtm_host_input* a_host, const bwtm_host_input* b_host, bwtm_upload* b_pending,
+  const bwtm_host_input* next, bwtm_upload** next_pending, bwtm_alloc_fn alloc, void* user, int want_samples, bwtm_host_output* out, bwtm_index** keep)
+{
+  const bool bad = (!alloc || !out || ((a_device != nullptr) == (a_host != nullptr)) || ((b_host != nullptr) == (b_pending != nullptr)) || (next && !next_pending) ||
+    (a_host && a_host->nbytes > 0 && !a_host->data) || (b_host && b_host->nbytes > 0 && !b_host->data) || (next && next->nbytes > 0 && !next->data));
+  if(bad || (want_samples == BWTM_RESULT_ON_DEVICE && !keep))
+  {
+    bwtm_index_free(a_device); bwtm_upload_free(b_pending);
+    return fail(BWTM_EINVAL, "bwtm_merge_host_pipelined: exactly one form of each input is required (and `keep` for a result that stays on the device)");
+  }
+  if(next_pending) { *next_pending = nullptr; }
+  ENTER(a_device ? a_device->ctx : (b_pending && b_pending->x ? b_pending->x->ctx : nullptr));
+  return merge_host_impl(a_device, a_host, b_host, b_pending, next, next_pending, alloc, user, want_samples, out, keep);
+}
+
+extern "C" int bwtm_upload_begin(const bwtm_host_input* in, bwtm_upload** out)
+{
+  if(!in || !out || (in->nbytes > 0 && !in->data)) { return fail(BWTM_EINVAL, "bwtm_upload_begin: null argument"); }
+  ENTER(nullptr);
+  bwtm_upload* u = new bwtm_upload();
+  u->set(*in);
+  bwtm_index* x = new bwtm_index();
+  u->x = x;
+  x->ctx = t_ctx; x->nbytes = in->nbytes; x->n = in->bases; x->m = in->sequences;
+  int rc = alloc_native(x->data, in->nbytes);
+  if(rc == BWTM_OK) { rc = upload_prepare(x); }
+  if(rc == BWTM_OK) { rc = fork_copy_stream(); }
+  if(rc == BWTM_OK) { rc = upload_copies(x, (in->nbytes > 0 ? in->data : (const u8*)""), u->events); }
+  if(rc != BWTM_OK) { (void)hipStreamSynchronize(CTX.copy_stream); delete u; return rc; }
+  *out = u;
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_upload_finish(bwtm_upload* upload, bwtm_index** out)
+{
+  if(!upload || !out || !upload->x) { bwtm_upload_free(upload); return fail(BWTM_EINVAL, "bwtm_upload_finish: null argument"); }
+  ENTER(upload->x->ctx);
+  bwtm_index* x = upload->x;
+  int rc = upload_decode(x, &upload->events);
+  if(rc == BWTM_OK) { rc = upload_scan(x, 0); }
+  hipError_t e = hipStreamSynchronize(CTX.stream);                  // has waited for every chunk: the caller's buffer is free again
+  if(rc == BWTM_OK && e != hipSuccess) { rc = fail(BWTM_ENODEV, "upload failed: %s", hipGetErrorString(e)); }
+  if(rc != BWTM_OK) { (void)hipStreamSynchronize(CTX.copy_stream); }
+  if(rc == BWTM_OK) { rc = upload_validate(x, upload->host.sequences, upload->host.bases, upload->host.C, 0); }
+  if(rc == BWTM_OK) { rc = transcode(x); }
+  if(rc == BWTM_OK) { upload->x = nullptr; *out = x; }
+  delete upload;
+  return rc;
+}
+
+extern "C" void bwtm_upload_free(bwtm_upload* upload)
+{
+  if(!upload) { return; }
+  Scope scope(upload->x ? upload->x->ctx : nullptr);
+  if(scope.rc == BWTM_OK) { (void)hipStreamSynchronize(CTX.copy_stream); }       // queued copies still read the caller's buffer
+  delete upload;
 }

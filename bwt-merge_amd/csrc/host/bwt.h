@@ -89,7 +89,7 @@ public:
     std::swap(header, other.header); data.swap(other.data); block_end.swap(other.block_end);
     cum_flat.swap(other.cum_flat); std::swap(cum_stride, other.cum_stride);
     std::swap(sample_width, other.sample_width); fields.swap(other.fields); anchors.swap(other.anchors);
-    std::swap(device, other.device); std::swap(host_current, other.host_current);
+    std::swap(device, other.device); std::swap(pending, other.pending); std::swap(host_current, other.host_current);
   }
 
   size_type size() const { return header.bases; }
@@ -105,6 +105,7 @@ public:
   size_type field(size_type c, size_type k) const
   {
     const size_type at = c * (cum_stride - 1) + k;
+    if(sample_width == 1) { return (size_type)((const std::uint8_t*)fields.data())[at]; }
     return (sample_width == 2 ? (size_type)fields[at] : (size_type)((const std::uint32_t*)fields.data())[at]);
   }
   // start position (c == 0) / occurrences of c (1..5) before block k, k <= blocks, compact form
@@ -343,6 +344,12 @@ public:
   // verification after a merge finds it there).
   bwtm_index* onDevice(const std::vector<size_type>& C) const
   {
+    if(!device && pending)
+    {
+      bwtm_upload* u = pending; pending = nullptr;
+      gpuCheck(bwtm_upload_finish(u, &device), "BWT::onDevice()");           // announced by prefetchDevice(): the bytes are (nearly) there
+      gpuCheck(bwtm_index_drop_native(device), "BWT::onDevice()");
+    }
     if(!device)
     {
       uint64_t c_array[BWTM_SIGMA + 1];
@@ -352,10 +359,27 @@ public:
     }
     return device;
   }
+  // Announces that this BWT will be needed on the device soon: its bytes start travelling now (copy stream) and the call
+  // returns at once -- bwt_merge announces input k + 1 before it merges input k, so the copy runs under that merge's search.
+  void prefetchDevice(const std::vector<size_type>& C) const
+  {
+    if(device || pending) { return; }
+    materialize();
+    uint64_t c_array[BWTM_SIGMA + 1];
+    for(size_type c = 0; c <= SIGMA; c++) { c_array[c] = C[c]; }
+    bwtm_host_input in = { data.data(), data.size(), sequences(), size(), c_array };      // the library keeps its own copy of C
+    gpuCheck(bwtm_upload_begin(&in, &pending), "BWT::prefetchDevice()");
+  }
+  // Hands the announced upload to the caller (bwtm_merge_host_pipelined consumes it); nullptr if there is none.
+  bwtm_upload* releasePending() { bwtm_upload* u = pending; pending = nullptr; return u; }
   // Hands the device copy to the caller (who frees or consumes it); nullptr if there is none.
   bwtm_index* releaseDevice() { bwtm_index* d = device; device = nullptr; return d; }
   bool deviceResident() const { return device != nullptr; }
-  void dropDevice() const { if(device) { bwtm_index_free(device); device = nullptr; } }
+  void dropDevice() const
+  {
+    if(pending) { bwtm_upload_free(pending); pending = nullptr; }           // waits for the queued copies: they read this object's bytes
+    if(device) { bwtm_index_free(device); device = nullptr; }
+  }
 
   // Takes over a merged device index; the host form is produced by materialize() when somebody asks for it.
   void adopt(bwtm_index* merged)
@@ -393,7 +417,7 @@ public:
     else
     {
       anchors.resizeUninitialized(SIGMA * ((nblocks + 63) / 64));
-      fields.resizeUninitialized(SIGMA * nblocks * (size_type)width / 2);
+      fields.resizeUninitialized((SIGMA * nblocks * (size_type)width + 1) / 2);
       gpuCheck(bwtm_index_download_samples_compact(device, width, fields.data(), anchors.data()), "BWT::materialize()");
     }
     gpuCheck(bwtm_index_drop_native(device), "BWT::materialize()");         // keep only the rank structure on the device
@@ -457,12 +481,13 @@ public:
   mutable HostArray<size_type>   block_end;            // last sequence position of each block (block_boundaries)
   mutable HostArray<size_type>   cum_flat;             // [SIGMA][cum_stride]: cum(c, k) = #c in blocks [0, k) (samples[c])
   mutable size_type              cum_stride = 0;       // blocks + 1
-  mutable int                    sample_width = 8;     // 8: block_end + cum_flat; 2 / 4: fields16 / fields32 + anchors
+  mutable int                    sample_width = 8;     // 8: block_end + cum_flat; 1 / 2 / 4: 8- / 16- / 32-bit fields + anchors
   mutable HostArray<std::uint16_t> fields;             // raw storage of the fields, 16 or 32 bits each (field())
   mutable HostArray<size_type>   anchors;
 
 private:
   mutable bwtm_index* device = nullptr;                // device copy (rank structure only), owned
+  mutable bwtm_upload* pending = nullptr;              // an announced upload of `data` (prefetchDevice), owned
   mutable bool        host_current = true;             // false: only the device holds the BWT (lazy result of a merge)
 
   struct Cursor { size_type block, rle_pos, seq_pos; };

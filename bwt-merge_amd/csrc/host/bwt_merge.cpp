@@ -171,16 +171,30 @@ int main(int argc, char** argv)
   FMI index; load(index, argv[optind], input_formats[0]);
   verifyFMI(index, "Input", patterns, pre_results);
 
+  // A chain is software-pipelined: input k + 1 is loaded and ANNOUNCED to the device (BWT::prefetchDevice: its bytes start
+  // travelling on the copy stream) before input k is merged, so the transfer runs under that merge's search.
   size_type bytes_added = 0;
+  FMI increment; load(increment, argv[optind + 1], input_formats[1]);
   for(int input = 1; input < inputs; input++)
   {
-    FMI increment; load(increment, argv[optind + input], input_formats[input]);
     bytes_added += increment.size();
     verifyFMI(increment, "Input", patterns, pre_results);
+    FMI next;
+    if(input + 1 < inputs)
+    {
+      load(next, argv[optind + input + 1], input_formats[input + 1]);
+      if(devices.size() == 1)
+      {
+        // this merge's own inputs go first on the link (the first merge of a chain uploads both of them)
+        index.bwt.onDevice(index.alpha.C); increment.bwt.onDevice(increment.alpha.C);
+        next.bwt.prefetchDevice(next.alpha.C);
+      }
+    }
     // Intermediate results of a chain are only ever the next merge's first input: they stay on the device.  The last
     // merge produces the host-resident FMI inside its timer, like the reference's.
     MergeParameters p = parameters; p.lazy_host = (input + 1 < inputs);
     merge(index, increment, p, devices);
+    increment.swap(next);
   }
 
   serialize(index, argv[argc - 1], output_format);

@@ -169,7 +169,7 @@ inline void* mergeSink(void* user, int what, uint64_t nbytes)
   case BWTM_BUF_BLOCK_END: bwt->block_end.resizeUninitialized(std::max<uint64_t>(nbytes / sizeof(size_type), 1)); bwt->block_end.resizeUninitialized(nbytes / sizeof(size_type)); return bwt->block_end.data();
   case BWTM_BUF_CUM:       bwt->cum_flat.resizeUninitialized(nbytes / sizeof(size_type)); return bwt->cum_flat.data();
   case BWTM_BUF_ANCHORS:   bwt->anchors.resizeUninitialized(std::max<uint64_t>(nbytes / sizeof(size_type), 1)); bwt->anchors.resizeUninitialized(nbytes / sizeof(size_type)); return bwt->anchors.data();
-  case BWTM_BUF_FIELDS:    bwt->fields.resizeUninitialized(std::max<uint64_t>(nbytes / 2, 1)); bwt->fields.resizeUninitialized(nbytes / 2); return bwt->fields.data();
+  case BWTM_BUF_FIELDS:    bwt->fields.resizeUninitialized(std::max<uint64_t>((nbytes + 1) / 2, 1)); bwt->fields.resizeUninitialized((nbytes + 1) / 2); return bwt->fields.data();
   }
   return nullptr;
 }
@@ -223,8 +223,14 @@ inline FMI::FMI(FMI& a, FMI& b, MergeParameters parameters)
     bwtm_host_input hb = { bdata.data(), bdata.size(), b.sequences(), b.size(), cb.data() };
     bwtm_host_output out;
     bwtm_index* kept = nullptr;
+    bwtm_upload* b_pending = (b.bwt.deviceResident() ? nullptr : b.bwt.releasePending());   // announced while the previous merge ran
     b.bwt.dropDevice();
-    if(a.bwt.deviceResident())
+    if(a.bwt.deviceResident() && b_pending)
+    {
+      gpuCheck(bwtm_merge_host_pipelined(a.bwt.releaseDevice(), nullptr, nullptr, b_pending, nullptr, nullptr, mergeSink, &this->bwt, BWTM_SAMPLES_COMPACT, &out, &kept),
+        "FMI::FMI()");
+    }
+    else if(a.bwt.deviceResident())
     {
       gpuCheck(bwtm_merge_host_chained(a.bwt.releaseDevice(), &hb, mergeSink, &this->bwt, BWTM_SAMPLES_COMPACT, &out, &kept), "FMI::FMI()");
     }
@@ -232,7 +238,8 @@ inline FMI::FMI(FMI& a, FMI& b, MergeParameters parameters)
     {
       const BlockArray& adata = a.bwt.hostData();
       bwtm_host_input ha = { adata.data(), adata.size(), a.sequences(), a.size(), ca.data() };
-      gpuCheck(bwtm_merge_host(&ha, &hb, mergeSink, &this->bwt, BWTM_SAMPLES_COMPACT, &out, &kept), "FMI::FMI()");
+      if(b_pending) { gpuCheck(bwtm_merge_host_pipelined(nullptr, &ha, nullptr, b_pending, nullptr, nullptr, mergeSink, &this->bwt, BWTM_SAMPLES_COMPACT, &out, &kept), "FMI::FMI()"); }
+      else { gpuCheck(bwtm_merge_host(&ha, &hb, mergeSink, &this->bwt, BWTM_SAMPLES_COMPACT, &out, &kept), "FMI::FMI()"); }
     }
     this->bwt.adoptHost(kept, out.blocks, out.sample_width);
     a.bwt.clear(); b.bwt.clear();

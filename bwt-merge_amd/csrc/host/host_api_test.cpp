@@ -97,7 +97,7 @@ int main(int argc, char** argv)
   }
   {
     FMI rebuilt; rebuilt.bwt.data = merged.bwt.data; rebuilt.bwt.buildFromData();
-    CHECK(merged.bwt.sample_width == 2);                                     // the merge downloaded the compact samples
+    CHECK(merged.bwt.sample_width == 1);                                     // the merge downloaded the compact samples (reads: 8-bit fields)
     CHECK(rebuilt.bwt.blockEnds() == merged.bwt.blockEnds());
     for(size_type c = 0; c < 6; c++) { CHECK(rebuilt.bwt.cumulative(c) == merged.bwt.cumulative(c)); }
     // queries on the compact form == queries on the full form

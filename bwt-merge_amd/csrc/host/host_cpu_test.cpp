@@ -1,6 +1,6 @@
 /*
   host_cpu_test -- the parts of the C++ facade that need no GPU: Run / ByteCode / RunBuffer / getBounds, BWT queries on the full
-  and on the COMPACT form of the samples (the form a merge downloads: 16- / 32-bit per-block fields + anchors every 64 blocks),
+  and on the COMPACT form of the samples (the form a merge downloads: 8- / 16- / 32-bit per-block fields + anchors every 64 blocks),
   expandSamples(), native serialization round trip.  Exit code 0 = every check passed.
 */
 #include <cstdio>
@@ -19,14 +19,15 @@ static void installCompact(const BWT& full, BWT& target, int width)
   const size_type nb = full.blocks(), nanch = (nb + 63) / 64;
   target.cum_stride = nb + 1; target.sample_width = width;
   target.anchors.resize(BWT::SIGMA * nanch);
-  target.fields.resize(BWT::SIGMA * nb * (size_type)width / 2);
+  target.fields.resize((BWT::SIGMA * nb * (size_type)width + 1) / 2);
   for(size_type k = 0; k < nb; k++)
   {
     size_type start = (k == 0 ? 0 : full.block_end[k - 1] + 1), length = full.block_end[k] + 1 - start;
     for(size_type c = 0; c < BWT::SIGMA; c++)
     {
       size_type value = (c == 0 ? length : full.cum(c, k + 1) - full.cum(c, k));
-      if(width == 2) { target.fields[c * nb + k] = (std::uint16_t)value; }
+      if(width == 1) { ((std::uint8_t*)target.fields.data())[c * nb + k] = (std::uint8_t)value; }
+      else if(width == 2) { target.fields[c * nb + k] = (std::uint16_t)value; }
       else { ((std::uint32_t*)target.fields.data())[c * nb + k] = (std::uint32_t)value; }
       if(k % 64 == 0) { target.anchors[c * nanch + k / 64] = (c == 0 ? start : full.cum(c, k)); }
     }
@@ -50,7 +51,7 @@ int main()
   CHECK(getBounds(range_type(0, 9), 4) == std::vector<range_type>({range_type(0, 1), range_type(2, 3), range_type(4, 6), range_type(7, 9)}));
 
   std::mt19937_64 rng(5);
-  for(int variant = 0; variant < 3; variant++)
+  for(int variant = 0; variant < 4; variant++)
   {
     // a run-structured string: short runs (variant 0), runs up to 70000 (variant 1: needs 32-bit fields), tiny (variant 2)
     FMI full;
@@ -61,13 +62,13 @@ int main()
     {
       comp_type c = (comp_type)(rng() % 6); if(c == previous) { c = (comp_type)((c + 1) % 6); } previous = c;
       size_type choices0[] = {1, 1, 2, 3, 41, 42, 170}, choices1[] = {1, 2, 50, 70000, 3};
-      size_type len = (variant == 1 ? choices1[rng() % 5] : choices0[rng() % 7]);
+      size_type len = (variant == 1 ? choices1[rng() % 5] : (variant == 3 ? choices0[rng() % 4] : choices0[rng() % 7]));   // variant 3: runs of 1 .. 3, 8-bit fields
       Run::write(full.bwt.data, c, len);
       if(symbols.size() < 400000) { for(size_type j = 0; j < len && symbols.size() < 400000; j++) { symbols.push_back(c); } }
     }
     full.bwt.buildFromData();
     const size_type n = full.bwt.size();
-    int width = (variant == 1 ? 4 : 2);
+    int width = (variant == 1 ? 4 : (variant == 3 ? 1 : 2));
     FMI compact; compact.bwt.header = full.bwt.header; compact.bwt.data = full.bwt.data;
     installCompact(full.bwt, compact.bwt, width);
     CHECK(compact.bwt.blocks() == full.bwt.blocks() && compact.bwt.blockEnds() == full.bwt.blockEnds());

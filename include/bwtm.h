@@ -127,7 +127,8 @@ int bwtm_index_download_samples(bwtm_index* index, uint64_t* block_end, uint64_t
    ANCHORS [6][ceil(blocks / 64)] of uint64: start position and counts of 1..5 before block 64 j.  Hence
      block_end[k]   = anchors[0][k / 64] + sum(fields[0][64 (k / 64) .. k]) - 1
      cum[c][k]      = anchors[c][k / 64] + sum(fields[c][64 (k / 64) .. k - 1])          (c = 1..5; c = 0: start - the five)
-   bwtm_index_samples_width() tells the narrowest width that holds every field: 2, 4, or 8 (= use the full arrays above). */
+   bwtm_index_samples_width() tells the narrowest width that holds every field: 1, 2, 4, or 8 (= use the full arrays above);
+   a stream of short runs (read collections: ~85 positions per block) takes 1. */
 int bwtm_index_samples_width(bwtm_index* index, int* width);
 int bwtm_index_download_samples_compact(bwtm_index* index, int width, void* fields, uint64_t* anchors);
 
@@ -211,7 +212,9 @@ typedef struct
 enum { BWTM_BUF_DATA = 0, BWTM_BUF_BLOCK_END = 1, BWTM_BUF_CUM = 2, BWTM_BUF_FIELDS = 3, BWTM_BUF_ANCHORS = 4 };
 /* want_samples: none, the full arrays (block_end + cum), or the compact form (fields + anchors; falls back to the full
    arrays, sample_width = 8, when a block encodes 2^32 - 1 positions or more). */
-enum { BWTM_SAMPLES_NONE = 0, BWTM_SAMPLES_FULL = 1, BWTM_SAMPLES_COMPACT = 2 };
+enum { BWTM_SAMPLES_NONE = 0, BWTM_SAMPLES_FULL = 1, BWTM_SAMPLES_COMPACT = 2,
+       BWTM_RESULT_ON_DEVICE = -1 };           /* nothing is encoded or downloaded: the result is only handed back in *keep (an
+                                                  intermediate result of a chained merge); the allocator is not called */
 typedef void* (*bwtm_alloc_fn)(void* user, int what, uint64_t nbytes);
 typedef struct
 {
@@ -220,7 +223,7 @@ typedef struct
   uint64_t C[BWTM_SIGMA + 1];
   uint64_t* block_end;                       /* [blocks]            (NULL unless samples were requested) */
   uint64_t* cum;                             /* [6][blocks + 1]     (NULL unless samples were requested) */
-  int sample_width;                          /* 0 = no samples; 8 = block_end + cum above; 2 / 4 = fields + anchors below */
+  int sample_width;                          /* 0 = no samples; 8 = block_end + cum above; 1 / 2 / 4 = fields + anchors below */
   void* fields;                              /* [6][blocks] of sample_width bytes (bwtm_index_download_samples_compact) */
   uint64_t* anchors;                         /* [6][ceil(blocks / 64)] */
   double ms_upload, ms_search, ms_interleave, ms_encode_download, ms_samples, ms_total;
@@ -231,6 +234,23 @@ int bwtm_merge_host(const bwtm_host_input* a, const bwtm_host_input* b, bwtm_all
 /* Chained form: `a` is a device index kept from the previous merge (consumed), `b` comes from the host. */
 int bwtm_merge_host_chained(bwtm_index* a, const bwtm_host_input* b, bwtm_alloc_fn alloc, void* user,
                             int want_samples, bwtm_host_output* out, bwtm_index** keep);
+
+/* Pipelined chain (bwt_merge in1 in2 in3 ...; bwt_merge.cpp:167-173): while THIS merge searches, the native bytes of the NEXT
+   increment travel to the device.  Exactly one of (a_device, a_host) and one of (b_host, b_pending) is given; `next` (optional)
+   announces the input of the following merge: its copies are queued on the copy stream behind this merge's own uploads and the
+   pending upload comes back in *next_pending, to be passed as b_pending of the next call (or released with bwtm_upload_free).
+   The caller's `next` buffer must stay valid until that call returns.  A chain then costs the first two uploads, the device
+   work of every merge and one download instead of the sum of all transfers and all device work. */
+typedef struct bwtm_upload bwtm_upload;
+int bwtm_merge_host_pipelined(bwtm_index* a_device, const bwtm_host_input* a_host, const bwtm_host_input* b_host, bwtm_upload* b_pending,
+                              const bwtm_host_input* next, bwtm_upload** next_pending, bwtm_alloc_fn alloc, void* user,
+                              int want_samples, bwtm_host_output* out, bwtm_index** keep);
+void bwtm_upload_free(bwtm_upload* upload);
+/* The same announcement on its own: the copies of `in` are queued on the copy stream NOW (behind whatever was queued before)
+   and the call returns; bwtm_upload_finish() waits for them, decodes, validates the header and returns the device index
+   (like bwtm_index_upload; the pending upload is consumed, also on failure).  `in->data` must stay valid until then. */
+int bwtm_upload_begin(const bwtm_host_input* in, bwtm_upload** out);
+int bwtm_upload_finish(bwtm_upload* upload, bwtm_index** out);
 
 /* --- the result sharded by output range (one slice per GPU) --------------------------------------------
 

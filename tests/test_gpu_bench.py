@@ -49,7 +49,9 @@ def test_bench_chained_merge_of_four_sets(bwtm):
     device-resident; reads extracted from the final index equal the four generators'."""
     d = run_bench([sys.executable, "bench.py", "--chain", "4", "--workload", "mixed", "--reads", "60000", "--steps", "1", "--warmup", "1",
                    "--no-cpu-baseline", "--verify-reads", "4000"])
-    assert d["verified"] is True and len(d["config"]["bases"]) == 4 and d["host_to_host"] is None
+    assert d["verified"] is True and len(d["config"]["bases"]) == 4
+    h = d["host_to_host"]                               # the chain from page-locked inputs to a page-locked result, with and without announced uploads
+    assert h["equals_device_chain"] is True and h["pipelined"]["ms"] > 0 and h["sequential"]["ms"] > 0 and len(h["pipelined"]["phases_ms_per_merge"]) == 3
     n = d["config"]["bases"][0]
     assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] * 1e6 - 9 * n) < 0.01 * 9 * n      # (2 + 3 + 4) n bases pass through the merges
 

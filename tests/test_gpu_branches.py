@@ -232,8 +232,59 @@ def test_host_to_host_merge(gpu, oracle, chunks):
             hb.free()
 
 
+@pytest.mark.parametrize("chunk", [0, 4096])
+def test_pipelined_chain_of_host_merges(gpu, oracle, chunk):
+    """bwt_merge in0 in1 in2 in3 as three bwtm_merge_host_pipelined calls: every merge announces the input of the next one, whose
+    bytes travel under its search; intermediate results stay on the device (BWTM_RESULT_ON_DEVICE), the last merge downloads.
+    The bytes and samples equal the oracle's BWT of the whole collection; a pending upload can also be finished on its own
+    (bwtm_upload_begin / _finish == bwtm_index_upload) or dropped."""
+    sets = [oracle.generate_reads(5000 + k, 2500 + 400 * k, 100 if k % 2 == 0 else 150) for k in range(4)]
+    fm = [oracle.FMI.from_text(t) for t in sets]
+    pinned = []
+    for f in fm:
+        hb = gpu.HostBuffer(f.nbytes)
+        hb.array[:] = f.data
+        pinned.append(hb)
+    inp = [(pinned[k].array, fm[k].sequences, fm[k].bases) for k in range(4)]
+    gpu.tune("upload_chunk", chunk)
+    try:
+        r, pend = gpu.merge_host_pipelined(a=inp[0], b=inp[1], next=inp[2], samples=gpu.RESULT_ON_DEVICE, keep=True)
+        assert r.out.nbytes == 0 and 0 not in r.buffers and r.out.bases == fm[0].bases + fm[1].bases
+        kept, r.keep = r.keep, None
+        r, pend = gpu.merge_host_pipelined(chained=kept, pending=pend, next=inp[3], samples=gpu.RESULT_ON_DEVICE, keep=True)
+        kept, r.keep = r.keep, None
+        r, none = gpu.merge_host_pipelined(chained=kept, pending=pend, samples=2)
+        assert none is None
+        direct = oracle.FMI.from_text(np.concatenate(sets))
+        assert np.array_equal(r.data, direct.data) and np.array_equal(r.C, direct.C)
+        be, cum = r.expanded_samples(); obe, ocum = direct.samples
+        assert np.array_equal(be, obe) and np.array_equal(cum, ocum)
+        r.free()
+        # the announcement on its own
+        u = gpu.upload_begin(*inp[1])
+        X = u.finish()
+        Y = gpu.Index.upload(fm[1].data, fm[1].sequences, fm[1].bases)
+        w0 = np.arange(0, fm[1].bases, 37, dtype=np.uint64); cs = (w0 % 6).astype(np.uint8)
+        assert np.array_equal(X.rank(w0, cs), Y.rank(w0, cs)) and np.array_equal(X.C, Y.C)
+        X.free(); Y.free()
+        gpu.upload_begin(*inp[2]).free()                                 # never consumed
+        with pytest.raises(gpu.BwtmError, match="header says"):
+            gpu.upload_begin(pinned[3].array, fm[3].sequences, fm[3].bases - 5).finish()
+        # a pending upload with a wrong header is refused by the merge that consumes it
+        kept = gpu.Index.upload(fm[0].data, fm[0].sequences, fm[0].bases)
+        bad = gpu.upload_begin(pinned[1].array, fm[1].sequences + 2, fm[1].bases)
+        with pytest.raises(gpu.BwtmError, match="header says"):
+            gpu.merge_host_pipelined(chained=kept, pending=bad, samples=False)
+        with pytest.raises(gpu.BwtmError):
+            gpu.merge_host_pipelined(a=inp[0], b=inp[1], samples=gpu.RESULT_ON_DEVICE)      # a device-only result needs `keep`
+    finally:
+        gpu.tune("upload_chunk", 0)
+        for hb in pinned:
+            hb.free()
+
+
 def test_compact_samples(gpu, oracle):
-    """The 12 / 24-byte form of the samples (fields + anchors) expands to exactly the arrays BWT::build computes, at both
+    """The 6 / 12 / 24-byte form of the samples (fields + anchors) expands to exactly the arrays BWT::build computes, at both
     widths, and the library falls back to the full arrays when a block encodes 2^32 - 1 positions or more."""
     rng = np.random.default_rng(23)
     cases = []
@@ -242,7 +293,10 @@ def test_compact_samples(gpu, oracle):
     syms = rng.integers(0, 6, 3000).astype(np.uint64); lens = rng.choice([1, 2, 50, 70000, 300000], 3000).astype(np.uint64)
     cases.append((oracle.FMI.from_runs(syms, lens), 4))                                               # runs >= 65535: 32-bit fields
     cases.append((oracle.FMI.from_runs(np.array([1, 2, 3], dtype=np.uint64), np.array([10, 5_000_000_000, 7], dtype=np.uint64)), 8))
-    cases.append((oracle.FMI.from_symbols(np.array([3], dtype=np.uint8)), 2))
+    cases.append((oracle.FMI.from_symbols(np.array([3], dtype=np.uint8)), 1))
+    cases.append((oracle.FMI.from_text(oracle.generate_reads(77, 4000, 100)), 1))                    # a read collection: 8-bit fields
+    syms = rng.integers(0, 6, 60000); lens = rng.choice([1, 2, 3], 60000)
+    cases.append((oracle.FMI.from_symbols(np.repeat(syms.astype(np.uint8), lens)), 1))
     for f, expect_width in cases:
         ix = upload(gpu, f)
         width, fields, anchors = ix.samples_compact()
@@ -251,10 +305,14 @@ def test_compact_samples(gpu, oracle):
         if width != 8:
             be, cum = gpu.capi.expand_samples(width, fields, anchors, f.blocks, f.bases)
             assert np.array_equal(be, obe) and np.array_equal(cum, ocum)
-            if width == 2:
-                w4 = ix.samples_compact(4)                                        # a wider form may always be asked for
-                be, cum = gpu.capi.expand_samples(4, w4[1], w4[2], f.blocks, f.bases)
-                assert np.array_equal(be, obe) and np.array_equal(cum, ocum)
+            if width < 4:
+                for wider in (2, 4)[(width == 2):]:                               # a wider form may always be asked for
+                    w = ix.samples_compact(wider)
+                    be, cum = gpu.capi.expand_samples(wider, w[1], w[2], f.blocks, f.bases)
+                    assert np.array_equal(be, obe) and np.array_equal(cum, ocum)
+                if width == 2:
+                    with pytest.raises(gpu.BwtmError, match="too many positions"):
+                        ix.samples_compact(1)
             else:
                 with pytest.raises(gpu.BwtmError, match="too many positions"):
                     ix.samples_compact(2)
