@@ -424,6 +424,24 @@ def verify_full_size(pkg, synth, np, last, meta, args, wargs, load_inputs):
         A.free(); B.free()
         checks["frontier_equals_walk"] = bool(np.array_equal(bits[0], bits[1]))
         del bits
+    elif len(meta) == 2:
+        # Too large for two full bitvectors on the host: the level-synchronous search of the WHOLE collection against the per-chain
+        # walk of a 1 % block of its sequences, compared on the device -- every bit the walk sets must be set by the frontier
+        # search, and the walk must set exactly one bit per position of its sequences.
+        A, B = load_inputs()
+        m_b = meta[1]["sequences"]
+        s0 = int(rng.integers(0, max(1, m_b - m_b // 100)))
+        s1 = min(m_b - 1, s0 + max(1, m_b // 100) - 1)
+        pkg.tune("search_algo", 2)
+        whole = pkg.RankArray(A, B); whole.search(A, B, 0, m_b - 1)
+        pkg.tune("search_algo", 1)
+        part = pkg.RankArray(A, B); part.search(A, B, s0, s1)
+        pkg.tune("search_algo", 0)
+        ones, outside = part.subset_check(whole)
+        part.free(); whole.free(); A.free(); B.free()
+        per_seq = meta[1]["bases"] // m_b
+        checks["walk_of_a_shard_inside_frontier"] = bool(outside == 0 and (ones == (s1 - s0 + 1) * per_seq or args.workload != "iid"))
+        checks["walk_shard_sequences"] = int(s1 - s0 + 1)
     return all(v for k, v in checks.items() if isinstance(v, bool)), checks
 
 

@@ -101,6 +101,7 @@ SYMBOLS = [
     ("bwtm_search", C.c_int, [vp, vp, u64, u64, vp]),
     ("bwtm_ra_device_buffer", C.c_int, [vp, C.POINTER(vp), p_u64]),
     ("bwtm_ra_finalize", C.c_int, [vp]),
+    ("bwtm_ra_subset_check", C.c_int, [vp, vp, p_u64, p_u64]),
     ("bwtm_ra_values", u64, [vp]),
     ("bwtm_ra_download", C.c_int, [vp, p_u64, u64]),
     ("bwtm_ra_download_bits", C.c_int, [vp, p_u64, u64]),
@@ -111,6 +112,7 @@ SYMBOLS = [
     ("bwtm_builder_reads", u64, [vp]),
     ("bwtm_builder_finish", C.c_int, [vp, C.POINTER(vp)]),
     ("bwtm_builder_free", None, [vp]),
+    ("bwtm_pool_stats", C.c_int, [vp]),
     ("bwtm_profile_enable", C.c_int, [C.c_int]),
     ("bwtm_profile_only", C.c_int, [C.c_char_p]),
     ("bwtm_profile_reset", C.c_int, []),
@@ -578,6 +580,12 @@ class RankArray:
         ptr, n = other.device_buffer()
         check(lib().bwtm_ra_or_from(self.h, vp(ptr), n))
 
+    def subset_check(self, whole):
+        """(set bits of this array, 64-bit words in which it has a bit that `whole` lacks)."""
+        ones, bad = u64(0), u64(0)
+        check(lib().bwtm_ra_subset_check(self.h, whole.h, C.byref(ones), C.byref(bad)))
+        return int(ones.value), int(bad.value)
+
     def finalize(self):
         check(lib().bwtm_ra_finalize(self.h))
         return self
@@ -755,6 +763,17 @@ class Builder:
             self.free()
         except Exception:
             pass
+
+
+class PoolInfo(C.Structure):
+    _fields_ = [("held_bytes", u64), ("cached_bytes", u64), ("peak_bytes", u64), ("mapped_blocks", u64), ("address_bytes_reserved", u64),
+                ("address_space_exhausted", C.c_int), ("hipmalloc_fallbacks", u64)]
+
+
+def pool_stats():
+    info = PoolInfo()
+    check(lib().bwtm_pool_stats(C.byref(info)))
+    return {k: int(getattr(info, k)) for k, _ in PoolInfo._fields_}
 
 
 def profile_enable(on=True):

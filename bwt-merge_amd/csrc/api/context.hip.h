@@ -60,6 +60,7 @@ struct bwtm_context
   std::vector<hipMemGenericAllocationHandle_t> free_chunks; // physical chunks that are not mapped anywhere
   std::map<void*, VBlock> vblocks;                          // every mapped block, in use or released
   u64 device_total = 0;
+  u64 va_fallbacks = 0;                                     // large blocks that came from hipMalloc because no address range was left
 
   // small page-locked scratch for results read back by the host (a pageable destination would make
   // hipMemcpyAsync stage and block)
@@ -181,7 +182,13 @@ struct Scope
   }
   ~Scope()
   {
-    if(ctx) { t_ctx = prev; ctx->mu.unlock(); }
+    if(ctx)
+    {
+      t_ctx = prev;
+      // a nested scope may have switched the thread to another device: the rest of the outer call must run on its own
+      if(prev && prev->device != ctx->device) { (void)hipSetDevice(prev->device); }
+      ctx->mu.unlock();
+    }
   }
   Scope(const Scope&) = delete; Scope& operator=(const Scope&) = delete;
 };
@@ -285,7 +292,7 @@ struct AddressSpace
   bool exhausted = false;
 };
 AddressSpace g_va;
-constexpr u64 VA_SEGMENT = 8ull << 40, VA_LIMIT = 64ull << 40;
+u64 VA_SEGMENT = 8ull << 40, VA_LIMIT = 64ull << 40;        // BWTM_POOL_VA_SEGMENT / BWTM_POOL_VA_LIMIT (bytes) override them: the tests exhaust a small range
 
 void vmm_setup(bwtm_context* c)
 {
@@ -293,6 +300,8 @@ void vmm_setup(bwtm_context* c)
   if(env && env[0] == '0') { return; }
   if(const char* v = std::getenv("BWTM_POOL_VMM_CHUNK")) { u64 x = std::strtoull(v, nullptr, 10); if(x >= (2ull << 20)) { VMM_CHUNK = x / (2ull << 20) * (2ull << 20); } }
   if(const char* v = std::getenv("BWTM_POOL_VMM_MIN")) { u64 x = std::strtoull(v, nullptr, 10); if(x >= 4096) { VMM_MIN = x; } }
+  if(const char* v = std::getenv("BWTM_POOL_VA_SEGMENT")) { u64 x = std::strtoull(v, nullptr, 10); if(x >= VMM_CHUNK) { VA_SEGMENT = x / VMM_CHUNK * VMM_CHUNK; } }
+  if(const char* v = std::getenv("BWTM_POOL_VA_LIMIT")) { u64 x = std::strtoull(v, nullptr, 10); if(x >= VMM_CHUNK) { VA_LIMIT = x; } }
   size_t free_b = 0, total_b = 0;
   if(hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
   c->device_total = total_b;
@@ -345,7 +354,8 @@ void vmm_harvest(bwtm_context* c, u64 need, bool wait)
     --it;
     auto vb = c->vblocks.find(it->second);
     if(vb == c->vblocks.end()) { continue; }                  // a small hipMalloc block
-    if(!wait && vb->second.released && hipEventQuery(vb->second.released) != hipSuccess) { (void)hipGetLastError(); continue; }
+    // without an event (its creation failed) nothing proves that the GPU is done with the block: only a drained stream does
+    if(!wait && (!vb->second.released || hipEventQuery(vb->second.released) != hipSuccess)) { (void)hipGetLastError(); continue; }
     void* p = it->second;
     c->cached_bytes -= it->first;
     it = c->free_blocks.erase(it);
@@ -437,6 +447,11 @@ hipError_t pool_get(bwtm_context* c, u64 n, void** p, u64* actual)
   if(large)
   {
     hipError_t ve = vmm_alloc(c, n, p);
+    if(ve == hipErrorOutOfMemory && !g_va.exhausted && !c->free_blocks.empty())
+    {
+      pool_trim(c);                       // cached small hipMalloc blocks (and idle chunks) go back to the driver, then once more
+      ve = vmm_alloc(c, n, p);
+    }
     if(ve == hipSuccess || !g_va.exhausted) { return ve; }
     // no addresses left for mapped blocks: give the pooled chunks back to the driver and go on with hipMalloc blocks
     pool_trim(c);
@@ -445,6 +460,7 @@ hipError_t pool_get(bwtm_context* c, u64 n, void** p, u64* actual)
   hipError_t e = hipMalloc(p, n);
   if(e != hipSuccess) { (void)hipGetLastError(); pool_trim(c); e = hipMalloc(p, n); }
   if(e == hipSuccess) { c->held_bytes += n; if(c->held_bytes > c->peak_bytes) { c->peak_bytes = c->held_bytes; } }
+  if(e == hipSuccess && g_va.exhausted && n >= VMM_MIN) { c->va_fallbacks++; }      // a large block that should have been a mapped one
   return e;
 }
 
@@ -635,6 +651,19 @@ extern "C" uint64_t bwtm_device_bytes_peak(int reset)
   u64 peak = CTX.peak_bytes;
   if(reset) { CTX.peak_bytes = CTX.held_bytes; }
   return peak;
+}
+
+extern "C" int bwtm_pool_stats(bwtm_pool_info* info)
+{
+  if(!info) { return fail(BWTM_EINVAL, "bwtm_pool_stats: null argument"); }
+  ENTER(nullptr);
+  info->held_bytes = CTX.held_bytes; info->cached_bytes = CTX.cached_bytes; info->peak_bytes = CTX.peak_bytes;
+  info->mapped_blocks = CTX.vblocks.size(); info->hipmalloc_fallbacks = CTX.va_fallbacks;
+  {
+    std::lock_guard<std::mutex> lock(g_va.mu);
+    info->address_bytes_reserved = g_va.reserved_total; info->address_space_exhausted = (g_va.exhausted ? 1 : 0);
+  }
+  return BWTM_OK;
 }
 
 extern "C" int bwtm_host_alloc(uint64_t nbytes, void** out)

@@ -69,8 +69,12 @@ int ra_make(const bwtm_index* a, const bwtm_index* b, bwtm_ra** out)
 int merge_records(bwtm_index*& a, bwtm_index*& b, bool consume, bwtm_index** out)
 {
   bwtm_ra* ra = nullptr;
-  TRY(ra_make(a, b, &ra));
-  int rc = BWTM_OK;
+  int rc = ra_make(a, b, &ra);
+  if(rc != BWTM_OK)
+  {
+    if(consume) { delete a; delete b; a = nullptr; b = nullptr; }   // "destroying them" holds on every exit path
+    return rc;
+  }
   if(b->m > 0) { rc = bwtm_search(a, b, 0, b->m - 1, ra); }
   if(rc == BWTM_OK) { rc = ra_finalize(ra); }
   if(rc == BWTM_OK) { rc = check_interleave_args(a, b, ra); }
@@ -276,7 +280,8 @@ extern "C" int bwtm_merge_consume(bwtm_index* a, bwtm_index* b, bwtm_index** out
 {
   if(!a || !b || !out) { bwtm_index_free(a); bwtm_index_free(b); return fail(BWTM_EINVAL, "bwtm_merge_consume: null argument"); }
   if(a->ctx != b->ctx) { bwtm_index_free(a); bwtm_index_free(b); return fail(BWTM_EINVAL, "bwtm_merge_consume: the two indexes live in different contexts"); }
-  ENTER(a->ctx);
+  Scope scope_(a->ctx);
+  if(scope_.rc != BWTM_OK) { bwtm_index_free(a); bwtm_index_free(b); return scope_.rc; }      // the inputs are freed also when the call fails
   int rc = bwtm_index_drop_native(a);
   if(rc == BWTM_OK) { rc = bwtm_index_drop_native(b); }
   bwtm_index* x = nullptr;

@@ -520,6 +520,20 @@ extern "C" int bwtm_ra_or_from(bwtm_ra* ra, const void* device_bits, uint64_t nb
   return BWTM_OK;
 }
 
+extern "C" int bwtm_ra_subset_check(bwtm_ra* part, bwtm_ra* whole, uint64_t* part_bits, uint64_t* words_outside)
+{
+  if(!part || !whole || !part_bits || !words_outside) { return fail(BWTM_EINVAL, "bwtm_ra_subset_check: null argument"); }
+  if(part->ctx != whole->ctx || part->n_out != whole->n_out) { return fail(BWTM_EINVAL, "bwtm_ra_subset_check: rank arrays of different contexts or shapes"); }
+  ENTER(part->ctx);
+  const u64 nwords = part->nchunks * CHUNK_WORDS;
+  DevBuf acc; TRY(acc.alloc(2 * sizeof(u64), true));
+  LAUNCH("bits_subset", k_bits_subset, div_up(nwords, BLOCK_THREADS), BLOCK_THREADS, part->bits_as<const u64>(), whole->bits_as<const u64>(), nwords, acc.as<unsigned long long>());
+  TRY(fetch_u64(acc.as<u64>(), 0, 2));
+  HIP_TRY(hipStreamSynchronize(CTX.stream));
+  *part_bits = CTX.host_scratch[0]; *words_outside = CTX.host_scratch[1];
+  return BWTM_OK;
+}
+
 namespace
 {
 int ra_finalize(bwtm_ra* ra)

@@ -28,6 +28,20 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_bits_or(u64* dst, const u64* 
   if(k < nwords) { u64 v = src[k]; if(v != 0) { dst[k] |= v; } }
 }
 
+// Cross-check of two searches: set bits of `part` and the words in which `part` has a bit that `whole` lacks.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_bits_subset(const u64* part, const u64* whole, u64 nwords, unsigned long long* out)
+{
+  u64 k = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  u64 p = (k < nwords ? part[k] : 0), w = (k < nwords ? whole[k] : 0);
+  const u64 ones = wave_sum((u64)__builtin_popcountll(p));
+  const u64 bad = __builtin_popcountll(__ballot((p & ~w) != 0));
+  if(lane_id() == 0)
+  {
+    if(ones != 0) { atomicAdd(out, (unsigned long long)ones); }
+    if(bad != 0) { atomicAdd(out + 1, (unsigned long long)bad); }
+  }
+}
+
 // RA[i] for every B position (tests / facade): one wave per chunk, one lane per record.
 __global__ void __launch_bounds__(BLOCK_THREADS) k_ra_extract(const u64* bits, const u64* chunk_base, u64 nchunks, u64 nb, u64* ra)
 {

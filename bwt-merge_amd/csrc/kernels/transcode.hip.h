@@ -531,11 +531,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_block_field_max(IndexView x, 
 {
   u64 b = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
   u64 m = 0;
-  if(b < nblocks)
-  {
-    u64 f[6], at[6]; block_fields(x, block_start, b, f, at);
-    m = f[0];                                               // the block's length bounds its five counts
-  }
+  if(b < nblocks) { m = block_start[b + 1] - block_start[b]; }     // the block's length bounds its five counts: no rank query needed
   m = wave_max(m);
   if(lane_id() == 0 && m > 0) { atomicMax(out_max, (unsigned long long)m); }
 }

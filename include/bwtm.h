@@ -169,6 +169,10 @@ int bwtm_ra_device_buffer(bwtm_ra* ra, void** device_ptr, uint64_t* nbytes);
    searched into separate buffers, e.g. by two contexts of one GPU); across devices use a collective on
    bwtm_ra_device_buffer().  Blocking. */
 int bwtm_ra_or_from(bwtm_ra* ra, const void* device_bits, uint64_t nbytes);
+/* Cross-check of two searches over the same inputs (e.g. a shard of the sequences walked per chain against the whole collection
+   searched level by level): the number of set bits of `part` and the number of 64-bit words in which `part` has a bit that `whole`
+   lacks (must be 0).  Neither array needs to be finalized. */
+int bwtm_ra_subset_check(bwtm_ra* part, bwtm_ra* whole, uint64_t* part_bits, uint64_t* words_outside);
 /* Finishes the rank array after all bwtm_search() calls / the exchange. */
 int bwtm_ra_finalize(bwtm_ra* ra);
 uint64_t bwtm_ra_values(const bwtm_ra* ra);   /* number of set bits after finalize (must equal bases of b) */
@@ -315,6 +319,20 @@ uint64_t bwtm_builder_reads(const bwtm_builder* builder);
 /* Merges what is left and hands the index over (records only, like bwtm_interleave's result); frees the builder. */
 int bwtm_builder_finish(bwtm_builder* builder, bwtm_index** out);
 void bwtm_builder_free(bwtm_builder* builder);
+
+/* --- the memory pool of the calling thread's context -------------------------------------------
+   Large blocks live in a reserved virtual address range that is consumed and never reused; when no range
+   is left they come from hipMalloc, which is correct but slow when it has to wait for deferred frees: `hipmalloc_fallbacks`
+   counts those blocks, so that a long-lived process can see that it has reached that state. */
+typedef struct
+{
+  uint64_t held_bytes, cached_bytes, peak_bytes;      /* physical memory held / idle in the pool / high-water mark */
+  uint64_t mapped_blocks;                             /* blocks that live in the reserved address range (in use or idle) */
+  uint64_t address_bytes_reserved;                    /* process-wide */
+  int address_space_exhausted;                        /* 1: no further range can be reserved */
+  uint64_t hipmalloc_fallbacks;                       /* large blocks served by hipMalloc since then */
+} bwtm_pool_info;
+int bwtm_pool_stats(bwtm_pool_info* info);
 
 /* --- measurement ----------------------------------------------------------------------------- */
 
