@@ -310,9 +310,11 @@ def main():
     host = None
     dev_in.clear()                                   # the device copies of the inputs are not needed any more
     torch.cuda.empty_cache()
-    if rank == 0 and world == 1 and not args.no_host and nsets == 2:
+    if rank == 0 and not sharded and not args.no_host and nsets == 2:
         host = host_to_host(pkg, np, torch, dev, host_in, meta, args)
-    if rank == 0 and world == 1 and not args.no_host and nsets > 2:
+    if sharded and not args.no_host and nsets == 2:
+        host = host_to_host_sharded(pkg, np, torch, dev, host_in, meta, args, rank, world, dist)       # collective: every rank takes part
+    if rank == 0 and not sharded and not args.no_host and nsets > 2:
         host = host_chain(pkg, np, torch, host_in, meta, args, chain_tail)
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N == 1)
@@ -537,6 +539,51 @@ def host_to_host(pkg, np, torch, dev, host_in, meta, args):
     for bfr in buffers.values():
         bfr.free()
     return host
+
+
+def host_to_host_sharded(pkg, np, torch, dev, host_in, meta, args, rank, world, dist):
+    """SURVEY 8(d)'s T on N GPUs: page-locked inputs -> this rank's byte range of the native result in page-locked memory.  Every
+    native byte crosses PCIe once (each rank uploads 1 / N of both inputs, the parts are all-gathered over xGMI), the sequences
+    of input2 are sharded, the rank arrays are combined by one all-reduce and every rank encodes and downloads its output slice.
+    Data only (the samples of a slice need its successor's first block start; the C++ host downloads them too)."""
+    from bwt_merge_amd.dist import merge_sharded, upload_sharded
+    torch.cuda.empty_cache(); pkg.trim()
+    out_buf, times, phases, from_host = None, [], None, 0
+    for it in range(2 + max(1, args.host_steps)):
+        pkg.synchronize(); torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        A, la = upload_sharded(pkg, host_in[0].array, meta[0]["sequences"], meta[0]["bases"], rank, world, dist, torch, dev)
+        B, lb = upload_sharded(pkg, host_in[1].array, meta[1]["sequences"], meta[1]["bases"], rank, world, dist, torch, dev)
+        t1 = time.perf_counter()
+        S = merge_sharded(pkg, A, B, rank, world, dist, torch, dev)
+        A.free(); B.free()
+        t2 = time.perf_counter()
+        if out_buf is None or out_buf.nbytes < S.nbytes:
+            if out_buf is not None:
+                out_buf.free()
+            out_buf = pkg.HostBuffer(S.nbytes + (1 << 20))
+        S.data_into(out_buf.array)
+        total = S.total_nbytes
+        S.free()
+        pkg.synchronize(); torch.cuda.synchronize(); dist.barrier()
+        t3 = time.perf_counter()
+        t = torch.tensor([t3 - t0, t1 - t0, t2 - t1, t3 - t2], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if it >= 2:
+            times.append(float(t[0].item()))
+            phases = {"ms_upload_allgather_transcode": round(float(t[1].item()) * 1e3, 2), "ms_search_exchange_encode": round(float(t[2].item()) * 1e3, 2),
+                      "ms_download": round(float(t[3].item()) * 1e3, 2)}
+        from_host = la + lb
+        if rank == 0:
+            log("host to host on %d GPUs, round %d: %.1f ms" % (world, it, float(t[0].item()) * 1e3))
+    if out_buf is not None:
+        out_buf.free()
+    merged = meta[0]["bases"] + meta[1]["bases"]
+    sec = sum(times) / len(times)
+    return {"value": round(merged / 1e9 / sec, 4), "unit": "Gbases/s", "ms_per_step": round(sec * 1e3, 2), "ms_each": [round(x * 1e3, 1) for x in times],
+            "phases_ms": phases, "includes": "sharded H2D of both native inputs (1 / N per link) + all-gather, transcode, sharded search, all-reduce, "
+            "interleave + encode of the rank's output slice, D2H of the slice; without the samples",
+            "bytes": {"h2d_this_rank": int(from_host), "h2d_all_inputs": meta[0]["nbytes"] + meta[1]["nbytes"], "d2h_all_ranks": int(total)}}
 
 
 def host_chain(pkg, np, torch, host_in, meta, args, chain_tail):

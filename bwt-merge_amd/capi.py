@@ -663,6 +663,11 @@ class Slice:
         check(lib().bwtm_slice_download_data(self.h, out.ctypes.data_as(p_u8), out.size))
         return out
 
+    def data_into(self, out):
+        """The slice's bytes into a caller-provided uint8 array (e.g. page-locked: HostBuffer.array)."""
+        check(lib().bwtm_slice_download_data(self.h, out.ctypes.data_as(p_u8), out.size))
+        return out[: self.nbytes]
+
     def samples(self, next_block_start):
         nb = self.blocks
         be = np.zeros(nb, dtype=np.uint64)

@@ -43,7 +43,7 @@ int main(int argc, char** argv)
   FMI a, b;
   load(a, argv[1], "plain_default"); load(b, argv[2], "plain_default");
   FMI a2 = a, b2 = b, a3 = a, b3 = b, b4 = b, b5 = b;
-  FMI a6 = a, b6 = b, a7 = a, b7 = b, a8 = a, b8 = b;
+  FMI a6 = a, b6 = b, a7 = a, b7 = b, a8 = a, b8 = b, a9 = a, b9 = b;
   std::vector<byte_type> sa = symbolsOf(a), sb = symbolsOf(b);
   size_type na = a.size(), nb = b.size();
 
@@ -141,12 +141,13 @@ int main(int argc, char** argv)
     CHECK(again.bwt.bytes() == 0);
   }
 
-  // One host thread per GPU (multi_gpu.h).  On this box the "GPUs" are contexts of GPU 0: 1, 2 and 3 threads, each
+  // One host thread per GPU (multi_gpu.h).  On this box the "GPUs" are contexts of GPU 0: 1, 2, 3 and 4 threads, each
   // searching its block of b's sequences and producing its range of the output; same bytes and samples as the single call.
   {
-    std::vector<std::vector<int>> device_lists = { {0}, {0, 0}, {0, 0, 0} };
-    FMI* as[3] = { &a6, &a7, &a8 }; FMI* bs[3] = { &b6, &b7, &b8 };
-    for(size_type k = 0; k < 3; k++)
+    std::vector<std::vector<int>> device_lists = { {0}, {0, 0}, {0, 0, 0}, {0, 0, 0, 0} };
+    FMI* as[4] = { &a6, &a7, &a8, &a9 }; FMI* bs[4] = { &b6, &b7, &b8, &b9 };
+    const size_type input_bytes = a.bwt.bytes() + b.bwt.bytes();
+    for(size_type k = 0; k < 4; k++)
     {
       FMI sharded; MultiGPUTimes times;
       mergeMultiGPU(*as[k], *bs[k], device_lists[k], sharded, &times);
@@ -154,6 +155,9 @@ int main(int argc, char** argv)
       CHECK(sharded.bwt.blockEnds() == merged.bwt.blockEnds());
       for(size_type c = 0; c < 6; c++) { CHECK(sharded.bwt.cumulative(c) == merged.bwt.cumulative(c)); }
       CHECK(sharded.alpha.C == merged.alpha.C && sharded.size() == merged.size() && sharded.sequences() == merged.sequences());
+      // sharded upload: every context receives 1 / G of the native bytes from the host (parts are rounded up to 256 bytes)
+      const size_type G = device_lists[k].size();
+      CHECK(times.host_bytes_gpu0 <= input_bytes / G + 512 && times.host_bytes_gpu0 + 512 * G >= input_bytes / G);
       CHECK(as[k]->bwt.bytes() == 0 && times.total > 0);
     }
   }

@@ -3,8 +3,9 @@
   each bound to its own library context (the reference's ParallelLoop workers, fmi.cpp:351-358, become threads
   that own a GPU each).
 
-    1. every thread uploads both inputs to its GPU (the indexes are replicated: every LF chain touches arbitrary
-       positions of both; eight uploads run on eight PCIe links at once);
+    1. every thread uploads 1 / G of each input's native bytes to its GPU and receives the other parts from its peers
+       (all-gather over xGMI: the PCIe links carry every byte once instead of G times), then decodes and transcodes the
+       complete copy (the indexes are replicated: every LF chain touches arbitrary positions of both);
     2. thread g searches block g of b's sequences (getBounds, utils.cpp:169-187) into its own bitvector;
     3. ONE exchange: all-reduce (sum == or, the bits are disjoint) of the bitvectors -- RCCL over xGMI, called
        directly (ncclAllReduce on the buffer bwtm_ra_device_buffer() exposes);
@@ -53,6 +54,7 @@ private:
 
 struct MultiGPUTimes
 {
+  uint64_t host_bytes_gpu0 = 0;          // native bytes GPU 0 received from the host (sharded upload: 1 / G of both inputs)
   double upload = 0, search = 0, exchange = 0, interleave_encode = 0, download = 0, total = 0;   // seconds, thread 0's view
 };
 
@@ -94,16 +96,70 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
   double t0 = readTimer();
   MultiGPUTimes local;
 
+#ifdef BWTM_WITH_RCCL
+  // One input, sharded over the links: staging[g] = this GPU's full-size device buffer (hipMalloc: peers and RCCL may touch it).
+  std::vector<void*> staging_a(G, nullptr), staging_b(G, nullptr);
+  std::vector<uint64_t> host_bytes_per_gpu(G, 0);
+  auto uploadSharded = [&](const BlockArray& data, size_type sequences, size_type bases, const uint64_t* C, size_type g, std::vector<void*>& staging, ncclComm_t comm) -> bwtm_index*
+  {
+    const uint64_t nbytes = data.size();
+    const uint64_t chunk = ((nbytes + G - 1) / G + 255) / 256 * 256;          // equal parts (the collective wants them), 256-byte aligned
+    const uint64_t off = std::min<uint64_t>(g * chunk, nbytes), len = std::min<uint64_t>(chunk, nbytes - off);
+    auto check = [&](hipError_t e, const char* what) { if(e != hipSuccess) { std::cerr << "mergeMultiGPU(): " << what << ": " << hipGetErrorString(e) << std::endl; std::exit(EXIT_FAILURE); } };
+    check(hipSetDevice(devices[g]), "hipSetDevice");
+    check(hipMalloc(&staging[g], chunk * G + 16), "hipMalloc of the staging buffer");
+    check(hipMemset((char*)staging[g] + nbytes, 0, chunk * G + 16 - nbytes), "hipMemset");      // readable zeros behind the stream
+    if(len > 0) { check(hipMemcpy((char*)staging[g] + off, data.data() + off, len, hipMemcpyHostToDevice), "H2D copy of this GPU's part"); }
+    host_bytes_per_gpu[g] += len;
+    barrier.wait();                                                         // every part is on its device
+    if(comm)
+    {
+      hipStream_t stream = nullptr;
+      check(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+      if(ncclAllGather((char*)staging[g] + g * chunk, staging[g], chunk, ncclUint8, comm, stream) != ncclSuccess) { std::cerr << "mergeMultiGPU(): ncclAllGather failed" << std::endl; std::exit(EXIT_FAILURE); }
+      check(hipStreamSynchronize(stream), "all-gather"); (void)hipStreamDestroy(stream);
+      check(hipMemset((char*)staging[g] + nbytes, 0, chunk * G + 16 - nbytes), "hipMemset");    // the padding of the last part travelled too
+    }
+    else
+    {
+      for(size_type h = 0; h < G; h++)
+      {
+        const uint64_t o = std::min<uint64_t>(h * chunk, nbytes), l = std::min<uint64_t>(chunk, nbytes - o);
+        if(h != g && l > 0) { check(hipMemcpy((char*)staging[g] + o, (const char*)staging[h] + o, l, hipMemcpyDeviceToDevice), "device-to-device copy of a peer's part"); }
+      }
+    }
+    barrier.wait();                                                         // nobody reads a peer's buffer any more
+    bwtm_index* x = nullptr;
+    gpuCheck(bwtm_index_from_device_borrowed(staging[g], nbytes, sequences, bases, C, &x), "mergeMultiGPU()");
+    gpuCheck(bwtm_index_drop_native(x), "mergeMultiGPU()");                 // synchronizes: the staging buffer is free again
+    check(hipFree(staging[g]), "hipFree"); staging[g] = nullptr;
+    return x;
+  };
+#endif
+
   auto worker = [&](size_type g)
   {
     bwtm_context* ctx = nullptr;
     gpuCheck(bwtm_context_create(devices[g], &ctx), "mergeMultiGPU()");
     gpuCheck(bwtm_context_make_current(ctx), "mergeMultiGPU()");
     bwtm_index *A = nullptr, *B = nullptr; bwtm_ra* ra = nullptr; bwtm_slice* slice = nullptr;
-    gpuCheck(bwtm_index_upload(adata.data(), adata.size(), a.sequences(), a.size(), ca.data(), &A), "mergeMultiGPU()");
-    gpuCheck(bwtm_index_drop_native(A), "mergeMultiGPU()");
-    gpuCheck(bwtm_index_upload(bdata.data(), bdata.size(), b.sequences(), b.size(), cb.data(), &B), "mergeMultiGPU()");
-    gpuCheck(bwtm_index_drop_native(B), "mergeMultiGPU()");
+#ifdef BWTM_WITH_RCCL
+    if(G > 1)
+    {
+      // Sharded upload: this GPU's PCIe link carries only 1 / G of each input's native bytes; the other parts arrive from the
+      // peers (all-gather over xGMI, or device-to-device copies between contexts of one GPU); every GPU then decodes and
+      // transcodes its complete device copy (BWT::load, ~9 ms per 5 Gbase input).
+      A = uploadSharded(adata, a.sequences(), a.size(), ca.data(), g, staging_a, (distinct ? comms[g] : nullptr));
+      B = uploadSharded(bdata, b.sequences(), b.size(), cb.data(), g, staging_b, (distinct ? comms[g] : nullptr));
+    }
+    else
+#endif
+    {
+      gpuCheck(bwtm_index_upload(adata.data(), adata.size(), a.sequences(), a.size(), ca.data(), &A), "mergeMultiGPU()");
+      gpuCheck(bwtm_index_drop_native(A), "mergeMultiGPU()");
+      gpuCheck(bwtm_index_upload(bdata.data(), bdata.size(), b.sequences(), b.size(), cb.data(), &B), "mergeMultiGPU()");
+      gpuCheck(bwtm_index_drop_native(B), "mergeMultiGPU()");
+    }
     if(g == 0) { local.upload = readTimer() - t0; }
 
     // Across devices the bitvector is handed to ncclAllReduce, which (all ranks in one process) may let a peer GPU read or write the
@@ -223,6 +279,11 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
   result.alpha = merged;
   a.bwt.clear(); b.bwt.clear();
   local.total = readTimer() - t0;
+#ifdef BWTM_WITH_RCCL
+  local.host_bytes_gpu0 = (G > 1 ? host_bytes_per_gpu[0] : adata.size() + bdata.size());
+#else
+  local.host_bytes_gpu0 = adata.size() + bdata.size();
+#endif
   if(times) { *times = local; }
 }
 

@@ -84,6 +84,27 @@ def exchange_encoder_carries(lasthead, size_table_fn, rank, world, dist, torch, 
     return heads_before, offsets[rank], offsets[world]
 
 
+def upload_sharded(pkg, host_array, sequences, bases, rank, world, dist, torch, device):
+    """BWT::load of one input on `world` GPUs with every native byte crossing PCIe ONCE: this rank copies its 1 / world of the
+    page-locked bytes to its GPU, the parts are all-gathered over xGMI (RCCL) into every rank's full-size buffer, and the rank
+    decodes / transcodes its complete device copy.  Returns (index, bytes this rank received from the host)."""
+    nbytes = int(host_array.size)
+    chunk = ((nbytes + world - 1) // world + 255) // 256 * 256
+    full = torch.empty(chunk * world + 16, dtype=torch.uint8, device=device)
+    off = min(rank * chunk, nbytes)
+    length = min(chunk, nbytes - off)
+    if length > 0:
+        full[off: off + length].copy_(torch.from_numpy(host_array[off: off + length]), non_blocking=True)
+    if dist is not None and world > 1:
+        dist.all_gather_into_tensor(full[: chunk * world], full[rank * chunk: (rank + 1) * chunk])     # in place
+    full[nbytes:].zero_()                                    # the borrowed form wants readable zeros behind the stream
+    torch.cuda.synchronize()
+    ix = pkg.Index.from_device(full.data_ptr(), nbytes, sequences, bases, borrow=True)
+    ix.drop_native()                                         # synchronizes: `full` may go
+    del full
+    return ix, length
+
+
 def merge_sharded(pkg, A, B, rank, world, dist, torch, device):
     """FMI::FMI(a, b) on `world` GPUs, as this rank sees it: search of its block of b's sequences, all-reduce of the
     rank-array bitvector (RCCL over xGMI), then interleave + encode of its own slice of the output.  Returns the

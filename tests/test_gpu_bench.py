@@ -41,7 +41,9 @@ def test_bench_distributed_path_on_one_rank(bwtm):
     d = run_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                    "--master-port", "29517", "bench.py", "--gpus", "1", "--force-dist", "--reads", "200000", "--steps", "2", "--warmup", "1",
                    "--no-cpu-baseline"])
-    assert d["value"] > 0 and d["config"]["native_bytes"][2] > 0 and d["verified"] is True
+    assert d["value"] > 0 and d["config"]["native_bytes"][2] > 0 and d["verified"] is True and d["rccl_ranks"] == 1
+    h = d["host_to_host"]                     # the N-GPU host-to-host leg (sharded upload + all-gather, slice download) on its one rank
+    assert h["value"] > 0 and h["bytes"]["h2d_this_rank"] == h["bytes"]["h2d_all_inputs"] and h["bytes"]["d2h_all_ranks"] == d["config"]["native_bytes"][2]
 
 
 def test_bench_chained_merge_of_four_sets(bwtm):
