@@ -76,6 +76,12 @@ def main():
         # relays rank 0's JSON line.
         sys.exit(launch_ranks(args.gpus))
 
+    # stdout carries the ONE JSON line and nothing else: native libraries (RCCL prints a version banner through C stdio) are sent
+    # to stderr by pointing file descriptor 1 there; the line itself goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -347,7 +353,7 @@ def main():
             "host_to_host": host, "peak_device_bytes": peak_device,
             "cpu_baseline": cpu, "verified": verified, "verification": checks,
         }
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

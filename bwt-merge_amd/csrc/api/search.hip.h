@@ -403,13 +403,27 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
     f.seg_len_next = seg_len[1 - cur].as<u64>(); f.seg_phys_next = seg_phys[1 - cur].as<u64>();
     f.nb_max = nb_max;
     f.emit16 = emit16.as<unsigned short>(); f.emit_base = emit_base.as<const u64>(); f.emit_cap = emit_cap; f.bits32 = ra->bits_as<u32>();
-    f.bound_row = bound.as<u32>() + in_epoch * (ntiles + 1); f.step = in_epoch;
+    f.bound_row = bound.as<u32>() + in_epoch * (ntiles + 1); f.step = in_epoch; f.block_base = 0;
 #ifdef BWTM_DIAGNOSTICS
     if(g_tune.walk_emit == 1 && wide) { LAUNCH("frontier_step_noemit", (k_frontier_step<1, true>), nb_max, FR_BLOCK, a->view(), b->view(), f); }
     else if(g_tune.walk_emit == 1) { LAUNCH("frontier_step_noemit", (k_frontier_step<1, false>), nb_max, FR_BLOCK, a->view(), b->view(), f); }
     else
 #endif
-    if(wide) { LAUNCH("frontier_step", (k_frontier_step<0, true>), nb_max, FR_BLOCK, a->view(), b->view(), f); }
+    if(g_tune.frontier_parts > 1)
+    {
+      // Measurement of the dense multi-GPU model: the step as `frontier_parts` launches, each over a
+      // contiguous slice of the sorted frontier -- what one GPU of a position-sliced search would run.  Same results.
+      const u64 parts = (u64)g_tune.frontier_parts, per = div_up(nb_max, parts);
+      for(u64 part = 0; part < parts && part * per < nb_max; part++)
+      {
+        f.block_base = (u32)(part * per);
+        const u64 nb_part = std::min<u64>(per, nb_max - part * per);
+        const char* label = (part == 0 ? "frontier_step_slice0" : "frontier_step_slices");
+        if(wide) { LAUNCH(label, (k_frontier_step<0, true>), nb_part, FR_BLOCK, a->view(), b->view(), f); }
+        else { LAUNCH(label, (k_frontier_step<0, false>), nb_part, FR_BLOCK, a->view(), b->view(), f); }
+      }
+    }
+    else if(wide) { LAUNCH("frontier_step", (k_frontier_step<0, true>), nb_max, FR_BLOCK, a->view(), b->view(), f); }
     else { LAUNCH("frontier_step", (k_frontier_step<0, false>), nb_max, FR_BLOCK, a->view(), b->view(), f); }
     cur = 1 - cur;
     in_epoch++; epoch_used += alive_bound;

@@ -146,10 +146,10 @@ int main(int argc, char** argv)
   {
     std::vector<std::vector<int>> device_lists = { {0}, {0, 0}, {0, 0, 0}, {0, 0, 0, 0} };
     FMI* as[4] = { &a6, &a7, &a8, &a9 }; FMI* bs[4] = { &b6, &b7, &b8, &b9 };
-    const size_type input_bytes = a.bwt.bytes() + b.bwt.bytes();
     for(size_type k = 0; k < 4; k++)
     {
       FMI sharded; MultiGPUTimes times;
+      const size_type input_bytes = as[k]->bwt.bytes() + bs[k]->bwt.bytes();
       mergeMultiGPU(*as[k], *bs[k], device_lists[k], sharded, &times);
       CHECK(sharded.bwt.data.bytes == expected);
       CHECK(sharded.bwt.blockEnds() == merged.bwt.blockEnds());

@@ -74,6 +74,7 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
   for(size_type c = 0; c <= merged.sigma; c++) { merged.C[c] += b.alpha.C[c]; }
   const BlockArray& adata = a.bwt.hostData(); const BlockArray& bdata = b.bwt.hostData();
   a.bwt.dropDevice(); b.bwt.dropDevice();
+  const uint64_t input_bytes = adata.size() + bdata.size();
   std::vector<uint64_t> ca(a.alpha.C.begin(), a.alpha.C.end()), cb(b.alpha.C.begin(), b.alpha.C.end());
   std::vector<range_type> blocks = (b.sequences() > 0 ? getBounds(range_type(0, b.sequences() - 1), G) : std::vector<range_type>());
 
@@ -279,10 +280,9 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
   result.alpha = merged;
   a.bwt.clear(); b.bwt.clear();
   local.total = readTimer() - t0;
+  local.host_bytes_gpu0 = input_bytes;
 #ifdef BWTM_WITH_RCCL
-  local.host_bytes_gpu0 = (G > 1 ? host_bytes_per_gpu[0] : adata.size() + bdata.size());
-#else
-  local.host_bytes_gpu0 = adata.size() + bdata.size();
+  if(G > 1) { local.host_bytes_gpu0 = host_bytes_per_gpu[0]; }
 #endif
   if(times) { *times = local; }
 }

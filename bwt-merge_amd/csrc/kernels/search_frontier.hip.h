@@ -45,6 +45,7 @@ struct FrontierView
   u32* bits32;                                 // the bitvector (fallback path only)
   u32* bound_row;                              // this step's row of tile boundaries: [ntiles + 1], pre-set to ~0
   u64 step;
+  u32 block_base;                              // first block of this launch (0 unless the step is launched in slices)
 };
 
 __global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_init(uint2* lo, unsigned short* hi, u64* seg_len, u64* seg_phys, u64 nb_max,
@@ -98,18 +99,19 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
   __shared__ u64 s_prefix[FR_SEGS + 1], s_phys[FR_SEGS + 1];
   const u64 nseg = 5 * f.nb_max;
   const u64 N = f.seg_prefix[nseg];
-  const u64 g0 = (u64)blockIdx.x * FR_BLOCK;
+  const u32 bid = blockIdx.x + f.block_base;                      // a launch may cover a range of the step's blocks (one slice of the frontier)
+  const u64 g0 = (u64)bid * FR_BLOCK;
   const u32 lane = lane_id(), wave = threadIdx.x >> 6;
 
   // Blocks past the frontier only publish empty segments.
   if(g0 >= N)
   {
-    if(threadIdx.x < 5) { f.seg_len_next[(u64)threadIdx.x * f.nb_max + blockIdx.x] = 0; f.seg_phys_next[(u64)threadIdx.x * f.nb_max + blockIdx.x] = g0; }
-    if(blockIdx.x == 0 && threadIdx.x == 5) { f.seg_len_next[nseg] = 0; }
+    if(threadIdx.x < 5) { f.seg_len_next[(u64)threadIdx.x * f.nb_max + bid] = 0; f.seg_phys_next[(u64)threadIdx.x * f.nb_max + bid] = g0; }
+    if(bid == 0 && threadIdx.x == 5) { f.seg_len_next[nseg] = 0; }
     return;
   }
   // The block's elements live in a handful of segments: stage their table entries in LDS.
-  const u64 first_seg = f.first_seg[blockIdx.x];
+  const u64 first_seg = f.first_seg[bid];
   if(threadIdx.x <= FR_SEGS)
   {
     u64 sidx = first_seg + threadIdx.x; if(sidx > nseg) { sidx = nseg; }
@@ -262,10 +264,10 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
     for(u32 k = 1; k < 6; k++) { if(k == kk) { tot = tot_k[k]; } if(k < kk) { base_k += tot_k[k]; } }
     if(kk < 6)
     {
-      f.seg_len_next[(u64)(kk - 1) * f.nb_max + blockIdx.x] = tot;
-      f.seg_phys_next[(u64)(kk - 1) * f.nb_max + blockIdx.x] = g0 + base_k;
+      f.seg_len_next[(u64)(kk - 1) * f.nb_max + bid] = tot;
+      f.seg_phys_next[(u64)(kk - 1) * f.nb_max + bid] = g0 + base_k;
     }
-    if(blockIdx.x == 0 && threadIdx.x == 5) { f.seg_len_next[nseg] = 0; }
+    if(bid == 0 && threadIdx.x == 5) { f.seg_len_next[nseg] = 0; }
   }
   if(mark_first) { atomicMin(&f.bound_row[tile_first], (u32)g); }
 }
