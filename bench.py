@@ -436,6 +436,8 @@ def verify_full_size(pkg, synth, np, last, meta, args, wargs, load_inputs):
         # Too large for two full bitvectors on the host: the level-synchronous search of the WHOLE collection against the per-chain
         # walk of a 1 % block of its sequences, compared on the device -- every bit the walk sets must be set by the frontier
         # search, and the walk must set exactly one bit per position of its sequences.
+        last.free()                                            # the result (126 GB at 2 x 50 Gbase) makes room for a second pair of record arrays
+        pkg.trim()
         A, B = load_inputs()
         m_b = meta[1]["sequences"]
         s0 = int(rng.integers(0, max(1, m_b - m_b // 100)))

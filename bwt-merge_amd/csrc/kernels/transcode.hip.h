@@ -529,9 +529,14 @@ __device__ inline void block_fields(const IndexView& x, const u64* block_start, 
 
 __global__ void __launch_bounds__(BLOCK_THREADS) k_block_field_max(IndexView x, const u64* block_start, u64 nblocks, unsigned long long* out_max)
 {
-  u64 b = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  // grid-stride: one atomic per wave of a few thousand waves (one per 64 blocks of the stream was two million atomics on ONE address,
+  // 10 - 17 ms at config 2 -- more than the download of the fields it sizes)
   u64 m = 0;
-  if(b < nblocks) { m = block_start[b + 1] - block_start[b]; }     // the block's length bounds its five counts: no rank query needed
+  for(u64 b = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x; b < nblocks; b += (u64)gridDim.x * BLOCK_THREADS)
+  {
+    const u64 len = block_start[b + 1] - block_start[b];            // the block's length bounds its five counts: no rank query needed
+    m = (len > m ? len : m);
+  }
   m = wave_max(m);
   if(lane_id() == 0 && m > 0) { atomicMax(out_max, (unsigned long long)m); }
 }
