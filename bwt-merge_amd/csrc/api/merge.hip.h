@@ -202,7 +202,13 @@ int merge_host_impl(bwtm_index* a_dev, const bwtm_host_input* a_host, const bwtm
     else { TRY(encode_blocking(x)); }
     plan_holder.reset();                                           // the size tables return to the pool
     int width = 8;
-    if(want_samples == BWTM_SAMPLES_COMPACT) { TRY(samples_width(x, &width)); }      // queued behind the encoder; its wait overlaps with the data's D2H
+    if(want_samples == BWTM_SAMPLES_COMPACT)
+    {
+      // after the data has left: queued behind the encoder it cost ~10 ms of the download (its small result copy and the pinned
+      // allocations of the caller share the link with the 128-MiB chunks); on its own it takes 0.2 ms
+      HIP_TRY(hipStreamSynchronize(CTX.copy_stream));
+      TRY(samples_width(x, &width));
+    }
     if(want_samples && width == 8)
     {
       out->block_end = (u64*)alloc(user, BWTM_BUF_BLOCK_END, out->blocks * sizeof(u64));
