@@ -101,6 +101,13 @@ SYMBOLS = [
     ("bwtm_search", C.c_int, [vp, vp, u64, u64, vp]),
     ("bwtm_ra_device_buffer", C.c_int, [vp, C.POINTER(vp), p_u64]),
     ("bwtm_ra_finalize", C.c_int, [vp]),
+    ("bwtm_fslice_create", C.c_int, [vp, vp, vp, u64, C.c_int, C.POINTER(vp)]),
+    ("bwtm_fslice_free", None, [vp]),
+    ("bwtm_fslice_seed", C.c_int, [vp, u64, u64]),
+    ("bwtm_fslice_export", C.c_int, [vp, vp]),
+    ("bwtm_fslice_gather", C.c_int, [vp, vp, C.c_int, u64, u64]),
+    ("bwtm_fslice_advance", C.c_int, [vp]),
+    ("bwtm_fslice_finish", C.c_int, [vp]),
     ("bwtm_ra_subset_check", C.c_int, [vp, vp, p_u64, p_u64]),
     ("bwtm_ra_values", u64, [vp]),
     ("bwtm_ra_download", C.c_int, [vp, p_u64, u64]),
@@ -679,6 +686,45 @@ class Slice:
         out = np.zeros(count, dtype=np.uint8)
         check(lib().bwtm_slice_extract(self.h, first, count, out.ctypes.data_as(p_u8)))
         return out
+
+
+class FSliceView(C.Structure):
+    _fields_ = [("lo", vp), ("hi", vp), ("prefix", vp), ("phys", vp), ("blocks", u64), ("totals", u64 * 5)]
+
+
+class FSlice:
+    """One GPU's state of the sliced frontier search (bwtm_fslice; include/bwtm.h)."""
+
+    def __init__(self, a, b, ra, capacity, parts):
+        out = vp()
+        check(lib().bwtm_fslice_create(a.h, b.h, ra.h, capacity, parts, C.byref(out)))
+        self.h = out
+
+    def free(self):
+        if self.h:
+            lib().bwtm_fslice_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def seed(self, seq_first, count):
+        check(lib().bwtm_fslice_seed(self.h, seq_first, count))
+
+    def export(self, view):
+        check(lib().bwtm_fslice_export(self.h, C.byref(view)))
+
+    def gather(self, views, parts, first, last):
+        check(lib().bwtm_fslice_gather(self.h, C.byref(views), parts, first, last))
+
+    def advance(self):
+        check(lib().bwtm_fslice_advance(self.h))
+
+    def finish(self):
+        check(lib().bwtm_fslice_finish(self.h))
 
 
 def merged_records(a, b):

@@ -28,7 +28,9 @@ static void printUsage()
   std::cerr << "  -o format     Write the output in the given format (default: native)" << std::endl;
   std::cerr << "  -g N[,M,...]  Use GPU N (default: 0), or one host thread per listed GPU: the sequences of the increment are" << std::endl;
   std::cerr << "                sharded over them and every GPU produces its range of the output" << std::endl;
-  std::cerr << "                (the buffer options have no effect on the device)" << std::endl << std::endl;
+  std::cerr << "                (the buffer options have no effect on the device)" << std::endl;
+  std::cerr << "  -S            With several GPUs: sliced search (every GPU advances a contiguous slice of the sorted frontier" << std::endl;
+  std::cerr << "                instead of a block of sequences; prototype)" << std::endl << std::endl;
   printFormats(std::cerr);
 }
 
@@ -72,13 +74,15 @@ static void verifyFMI(const FMI& fmi, const std::string& name, const std::vector
   std::cout << std::endl;
 }
 
+static bool sliced_search = false;      // -S: with several GPUs, every GPU advances a slice of the sorted frontier (multi_gpu.h)
+
 static void merge(FMI& index, FMI& increment, const MergeParameters& parameters, const std::vector<int>& devices)
 {
   double increment_mb = inMegabytes(increment.size());
   double start = readTimer();
   if(devices.size() > 1)
   {
-    FMI temp; mergeMultiGPU(index, increment, devices, temp);      // one host thread per GPU, result assembled on the host
+    FMI temp; mergeMultiGPU(index, increment, devices, temp, nullptr, sliced_search);      // one host thread per GPU, result assembled on the host
     index.swap(temp);
   }
   else
@@ -103,7 +107,7 @@ int main(int argc, char** argv)
   MergeParameters parameters;
   std::string pattern_name, output_format;
   std::vector<std::string> input_formats;
-  while((c = getopt(argc, argv, "b:m:r:s:t:d:v:i:o:g:")) != -1)
+  while((c = getopt(argc, argv, "b:m:r:s:t:d:v:i:o:g:S")) != -1)
   {
     switch(c)
     {
@@ -119,6 +123,7 @@ int main(int argc, char** argv)
         for(std::string token; std::getline(ss, token, ','); ) { devices.push_back(std::stoi(token)); }
       }
       break;
+    case 'S': sliced_search = true; break;
     case 'v': pattern_name = optarg; verify = true; break;
     case 'i':
       {

@@ -43,7 +43,7 @@ int main(int argc, char** argv)
   FMI a, b;
   load(a, argv[1], "plain_default"); load(b, argv[2], "plain_default");
   FMI a2 = a, b2 = b, a3 = a, b3 = b, b4 = b, b5 = b;
-  FMI a6 = a, b6 = b, a7 = a, b7 = b, a8 = a, b8 = b, a9 = a, b9 = b;
+  FMI a6 = a, b6 = b, a7 = a, b7 = b, a8 = a, b8 = b, a9 = a, b9 = b, a10 = a, b10 = b;
   std::vector<byte_type> sa = symbolsOf(a), sb = symbolsOf(b);
   size_type na = a.size(), nb = b.size();
 
@@ -160,6 +160,15 @@ int main(int argc, char** argv)
       CHECK(times.host_bytes_gpu0 <= input_bytes / G + 512 && times.host_bytes_gpu0 + 512 * G >= input_bytes / G);
       CHECK(as[k]->bwt.bytes() == 0 && times.total > 0);
     }
+  }
+
+  // The same with the sliced frontier search: three contexts, each advancing a slice of the sorted frontier.
+  {
+    FMI sliced; MultiGPUTimes times;
+    mergeMultiGPU(a10, b10, std::vector<int>({0, 0, 0}), sliced, &times, true);
+    CHECK(sliced.bwt.data.bytes == expected);
+    CHECK(sliced.bwt.blockEnds() == merged.bwt.blockEnds());
+    for(size_type c = 0; c < 6; c++) { CHECK(sliced.bwt.cumulative(c) == merged.bwt.cumulative(c)); }
   }
 
   // Native file round trip.

@@ -59,7 +59,11 @@ struct MultiGPUTimes
 };
 
 // Merges a and b (both consumed) into `result` using the given devices.
-inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& result, MultiGPUTimes* times = nullptr)
+// sliced = false: GPU g searches block g of b's sequences (bwtm_search).  sliced = true: the sliced frontier search (bwtm_fslice_*,
+// include/bwtm.h): GPU g advances slice g of the sorted frontier and pulls its next slice from all GPUs' outputs -- every GPU
+// then streams 1 / G of both rank structures per LF step instead of a thinned 100 % (prototype: contexts of one GPU, or devices
+// with peer access).
+inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& result, MultiGPUTimes* times = nullptr, bool sliced = false)
 {
   if(a.alpha != b.alpha)
   {
@@ -93,6 +97,7 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
   std::vector<void*> bits(G, nullptr); std::vector<uint64_t> bits_bytes(G, 0);
   std::vector<uint64_t> heads(G, 0), tables(G * 64, 0), offsets(G + 1, 0), first_block_start(G, ~(uint64_t)0);
   std::vector<uint64_t> block_first(G, 0), block_count(G, 0);
+  std::vector<bwtm_fslice_view> views(G);
   BWT& out = result.bwt;
   double t0 = readTimer();
   MultiGPUTimes local;
@@ -178,7 +183,30 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
 #endif
     }
     else { gpuCheck(bwtm_ra_create(A, B, &ra), "mergeMultiGPU()"); }
-    if(g < blocks.size()) { gpuCheck(bwtm_search(A, B, blocks[g].first, blocks[g].second, ra), "mergeMultiGPU()"); }
+    if(sliced && b.sequences() > 0)
+    {
+      const uint64_t capacity = (b.sequences() + G - 1) / G + 1;
+      bwtm_fslice* fs = nullptr;
+      gpuCheck(bwtm_fslice_create(A, B, ra, capacity, (int)G, &fs), "mergeMultiGPU()");
+      gpuCheck(bwtm_fslice_seed(fs, (g < blocks.size() ? blocks[g].first : 0), (g < blocks.size() ? blocks[g].second - blocks[g].first + 1 : 0)), "mergeMultiGPU()");
+      gpuCheck(bwtm_fslice_export(fs, &views[g]), "mergeMultiGPU()");
+      barrier.wait();
+      while(true)
+      {
+        uint64_t total = 0;
+        for(size_type h = 0; h < G; h++) { for(int c = 0; c < 5; c++) { total += views[h].totals[c]; } }
+        if(total == 0) { break; }
+        const uint64_t per = (total + G - 1) / G, first = std::min<uint64_t>(total, g * per), last = std::min<uint64_t>(total, (g + 1) * per);
+        gpuCheck(bwtm_fslice_gather(fs, views.data(), (int)G, first, last), "mergeMultiGPU()");
+        barrier.wait();                                            // every GPU has pulled its slice: the outputs may be overwritten
+        gpuCheck(bwtm_fslice_advance(fs), "mergeMultiGPU()");
+        gpuCheck(bwtm_fslice_export(fs, &views[g]), "mergeMultiGPU()");
+        barrier.wait();                                            // every GPU's new outputs and totals are visible
+      }
+      gpuCheck(bwtm_fslice_finish(fs), "mergeMultiGPU()");
+      bwtm_fslice_free(fs);
+    }
+    else if(g < blocks.size()) { gpuCheck(bwtm_search(A, B, blocks[g].first, blocks[g].second, ra), "mergeMultiGPU()"); }
     gpuCheck(bwtm_ra_device_buffer(ra, &bits[g], &bits_bytes[g]), "mergeMultiGPU()");      // synchronizes: the search is done
     if(g == 0) { local.search = readTimer() - t0 - local.upload; }
 

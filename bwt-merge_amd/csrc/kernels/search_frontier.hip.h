@@ -516,3 +516,42 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_tile_build_frontier(const uns
     if(w < nwords && v != 0) { bits[w] = old[r] | v; }
   }
 }
+
+//------------------------------------------------------------------------------
+// Sliced frontier (the dense multi-GPU form of the search).  The sorted frontier F_t is cut into G contiguous
+// slices, one per GPU: a slice touches a contiguous range of B's AND of A's records (both coordinates are monotone along the
+// frontier), so every GPU streams 1 / G of the records instead of a thinned 100 %.  The elements a GPU produces in a step belong
+// anywhere in F_{t+1} (stable split by class over ALL GPUs): the logical order of F_{t+1} is (class, GPU, block), and a GPU's next
+// slice is assembled from up to 5 G contiguous PIECES of its peers' outputs, read through their segment tables.
+//
+// k_frontier_gather pulls one GPU's slice into a contiguous local buffer (the layout k_frontier_init produces), after which the
+// unchanged k_frontier_step runs on it.  (A production version would fold the gather into the step kernel's prologue.)
+struct SlicePiece
+{
+  const uint2* lo; const unsigned short* hi;     // the source GPU's output coordinates (physical layout)
+  const u64* prefix;                             // exclusive scan of the source's segment lengths (class-major, 5 nbl + 1 entries)
+  const u64* phys;                               // physical start of every segment of the source
+  u64 seg_first, seg_count;                      // the class's entries in those tables
+  u64 src_first;                                 // index, inside the (class, GPU) piece, of the first element taken
+  u64 count;                                     // elements taken
+  u64 dst_first;                                 // where they go in this GPU's input
+};
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_gather(const SlicePiece* pieces, u32 npieces, u64 n_in, uint2* lo_in, unsigned short* hi_in)
+{
+  const u64 j = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(j >= n_in) { return; }
+  u32 q = 0;
+  for(u32 k = 1; k < npieces; k++) { if(pieces[k].dst_first <= j) { q = k; } }      // pieces are sorted by dst_first; at most 5 G of them
+  const SlicePiece pc = pieces[q];
+  const u64 x = pc.prefix[pc.seg_first] + pc.src_first + (j - pc.dst_first);        // position in the source's scanned order
+  u64 lo_s = pc.seg_first, hi_s = pc.seg_first + pc.seg_count;                       // prefix[lo_s] <= x < prefix[hi_s]
+  while(hi_s - lo_s > 1)
+  {
+    const u64 mid = (lo_s + hi_s) >> 1;
+    if(pc.prefix[mid] <= x) { lo_s = mid; } else { hi_s = mid; }
+  }
+  const u64 at = pc.phys[lo_s] + (x - pc.prefix[lo_s]);
+  lo_in[j] = pc.lo[at];
+  if(hi_in) { hi_in[j] = pc.hi[at]; }
+}

@@ -105,6 +105,53 @@ def upload_sharded(pkg, host_array, sequences, bases, rank, world, dist, torch, 
     return ix, length
 
 
+def slice_range(total, part, parts):
+    """Contiguous share `part` of `total` frontier elements: [first, last)."""
+    per = (total + parts - 1) // parts
+    return min(total, part * per), min(total, (part + 1) * per)
+
+
+def search_sliced(pkg, indexes, ras, sequences, enter=None):
+    """The sliced frontier search driven from ONE host thread over `parts` GPUs (or contexts of one GPU): indexes[g] = (A, B) as
+    GPU g holds them, ras[g] = its rank array; enter(g) makes GPU g's context current for the calling thread (None: one context).
+    Every GPU ends up with the bits of the elements it advanced; combine the rank arrays as after bwtm_search().  Returns the
+    number of LF steps.  (A host thread or process per GPU would run the same loop with barriers where this one switches GPUs.)"""
+    parts = len(indexes)
+    cap = (sequences + parts - 1) // parts + 1
+    views = (pkg.FSliceView * parts)()
+    fs = []
+    for g in range(parts):
+        if enter:
+            enter(g)
+        f = pkg.FSlice(indexes[g][0], indexes[g][1], ras[g], cap, parts)
+        first, last = shard_range(sequences, g, parts)
+        f.seed(first, (last - first + 1) if first <= last else 0)
+        f.export(views[g])
+        fs.append(f)
+    steps = 0
+    while True:
+        total = sum(int(views[h].totals[c]) for h in range(parts) for c in range(5))
+        if total == 0:
+            break
+        for g in range(parts):                              # every GPU pulls its slice of the frontier from all GPUs' outputs ...
+            if enter:
+                enter(g)
+            first, last = slice_range(total, g, parts)
+            fs[g].gather(views, parts, first, last)
+        for g in range(parts):                              # ... and only then overwrites its own outputs
+            if enter:
+                enter(g)
+            fs[g].advance()
+            fs[g].export(views[g])
+        steps += 1
+    for g in range(parts):
+        if enter:
+            enter(g)
+        fs[g].finish()
+        fs[g].free()
+    return steps
+
+
 def merge_sharded(pkg, A, B, rank, world, dist, torch, device):
     """FMI::FMI(a, b) on `world` GPUs, as this rank sees it: search of its block of b's sequences, all-reduce of the
     rank-array bitvector (RCCL over xGMI), then interleave + encode of its own slice of the output.  Returns the

@@ -36,7 +36,7 @@ def intersect(a, b):
     return acc
 
 
-def main():
+def main():  # noqa: C901
     kpath, cpath = sys.argv[1], sys.argv[2]
     all_kernels = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(kpath))]
     kernels = [k for k in all_kernels if "bwtm::" in k[2]]
