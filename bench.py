@@ -228,6 +228,11 @@ def main():
     dom_ms, dom_launches = prof.get(dom, (0.0, 0))
     searches = max(1, args.steps)
     units_per_search = ((seq_last - seq_first + 1) / max(1, m_b) * n_b if seq_first <= seq_last else 0) if nsets == 2 else searched_bases
+    # LF steps taken on trie NODES (k_range_step, one launch per level) are not this kernel's: every sequence of the shard is alive on
+    # each of those first levels (they are far fewer than the shortest read is long), so they account for levels x sequences steps
+    node_levels = (prof_all.get("range_step", (0.0, 0))[1] / prof_all_steps / max(1, nsets - 1)) if dom == "frontier_step" else 0
+    if nsets == 2 and dom == "frontier_step":
+        units_per_search = max(0.0, units_per_search - node_levels * (seq_last - seq_first + 1))
     launches_per_search = dom_launches / searches if dom_launches else 0
     avg_launch_s = (dom_ms / 1e3 / dom_launches) if dom_launches else float("nan")
     units_per_launch = units_per_search / launches_per_search if launches_per_search else 0
@@ -278,6 +283,7 @@ def main():
                 "design_floor_bytes_per_launch": (round(floor_bytes) if floor_bytes else None),
                 "traffic_over_design_floor": (round(traffic / floor_bytes, 3) if traffic and floor_bytes else None),
                 "copy_ceiling_GBs": 6290.0, "frac_of_copy_ceiling": round(frac * HBM_PEAK_GBS / 6290.0, 4),
+                "node_levels": round(node_levels, 2), "lf_steps_of_this_kernel_per_step": int(units_per_search),
                 "launches_per_step": round(launches_per_search, 2), "avg_launch_ms": round(avg_launch_s * 1e3, 4),
                 "kernel_ms_per_step": round(dom_ms / searches, 3)}
     kernel_ms = {name: round(ms / prof_all_steps, 3) for name, (ms, n) in sorted(prof_all.items(), key=lambda kv: -kv[1][0])}
