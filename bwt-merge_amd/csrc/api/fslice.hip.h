@@ -188,7 +188,7 @@ extern "C" int bwtm_fslice_advance(bwtm_fslice* fs)
     LAUNCH("scan_reduce", k_scan_reduce<0>, scan_tiles, BLOCK_THREADS, fs->seg_len_in.as<const u64>(), fs->scan_partial.as<u64>(), nseg + 1, (u64)0, scan_tiles);
   }
   LAUNCH("frontier_scan", k_frontier_scan, scan_tiles, BLOCK_THREADS, fs->seg_len_in.as<const u64>(), fs->scan_partial.as<const u64>(), nseg,
-    fs->seg_prefix_in.as<u64>(), fs->first_seg.as<u32>(), fs->emit_base.as<u64>(), fs->in_epoch);
+    fs->seg_prefix_in.as<u64>(), fs->first_seg.as<u32>(), fs->emit_base.as<u64>(), fs->in_epoch, (u64*)nullptr);
   FrontierView f;
   f.lo = fs->lo_in.as<const uint2>(); f.hi = fs->hi_in.as<const unsigned short>();
   f.lo_next = fs->lo_out; f.hi_next = fs->hi_out;

@@ -367,8 +367,18 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   int cur = 0;
   u64 in_epoch = 0;
   u64 alive_bound = count, epoch_used = 0;                         // N_t <= alive_bound; emits reserved in this epoch so far
+  u64* host_ring = nullptr;                                        // device-visible address of host_scratch[64 ..): the ring of frontier sizes
+  HIP_TRY(hipHostGetDevicePointer((void**)&host_ring, CTX.host_scratch + 64, 0));
   for(u64 t = 0; t <= b->n; t++)
   {
+    bool size_in_ring = false;
+    if(t >= LOOK)
+    {
+      // before this step's scan may overwrite the slot: the size of step t - LOOK
+      HIP_TRY(hipEventSynchronize(events.ev[t % LOOK]));
+      alive_bound = CTX.host_scratch[64 + (u32)(t % LOOK)];
+      if(alive_bound == 0) { break; }
+    }
     if(scan_tiles <= FRONTIER_SCAN_TILES && g_tune.frontier_unfused == 0)
     {
       // scan of the segment lengths + per-step bookkeeping in two launches (k_frontier_scan)
@@ -377,7 +387,8 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
         LAUNCH("scan_reduce", k_scan_reduce<0>, scan_tiles, BLOCK_THREADS, seg_len[cur].as<const u64>(), scan_partial.as<u64>(), nseg + 1, (u64)0, scan_tiles);
       }
       LAUNCH("frontier_scan", k_frontier_scan, scan_tiles, BLOCK_THREADS, seg_len[cur].as<const u64>(), scan_partial.as<const u64>(), nseg,
-        seg_prefix.as<u64>(), first_seg.as<u32>(), emit_base.as<u64>(), in_epoch);
+        seg_prefix.as<u64>(), first_seg.as<u32>(), emit_base.as<u64>(), in_epoch, host_ring + (t % LOOK));
+      size_in_ring = true;
     }
     else
     {
@@ -385,17 +396,7 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
       LAUNCH("frontier_prep", k_frontier_prep, div_up(nseg, BLOCK_THREADS), BLOCK_THREADS, seg_prefix.as<const u64>(), nseg, first_seg.as<u32>(),
         emit_base.as<u64>(), in_epoch);
     }
-    {
-      const u32 slot = (u32)(t % LOOK);
-      if(t >= LOOK)
-      {
-        HIP_TRY(hipEventSynchronize(events.ev[slot]));            // step t - LOOK has been scanned
-        alive_bound = CTX.host_scratch[64 + slot];
-        if(alive_bound == 0) { break; }
-      }
-      TRY(fetch_u64(seg_prefix.as<u64>() + nseg, 64 + slot));
-      HIP_TRY(hipEventRecord(events.ev[slot], CTX.stream));
-    }
+    if(!size_in_ring) { TRY(fetch_u64(seg_prefix.as<u64>() + nseg, 64 + (u32)(t % LOOK))); HIP_TRY(hipEventRecord(events.ev[t % LOOK], CTX.stream)); }
     FrontierView f;
     f.lo = lo[cur].as<const uint2>(); f.hi = hi[cur].as<const unsigned short>();
     f.lo_next = lo[1 - cur].as<uint2>(); f.hi_next = hi[1 - cur].as<unsigned short>();
@@ -425,6 +426,9 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
     }
     else if(wide) { LAUNCH("frontier_step", (k_frontier_step<0, true>), nb_max, FR_BLOCK, a->view(), b->view(), f); }
     else { LAUNCH("frontier_step", (k_frontier_step<0, false>), nb_max, FR_BLOCK, a->view(), b->view(), f); }
+    // the size of step t reaches the host behind step t's kernels: recorded AFTER the step kernel, so that reduce, scan and step
+    // follow each other without another command between them
+    if(size_in_ring) { HIP_TRY(hipEventRecord(events.ev[t % LOOK], CTX.stream)); }
     cur = 1 - cur;
     in_epoch++; epoch_used += alive_bound;
     // The epoch ends when the table is full or the next step might not fit (l1_cap: the tests want the overflow).

@@ -292,8 +292,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_prep(const u64* seg_
 // two launches per step instead of four.
 constexpr u64 FRONTIER_SCAN_TILES = 8192;
 
+// host_n (may be null): page-locked host memory the frontier's size N_t is written to directly -- a separate 8-byte copy command between
+// this kernel and the step kernel cost ~14 us of idle device per LF step (profiles/r03_config2_summary.md, gap table).
 __global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_scan(const u64* seg_len, const u64* partial, u64 nseg, u64* seg_prefix, u32* first_seg,
-  u64* emit_base, u64 step)
+  u64* emit_base, u64 step, u64* host_n)
 {
   __shared__ u64 lds[BLOCK_THREADS / WAVE];
   const u64 n = nseg + 1;                                            // the entry after the last segment holds 0 and receives N_t
@@ -326,7 +328,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_scan(const u64* seg_
         const u64 b = (run + FR_BLOCK - 1) / FR_BLOCK;
         if(b * FR_BLOCK < run + item[k]) { first_seg[b] = (u32)idx; }
       }
-      else { emit_base[step + 1] = emit_base[step] + run; }
+      else { emit_base[step + 1] = emit_base[step] + run; if(host_n) { *host_n = run; } }
     }
     run += item[k];
   }

@@ -4,7 +4,8 @@ restricted to the TIMED steps of the bench (the input tooling launches the same 
 
 The timed region is recognised structurally: every merge step ends with the encoder
 (k_enc_emit) followed by the sample builder (k_block_cum); the last `steps` emits are
-the timed steps.  Usage: summarize_kernel_trace.py kernel_trace.csv steps > summary.md
+the timed steps -- not counting the `extra` untimed steps bench.py runs after them (since round 3: one step with every kernel
+bracketed by events, for the per-kernel table).  Usage: summarize_kernel_trace.py kernel_trace.csv steps [extra = 1] > summary.md
 """
 import csv
 import re
@@ -14,6 +15,7 @@ from collections import defaultdict
 
 def main():
     path, steps = sys.argv[1], int(sys.argv[2])
+    extra = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     rows = []
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"]
@@ -23,6 +25,8 @@ def main():
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short, r))
     rows.sort()
     emits = [k for k, r in enumerate(rows) if r[2] == "k_enc_emit"]
+    if extra > 0:
+        emits = emits[:-extra]
     first = emits[-(steps + 1)] if len(emits) > steps else -1
     # the step before the timed ones ends with its own k_block_cum
     t_begin = next(r[1] for r in rows[first:] if r[2] == "k_block_cum") if first >= 0 else 0
@@ -40,6 +44,17 @@ def main():
     print("| all bwtm kernels | | | %.3f | 100 %% |" % (total / steps / 1e6))
     print()
     print("timed region: %.3f ms wall per step between first and last kernel" % ((t_end - t_begin) / steps / 1e6))
+    # idle time of the device between consecutive kernels of the timed steps, by the kernel that follows the gap
+    gaps = defaultdict(list)
+    for prev, cur in zip(sel, sel[1:]):
+        gaps[cur[2]].append(max(0, cur[0] - prev[1]))
+    print()
+    print("| gap before kernel | count | avg (us) | total per step (ms) |")
+    print("|---|---|---|---|")
+    for short, v in sorted(gaps.items(), key=lambda kv: -sum(kv[1]))[:14]:
+        print("| %s | %d | %.1f | %.3f |" % (short, len(v), sum(v) / len(v) / 1e3, sum(v) / steps / 1e6))
+    print("| all gaps | | | %.3f |" % (sum(sum(v) for v in gaps.values()) / steps / 1e6))
+    print()
     top = max(agg.items(), key=lambda kv: sum(kv[1]))[0]
     r = next(r for r in sel if r[2] == top)[3]
     print(top + " launch geometry: grid %s x workgroup %s, VGPR %s, SGPR %s, LDS %s B" %
