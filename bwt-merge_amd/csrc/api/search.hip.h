@@ -367,6 +367,11 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   int cur = 0;
   u64 in_epoch = 0;
   u64 alive_bound = count, epoch_used = 0;                         // N_t <= alive_bound; emits reserved in this epoch so far
+  // Blocks launched per step: the frontier only shrinks, and blocks past its end would only publish empty segments.  The grid
+  // follows the (delayed) size when at least a quarter of it would be idle (reads of mixed lengths: after the short ones have ended);
+  // the segment entries a buffer still holds from the wider grid that wrote it last are cleared then.
+  u64 grid = nb_max;
+  u64 written[2] = {nb_max, 0};                                    // blocks that wrote buffer k's entries when it last was the output
   u64* host_ring = nullptr;                                        // device-visible address of host_scratch[64 ..): the ring of frontier sizes
   HIP_TRY(hipHostGetDevicePointer((void**)&host_ring, CTX.host_scratch + 64, 0));
   for(u64 t = 0; t <= b->n; t++)
@@ -397,6 +402,16 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
         emit_base.as<u64>(), in_epoch);
     }
     if(!size_in_ring) { TRY(fetch_u64(seg_prefix.as<u64>() + nseg, 64 + (u32)(t % LOOK))); HIP_TRY(hipEventRecord(events.ev[t % LOOK], CTX.stream)); }
+    {
+      const u64 need = std::max<u64>(1, div_up(alive_bound, FR_BLOCK));
+      if(g_tune.frontier_parts <= 1 && need * 4 < grid * 3) { grid = need; }
+      const int nxt = 1 - cur;
+      if(written[nxt] > grid)
+      {
+        for(u64 c = 0; c < 5; c++) { HIP_TRY(hipMemsetAsync(seg_len[nxt].as<u64>() + c * nb_max + grid, 0, (written[nxt] - grid) * sizeof(u64), CTX.stream)); }
+      }
+      written[nxt] = grid;
+    }
     FrontierView f;
     f.lo = lo[cur].as<const uint2>(); f.hi = hi[cur].as<const unsigned short>();
     f.lo_next = lo[1 - cur].as<uint2>(); f.hi_next = hi[1 - cur].as<unsigned short>();
@@ -406,8 +421,8 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
     f.emit16 = emit16.as<unsigned short>(); f.emit_base = emit_base.as<const u64>(); f.emit_cap = emit_cap; f.bits32 = ra->bits_as<u32>();
     f.bound_row = bound.as<u32>() + in_epoch * (ntiles + 1); f.step = in_epoch; f.block_base = 0;
 #ifdef BWTM_DIAGNOSTICS
-    if(g_tune.walk_emit == 1 && wide) { LAUNCH("frontier_step_noemit", (k_frontier_step<1, true>), nb_max, FR_BLOCK, a->view(), b->view(), f); }
-    else if(g_tune.walk_emit == 1) { LAUNCH("frontier_step_noemit", (k_frontier_step<1, false>), nb_max, FR_BLOCK, a->view(), b->view(), f); }
+    if(g_tune.walk_emit == 1 && wide) { LAUNCH("frontier_step_noemit", (k_frontier_step<1, true>), grid, FR_BLOCK, a->view(), b->view(), f); }
+    else if(g_tune.walk_emit == 1) { LAUNCH("frontier_step_noemit", (k_frontier_step<1, false>), grid, FR_BLOCK, a->view(), b->view(), f); }
     else
 #endif
     if(g_tune.frontier_parts > 1)
@@ -424,8 +439,8 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
         else { LAUNCH(label, (k_frontier_step<0, false>), nb_part, FR_BLOCK, a->view(), b->view(), f); }
       }
     }
-    else if(wide) { LAUNCH("frontier_step", (k_frontier_step<0, true>), nb_max, FR_BLOCK, a->view(), b->view(), f); }
-    else { LAUNCH("frontier_step", (k_frontier_step<0, false>), nb_max, FR_BLOCK, a->view(), b->view(), f); }
+    else if(wide) { LAUNCH("frontier_step", (k_frontier_step<0, true>), grid, FR_BLOCK, a->view(), b->view(), f); }
+    else { LAUNCH("frontier_step", (k_frontier_step<0, false>), grid, FR_BLOCK, a->view(), b->view(), f); }
     // the size of step t reaches the host behind step t's kernels: recorded AFTER the step kernel, so that reduce, scan and step
     // follow each other without another command between them
     if(size_in_ring) { HIP_TRY(hipEventRecord(events.ev[t % LOOK], CTX.stream)); }

@@ -327,6 +327,32 @@ def test_partitioned_emit_rounds_fallbacks_and_variants(gpu, oracle):
         gpu.tune("search_algo", 2)
 
 
+@pytest.mark.parametrize("ratio", [0, -1])
+def test_frontier_grid_follows_a_shrinking_frontier(gpu, oracle, ratio):
+    """Reads of twelve lengths: the frontier shrinks in steps, the step kernel's grid follows it (a quarter of idle blocks triggers a
+    shrink) and the segment entries of the wider grids are cleared -- stale entries would resurrect dead chains."""
+    rng = np.random.default_rng(77)
+    lengths = [3, 9, 20, 33, 47, 60, 75, 90, 110, 140, 170, 200]
+    tb = np.concatenate([oracle.generate_reads(7000 + k, 600, n) for k, n in enumerate(lengths)])
+    ta = oracle.generate_reads(7100, 4000, 120)
+    a, b = oracle.FMI.from_text(ta), oracle.FMI.from_text(tb)
+    ranks, counts, _ = oracle.search(a, b, threads=2)
+    A = gpu.Index.upload(a.data, a.sequences, a.bases); B = gpu.Index.upload(b.data, b.sequences, b.bases)
+    gpu.tune("range_ratio", ratio)
+    try:
+        ra = gpu.RankArray(A, B)
+        ra.search(A, B, 0, b.sequences - 1)
+        ra.finalize()
+        assert ra.values == b.bases
+        assert np.array_equal(ra.download(), oracle.ra_from_runs(ranks, counts))
+        M = gpu.merge(A, B)
+        assert np.array_equal(M.data(), oracle.FMI.from_text(np.concatenate([ta, tb])).data)
+    finally:
+        gpu.tune("range_ratio", -1)
+    for x in (ra, M, A, B):
+        x.free()
+
+
 def test_find_batch_matches_oracle_backward_search(gpu, oracle):
     """FMI::find on the device (bwt_merge -v) against the oracle's backward search."""
     t = oracle.generate_reads(77, 600, 80)
