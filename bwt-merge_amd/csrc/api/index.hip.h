@@ -26,6 +26,8 @@ struct bwtm_index
   DevBuf gcum; u64 ngroups = 0;       // 6 x (ngroups + 1) u64: cumulative symbol counts at the starts of the 62-block groups
   DevBuf cum;                         // 6 x (nblocks + 1) u64: cumulative symbol counts at block starts (built on demand)
   DevBuf flags;                       // k_block_len's verdict on the stream (read by upload_validate)
+  mutable DevBuf sview, vsup;         // the search view (built on demand by the frontier search, dropped with the records)
+  mutable u64 nview = 0;
 
   IndexView view() const
   {
@@ -33,6 +35,7 @@ struct bwtm_index
     v.recs = recs.as<const uint4>(); v.sup = sup.as<const u64>();
     v.n = n; v.m = m; v.nrecs = nrecs;
     for(int c = 0; c < 8; c++) { v.C[c] = C[c]; }
+    v.view = sview.as<const uint4>(); v.vsup = vsup.as<const u64>(); v.nview = (sview.p ? nview : 0);
     return v;
   }
 };
@@ -230,6 +233,22 @@ int ensure_block_cum(bwtm_index* x)
   TRY(x->cum.alloc(6 * stride * sizeof(u64)));
   LAUNCH("block_cum", k_block_cum, div_up(stride, BLOCK_THREADS), BLOCK_THREADS,
     x->view(), x->block_start.as<const u64>(), (u64)0, stride, x->cum.as<u64>(), stride);
+  return BWTM_OK;
+}
+
+// The search view of an index (bwtm_device.h, kernels/search_view.hip.h): built when the frontier search first wants it, kept with
+// the records (a chained merge searches the same first input again), released with the handle.
+int ensure_view(const bwtm_index* x)
+{
+  if(x->sview.p) { return BWTM_OK; }
+  x->nview = num_view_records(x->n);
+  const u64 nvsup = num_view_supers(x->n);
+  TRY(x->vsup.alloc(nvsup * SUP_STRIDE * sizeof(u64)));
+  int rc = x->sview.alloc(x->nview * 64);
+  if(rc != BWTM_OK) { x->vsup.release(); return rc; }
+  IndexView v = x->view(); v.view = nullptr; v.nview = 0;
+  LAUNCH("view_sup", k_view_sup, div_up(nvsup, BLOCK_THREADS), BLOCK_THREADS, v, x->vsup.as<u64>(), nvsup);
+  LAUNCH("view_build", k_view_build, div_up(x->nview, BLOCK_THREADS), BLOCK_THREADS, v, x->vsup.as<const u64>(), x->sview.as<uint4>(), x->nview);
   return BWTM_OK;
 }
 

@@ -367,6 +367,23 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   int cur = 0;
   u64 in_epoch = 0;
   u64 alive_bound = count, epoch_used = 0;                         // N_t <= alive_bound; emits reserved in this epoch so far
+  // The search view (two bit-planes + exceptions, 0.4 instead of 0.5 bytes per base): worth building when the search will stream the
+  // indexes often enough -- long frontiers of many steps -- and memory allows; search_view: 0 = never, 1 = always (tests), 2 = by size.
+  bool use_view = (g_tune.search_view == 1);
+  if(g_tune.search_view == 2)
+  {
+    const u64 steps_left = (b->m > 0 ? b->n / b->m : 0);
+    size_t free_b = 0, total_b = 0;
+    const u64 need = (num_view_records(a->n) + num_view_records(b->n)) * 64;
+    use_view = (count >= (1ull << 22) && steps_left >= 32 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (u64)free_b + CTX.cached_bytes > need + (8ull << 30));
+    (void)hipGetLastError();
+  }
+  if(use_view)
+  {
+    int rc_view = ensure_view(a);
+    if(rc_view == BWTM_OK) { rc_view = ensure_view(b); }
+    if(rc_view != BWTM_OK) { use_view = false; }                  // no room: the ordinary records do
+  }
   // Blocks launched per step: the frontier only shrinks, and blocks past its end would only publish empty segments.  The grid
   // follows the (delayed) size when at least a quarter of it would be idle (reads of mixed lengths: after the short ones have ended);
   // the segment entries a buffer still holds from the wider grid that wrote it last are cleared then.
@@ -439,6 +456,8 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
         else { LAUNCH(label, (k_frontier_step<0, false>), nb_part, FR_BLOCK, a->view(), b->view(), f); }
       }
     }
+    else if(use_view && wide) { LAUNCH("frontier_step", (k_frontier_step<0, true, true>), grid, FR_BLOCK, a->view(), b->view(), f); }
+    else if(use_view) { LAUNCH("frontier_step", (k_frontier_step<0, false, true>), grid, FR_BLOCK, a->view(), b->view(), f); }
     else if(wide) { LAUNCH("frontier_step", (k_frontier_step<0, true>), grid, FR_BLOCK, a->view(), b->view(), f); }
     else { LAUNCH("frontier_step", (k_frontier_step<0, false>), grid, FR_BLOCK, a->view(), b->view(), f); }
     // the size of step t reaches the host behind step t's kernels: recorded AFTER the step kernel, so that reduce, scan and step

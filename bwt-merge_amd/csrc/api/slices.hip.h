@@ -47,6 +47,7 @@ struct bwtm_slice
     v.recs = recs_virtual(); v.sup = sup.as<const u64>();
     v.n = n; v.m = m; v.nrecs = nrecs_total;
     for(int c = 0; c < 8; c++) { v.C[c] = C[c]; }
+    v.view = nullptr; v.vsup = nullptr; v.nview = 0;
     return v;
   }
 };

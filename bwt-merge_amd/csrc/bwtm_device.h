@@ -134,6 +134,93 @@ BWTM_HD void range_mask128(u32 from, u32 count, u64& lo, u64& hi)
 }
 
 //------------------------------------------------------------------------------
+// Search view (round 3): a denser copy of the rank structure that only the level-synchronous search reads.
+// A full LF step streams every record of both indexes once and is bound by those bytes alone, and
+// almost every position holds one of A, C, G, T: two bit-planes hold 160 positions in the bytes three planes need for 107.
+//
+//     view record q covers positions [160 q, 160 q + 160), 16 x u32
+//       v[0..4]   bit 0 of (symbol - 1) for the 160 positions     (A, C, G, T -> 0, 1, 2, 3)
+//       v[5..9]   bit 1
+//       v[10..13] header: five 25-bit fields, field c - 1 = #c in [view super start, 160 q); bit 125 = OVERFLOW
+//       v[14..15] up to seven exceptions, 9 bits each: position in the record (8 bits) | kind << 8 (0 = endmarker, 1 = N);
+//                 an empty slot holds 0x1FF.  Exceptions are stored as 'A' in the planes.
+//     view super  vsup[8 s + c] = #c in [0, s * VIEW_SUPER_POS), one line per 2^17 records (counts inside a super fit 25 bits)
+//
+// A record with more than seven exceptions sets OVERFLOW; its elements take the ordinary 64-byte record of the same
+// position instead (one more dependent access, for the 0.2 % of the records of a read collection that need it).
+
+constexpr u32 VIEW_POS        = 160;
+constexpr u32 VIEW_WORDS      = 5;                  // words per plane
+constexpr int VIEW_SUPER_SHIFT = 17;                // view records per view super
+constexpr u64 VIEW_SUPER_POS  = (u64)VIEW_POS << VIEW_SUPER_SHIFT;     // 20 971 520 positions < 2^25
+constexpr u32 VIEW_EXC_SLOTS  = 7;
+constexpr u32 VIEW_EXC_EMPTY  = 0x1FFu;
+constexpr u32 VIEW_OVERFLOW_BIT = 29;               // bit 125 of the header = bit 29 of v[13]
+
+BWTM_HD u64 num_view_records(u64 n) { return n / VIEW_POS + 1; }
+BWTM_HD u64 num_view_supers(u64 n)  { return (n / VIEW_POS >> VIEW_SUPER_SHIFT) + 1; }
+
+// Exception slot k (0..6) of the 64-bit exception field.
+BWTM_HD u32 view_exception(u64 exc, u32 k) { return (u32)(exc >> (9 * k)) & 0x1FFu; }
+
+// Symbol at in-record position j (0..159) of a view record without OVERFLOW.
+BWTM_HD u32 view_symbol(const u32* v, u32 j)
+{
+  const u32 w = j >> 5, t = j & 31;
+  u32 b0 = 0, b1 = 0;
+#pragma unroll
+  for(u32 k = 0; k < VIEW_WORDS; k++) { if(k == w) { b0 = (v[k] >> t) & 1u; b1 = (v[VIEW_WORDS + k] >> t) & 1u; } }
+  u32 c = 1 + b0 + 2 * b1;
+  const u64 exc = (u64)v[14] | ((u64)v[15] << 32);
+#pragma unroll
+  for(u32 k = 0; k < VIEW_EXC_SLOTS; k++)
+  {
+    const u32 e = view_exception(exc, k);
+    if((e & 0xFFu) == j && e != VIEW_EXC_EMPTY) { c = (e >> 8 ? 5u : 0u); }
+  }
+  return c;
+}
+
+// Occurrences of c (1..5) among the first j positions (0..160) of a view record without OVERFLOW.
+BWTM_HD u32 view_count(const u32* v, u32 c, u32 j)
+{
+  const u64 exc = (u64)v[14] | ((u64)v[15] << 32);
+  u32 exc_a = 0, exc_n = 0;                         // exceptions below j: all of them sit in the planes as 'A'; those of kind N
+#pragma unroll
+  for(u32 k = 0; k < VIEW_EXC_SLOTS; k++)
+  {
+    const u32 e = view_exception(exc, k);
+    const bool below = (e != VIEW_EXC_EMPTY && (e & 0xFFu) < j);
+    exc_a += (below ? 1u : 0u); exc_n += (below && (e >> 8) ? 1u : 0u);
+  }
+  if(c == 5) { return exc_n; }
+  const u32 code = c - 1;
+  u32 total = 0;
+#pragma unroll
+  for(u32 k = 0; k < VIEW_WORDS; k++)
+  {
+    const u32 m0 = (code & 1) ? v[k] : ~v[k];
+    const u32 m1 = (code & 2) ? v[VIEW_WORDS + k] : ~v[VIEW_WORDS + k];
+    total += (u32)__builtin_popcount(m0 & m1 & below_mask(j, k));
+  }
+  return total - (c == 1 ? exc_a : 0u);
+}
+
+// Relative count field of symbol c (1..5) of a view record (the same packing as rec_header, in v[10..13]).
+BWTM_HD u32 view_header(const u32* v, u32 c)
+{
+  u64 lo = (u64)v[10] | ((u64)v[11] << 32);
+  u64 hi = (u64)v[12] | ((u64)v[13] << 32);
+  u32 sh = FIELD_BITS * (c - 1);
+  u64 x;
+  if(sh < 64) { x = lo >> sh; if(sh + FIELD_BITS > 64) { x |= hi << (64 - sh); } }
+  else { x = hi >> (sh - 64); }
+  return (u32)x & FIELD_MASK;
+}
+
+BWTM_HD bool view_overflow(const u32* v) { return ((v[13] >> VIEW_OVERFLOW_BIT) & 1u) != 0; }
+
+//------------------------------------------------------------------------------
 // Native run codec (support.h:221-286), decode side.  Reads one run at data[pos...].
 
 //------------------------------------------------------------------------------

@@ -44,6 +44,9 @@ struct IndexView
   u64 m;                 // sequences
   u64 nrecs;
   u64 C[8];              // C[c] = number of symbols smaller than c
+  const uint4* view;     // the search view (4 x uint4 per 160 positions; null unless built: bwtm_device.h)
+  const u64* vsup;
+  u64 nview;
 };
 
 #include "kernels/common.hip.h"
@@ -53,6 +56,7 @@ struct IndexView
 #ifdef BWTM_DIAGNOSTICS
 #include "kernels/diagnostics.hip.h"
 #endif
+#include "kernels/search_view.hip.h"
 #include "kernels/search_frontier.hip.h"
 #include "kernels/search_range.hip.h"
 #include "kernels/interleave.hip.h"

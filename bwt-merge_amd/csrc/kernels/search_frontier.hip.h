@@ -92,7 +92,20 @@ __device__ inline void record_words(const RecordFetch& rf, u32 w[16])
 }
 
 // HI: the coordinates have high bytes (an index of 2^32 positions or more); otherwise the 2-byte array is neither read nor written.
-template<int EMIT, bool HI>
+// rank(pos, c) on the ordinary records, out of line (the view's overflow path: rare, and its 16 record words must not take registers
+// from the common path).  want_symbol: c is first read from the record (the symbol at pos; 0 ends the chain and returns 0).
+__device__ __attribute__((noinline)) u64 ordinary_lf(const IndexView& X, u64 pos, u32& c, bool want_symbol)
+{
+  u32 w[16]; load_record(X.recs, pos >> REC_SHIFT, w);
+  const u32 j = (u32)(pos & (REC_POS - 1));
+  if(want_symbol) { c = rec_symbol(w, j); }
+  if(c == 0) { return 0; }
+  return X.sup[(pos >> SUPER_SHIFT) * SUP_STRIDE + c] + rec_header(w, c) + rec_count(w, c, j);
+}
+
+// VIEW: the records come from the search view (160 positions per 64 bytes, bwtm_device.h); an element whose view record has overflowed
+// its exception slots reads the ordinary record of its position instead.
+template<int EMIT, bool HI, bool VIEW = false>
 __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, IndexView B, FrontierView f)
 {
   __shared__ u32 wave_cnt[FR_BLOCK / WAVE][6];
@@ -182,39 +195,77 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
       tile_first = (u32)my_tile;                                  // meaningful in lane 0
       tile_last = (u32)shfl_u64(my_tile, (int)last_lane);
     }
-    u32 wb[16];
-    const u64 rec_b = (active ? i : li) >> REC_SHIFT, rec_a = (active ? r : lr) >> REC_SHIFT;
-    RecordFetch fb = record_issue(B.recs, B.nrecs, rec_b);
-    RecordFetch fa = record_issue(A.recs, A.nrecs, rec_a);     // in flight while B's record is used
-    const u64 sup_b0 = shfl_u64(i, 0) >> SUPER_SHIFT, sup_a0 = shfl_u64(r, 0) >> SUPER_SHIFT;   // lane 0 is always active here
-    const u64* row_b = B.sup + sup_b0 * SUP_STRIDE;                // wave-uniform addresses
-    const u64* row_a = A.sup + sup_a0 * SUP_STRIDE;
-    record_words(fb, wb);
-    if(active) { c = rec_symbol(wb, (u32)(i & (REC_POS - 1))); }   // BWT_B[i]; 0 ends the chain (fmi.cpp:299)
-    u64 supb = 0, supa = 0;
-    if(active && c != 0)
+    if(VIEW)
     {
-      // Super-table rows: the wave's coordinates are sorted, so nearly every lane needs the row of lane 0,
-      // which was requested with scalar loads (row_b / row_a) together with the records.
-      if((i >> SUPER_SHIFT) == sup_b0) { supb = (c == 1 ? row_b[1] : (c == 2 ? row_b[2] : (c == 3 ? row_b[3] : (c == 4 ? row_b[4] : row_b[5])))); }
-      else { supb = B.sup[(i >> SUPER_SHIFT) * SUP_STRIDE + c]; }
-      if((r >> SUPER_SHIFT) == sup_a0) { supa = (c == 1 ? row_a[1] : (c == 2 ? row_a[2] : (c == 3 ? row_a[3] : (c == 4 ? row_a[4] : row_a[5])))); }
-      else { supa = A.sup[(r >> SUPER_SHIFT) * SUP_STRIDE + c]; }
-      ni = rec_header(wb, c) + rec_count(wb, c, (u32)(i & (REC_POS - 1)));
-    }
-    u32 wa[16];
-    record_words(fa, wa);
-    if(active)
-    {
-      const u32 ja = (u32)(r & (REC_POS - 1));
-      if(c != 0)
+      // The same step on the view records.  Position p sits in view record p / 160 (a multiply-high), at p - 160 (p / 160).
+      const u64 pi = (active ? i : li), pr = (active ? r : lr);
+      const u64 qb = pi / VIEW_POS, qa = pr / VIEW_POS;
+      const u32 jb = (u32)(pi - qb * VIEW_POS), ja = (u32)(pr - qa * VIEW_POS);
+      RecordFetch fb = record_issue(B.view, B.nview, qb);
+      RecordFetch fa = record_issue(A.view, A.nview, qa);
+      bool over_b, over_a;
       {
-        ni += supb;
-        nr = supa + rec_header(wa, c) + rec_count(wa, c, ja);
-        // C[c]: kernel arguments cannot be indexed dynamically without scratch, hence the selects
-        u64 cb = (c == 1 ? B.C[1] : (c == 2 ? B.C[2] : (c == 3 ? B.C[3] : (c == 4 ? B.C[4] : B.C[5]))));
-        u64 ca = (c == 1 ? A.C[1] : (c == 2 ? A.C[2] : (c == 3 ? A.C[3] : (c == 4 ? A.C[4] : A.C[5]))));
-        ni += cb; nr += ca;                                     // LF_B(i), LF_A(r, c): utils.h:335-348
+        u32 wb[16];
+        record_words(fb, wb);
+        over_b = view_overflow(wb);
+        if(active && !over_b)
+        {
+          c = view_symbol(wb, jb);
+          if(c != 0) { ni = B.vsup[(qb >> VIEW_SUPER_SHIFT) * SUP_STRIDE + c] + view_header(wb, c) + view_count(wb, c, jb); }
+        }
+      }
+      // rare: more than seven endmarkers / N among the 160 positions -- the ordinary record of the position answers
+      if(__ballot(active && over_b) != 0) { if(active && over_b) { ni = ordinary_lf(B, i, c, true); } }
+      {
+        u32 wa[16];
+        record_words(fa, wa);
+        over_a = view_overflow(wa);
+        if(active && c != 0 && !over_a) { nr = A.vsup[(qa >> VIEW_SUPER_SHIFT) * SUP_STRIDE + c] + view_header(wa, c) + view_count(wa, c, ja); }
+      }
+      if(__ballot(active && c != 0 && over_a) != 0) { if(active && c != 0 && over_a) { nr = ordinary_lf(A, r, c, false); } }
+      if(active && c != 0)
+      {
+        const u64 cb = (c == 1 ? B.C[1] : (c == 2 ? B.C[2] : (c == 3 ? B.C[3] : (c == 4 ? B.C[4] : B.C[5]))));
+        const u64 ca = (c == 1 ? A.C[1] : (c == 2 ? A.C[2] : (c == 3 ? A.C[3] : (c == 4 ? A.C[4] : A.C[5]))));
+        ni += cb; nr += ca;                                       // LF_B(i), LF_A(r, c): utils.h:335-348
+      }
+    }
+    else
+    {
+      u32 wb[16];
+      const u64 rec_b = (active ? i : li) >> REC_SHIFT, rec_a = (active ? r : lr) >> REC_SHIFT;
+      RecordFetch fb = record_issue(B.recs, B.nrecs, rec_b);
+      RecordFetch fa = record_issue(A.recs, A.nrecs, rec_a);     // in flight while B's record is used
+      const u64 sup_b0 = shfl_u64(i, 0) >> SUPER_SHIFT, sup_a0 = shfl_u64(r, 0) >> SUPER_SHIFT;   // lane 0 is always active here
+      const u64* row_b = B.sup + sup_b0 * SUP_STRIDE;                // wave-uniform addresses
+      const u64* row_a = A.sup + sup_a0 * SUP_STRIDE;
+      record_words(fb, wb);
+      if(active) { c = rec_symbol(wb, (u32)(i & (REC_POS - 1))); }   // BWT_B[i]; 0 ends the chain (fmi.cpp:299)
+      u64 supb = 0, supa = 0;
+      if(active && c != 0)
+      {
+        // Super-table rows: the wave's coordinates are sorted, so nearly every lane needs the row of lane 0,
+        // which was requested with scalar loads (row_b / row_a) together with the records.
+        if((i >> SUPER_SHIFT) == sup_b0) { supb = (c == 1 ? row_b[1] : (c == 2 ? row_b[2] : (c == 3 ? row_b[3] : (c == 4 ? row_b[4] : row_b[5])))); }
+        else { supb = B.sup[(i >> SUPER_SHIFT) * SUP_STRIDE + c]; }
+        if((r >> SUPER_SHIFT) == sup_a0) { supa = (c == 1 ? row_a[1] : (c == 2 ? row_a[2] : (c == 3 ? row_a[3] : (c == 4 ? row_a[4] : row_a[5])))); }
+        else { supa = A.sup[(r >> SUPER_SHIFT) * SUP_STRIDE + c]; }
+        ni = rec_header(wb, c) + rec_count(wb, c, (u32)(i & (REC_POS - 1)));
+      }
+      u32 wa[16];
+      record_words(fa, wa);
+      if(active)
+      {
+        const u32 ja = (u32)(r & (REC_POS - 1));
+        if(c != 0)
+        {
+          ni += supb;
+          nr = supa + rec_header(wa, c) + rec_count(wa, c, ja);
+          // C[c]: kernel arguments cannot be indexed dynamically without scratch, hence the selects
+          u64 cb = (c == 1 ? B.C[1] : (c == 2 ? B.C[2] : (c == 3 ? B.C[3] : (c == 4 ? B.C[4] : B.C[5]))));
+          u64 ca = (c == 1 ? A.C[1] : (c == 2 ? A.C[2] : (c == 3 ? A.C[3] : (c == 4 ? A.C[4] : A.C[5]))));
+          ni += cb; nr += ca;                                     // LF_B(i), LF_A(r, c): utils.h:335-348
+        }
       }
     }
   }
