@@ -92,21 +92,39 @@ __device__ inline void record_words(const RecordFetch& rf, u32 w[16])
 }
 
 // HI: the coordinates have high bytes (an index of 2^32 positions or more); otherwise the 2-byte array is neither read nor written.
-// rank(pos, c) on the ordinary records, out of line (the view's overflow path: rare, and its 16 record words must not take registers
-// from the common path).  want_symbol: c is first read from the record (the symbol at pos; 0 ends the chain and returns 0).
-__device__ __attribute__((noinline)) u64 ordinary_lf(const IndexView& X, u64 pos, u32& c, bool want_symbol)
+// LF on the ordinary records, one 16-byte chunk at a time (the view's overflow path: rare, and it must not take sixteen registers from
+// the common path).  want_symbol: c is first read from the record (the symbol at pos; 0 ends the chain and returns 0).
+__device__ inline u64 ordinary_lf(const IndexView& X, u64 pos, u32& c, bool want_symbol)
 {
-  u32 w[16]; load_record(X.recs, pos >> REC_SHIFT, w);
+  const uint4* p = X.recs + 4 * (pos >> REC_SHIFT);
   const u32 j = (u32)(pos & (REC_POS - 1));
-  if(want_symbol) { c = rec_symbol(w, j); }
+  if(want_symbol)
+  {
+    const uint4 ch = p[j >> 5];
+    const u32 t = j & 31;
+    c = ((ch.x >> t) & 1u) | (((ch.y >> t) & 1u) << 1) | (((ch.z >> t) & 1u) << 2);
+  }
   if(c == 0) { return 0; }
-  return X.sup[(pos >> SUPER_SHIFT) * SUP_STRIDE + c] + rec_header(w, c) + rec_count(w, c, j);
+  u32 total = 0; u32 h[4];
+#pragma unroll
+  for(u32 k = 0; k < 4; k++)
+  {
+    const uint4 ch = p[k];
+    total += (u32)__builtin_popcount(plane_match(ch.x, ch.y, ch.z, c) & below_mask(j, k));
+    h[k] = ch.w;
+  }
+  const u32 sh = FIELD_BITS * (c - 1);
+  const u64 lo = (u64)h[0] | ((u64)h[1] << 32), hi = (u64)h[2] | ((u64)h[3] << 32);
+  u64 v;
+  if(sh < 64) { v = lo >> sh; if(sh + FIELD_BITS > 64) { v |= hi << (64 - sh); } }
+  else { v = hi >> (sh - 64); }
+  return X.sup[(pos >> SUPER_SHIFT) * SUP_STRIDE + c] + ((u32)v & FIELD_MASK) + total;
 }
 
 // VIEW: the records come from the search view (160 positions per 64 bytes, bwtm_device.h); an element whose view record has overflowed
 // its exception slots reads the ordinary record of its position instead.
 template<int EMIT, bool HI, bool VIEW = false>
-__global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, IndexView B, FrontierView f)
+__global__ void __launch_bounds__(FR_BLOCK, (VIEW ? 6 : 8)) k_frontier_step(IndexView A, IndexView B, FrontierView f)
 {
   __shared__ u32 wave_cnt[FR_BLOCK / WAVE][6];
   __shared__ u64 s_prefix[FR_SEGS + 1], s_phys[FR_SEGS + 1];
@@ -203,6 +221,10 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
       const u32 jb = (u32)(pi - qb * VIEW_POS), ja = (u32)(pr - qa * VIEW_POS);
       RecordFetch fb = record_issue(B.view, B.nview, qb);
       RecordFetch fa = record_issue(A.view, A.nview, qa);
+      // view-super rows of lane 0 (always active here) through scalar loads, requested together with the records
+      const u64 vs_b0 = shfl_u64(qb, 0) >> VIEW_SUPER_SHIFT, vs_a0 = shfl_u64(qa, 0) >> VIEW_SUPER_SHIFT;
+      const u64* vrow_b = B.vsup + vs_b0 * SUP_STRIDE;
+      const u64* vrow_a = A.vsup + vs_a0 * SUP_STRIDE;
       bool over_b, over_a;
       {
         u32 wb[16];
@@ -210,8 +232,16 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
         over_b = view_overflow(wb);
         if(active && !over_b)
         {
-          c = view_symbol(wb, jb);
-          if(c != 0) { ni = B.vsup[(qb >> VIEW_SUPER_SHIFT) * SUP_STRIDE + c] + view_header(wb, c) + view_count(wb, c, jb); }
+          u32 below, below_n, at;
+          view_exceptions(wb[14], wb[15], jb, below, below_n, at);
+          c = view_symbol(wb, jb, at);
+          if(c != 0)
+          {
+            u64 sb;
+            if((qb >> VIEW_SUPER_SHIFT) == vs_b0) { sb = (c == 1 ? vrow_b[1] : (c == 2 ? vrow_b[2] : (c == 3 ? vrow_b[3] : (c == 4 ? vrow_b[4] : vrow_b[5])))); }
+            else { sb = B.vsup[(qb >> VIEW_SUPER_SHIFT) * SUP_STRIDE + c]; }
+            ni = sb + view_header(wb, c) + view_count(wb, c, jb, below, below_n);
+          }
         }
       }
       // rare: more than seven endmarkers / N among the 160 positions -- the ordinary record of the position answers
@@ -220,7 +250,15 @@ __global__ void __launch_bounds__(FR_BLOCK, 8) k_frontier_step(IndexView A, Inde
         u32 wa[16];
         record_words(fa, wa);
         over_a = view_overflow(wa);
-        if(active && c != 0 && !over_a) { nr = A.vsup[(qa >> VIEW_SUPER_SHIFT) * SUP_STRIDE + c] + view_header(wa, c) + view_count(wa, c, ja); }
+        if(active && c != 0 && !over_a)
+        {
+          u64 sa;
+          if((qa >> VIEW_SUPER_SHIFT) == vs_a0) { sa = (c == 1 ? vrow_a[1] : (c == 2 ? vrow_a[2] : (c == 3 ? vrow_a[3] : (c == 4 ? vrow_a[4] : vrow_a[5])))); }
+          else { sa = A.vsup[(qa >> VIEW_SUPER_SHIFT) * SUP_STRIDE + c]; }
+          u32 below, below_n, at;
+          view_exceptions(wa[14], wa[15], ja, below, below_n, at);
+          nr = sa + view_header(wa, c) + view_count(wa, c, ja, below, below_n);
+        }
       }
       if(__ballot(active && c != 0 && over_a) != 0) { if(active && c != 0 && over_a) { nr = ordinary_lf(A, r, c, false); } }
       if(active && c != 0)

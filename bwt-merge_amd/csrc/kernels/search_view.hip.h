@@ -43,11 +43,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_view_build(IndexView x, const
     while(e)
     {
       const u32 b = (u32)__builtin_ctz(e); e &= e - 1;
-      if(nexc < VIEW_EXC_SLOTS) { exc |= (u64)((32 * k + b) | (((c.z >> b) & 1u) << 8)) << (9 * nexc); }
+      if(nexc < VIEW_EXC_SLOTS) { exc |= ((u64)(32 * k + b) << (8 * nexc)) | ((u64)((c.z >> b) & 1u) << (56 + nexc)); }
       nexc++;
     }
   }
-  for(u32 k = (nexc < VIEW_EXC_SLOTS ? nexc : VIEW_EXC_SLOTS); k < VIEW_EXC_SLOTS; k++) { exc |= (u64)VIEW_EXC_EMPTY << (9 * k); }
+  for(u32 k = (nexc < VIEW_EXC_SLOTS ? nexc : VIEW_EXC_SLOTS); k < VIEW_EXC_SLOTS; k++) { exc |= (u64)VIEW_EXC_EMPTY << (8 * k); }
   u64 r[6]; index_ranks(x, (p0 < x.n ? p0 : x.n), r);
   const u64* base = vsup + (q >> VIEW_SUPER_SHIFT) * SUP_STRIDE;
   u32 rel[6] = {0, (u32)(r[1] - base[1]), (u32)(r[2] - base[2]), (u32)(r[3] - base[3]), (u32)(r[4] - base[4]), (u32)(r[5] - base[5])};
