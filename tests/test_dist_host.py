@@ -150,3 +150,40 @@ def test_fold_offsets_binding_matches_host_logic(bwtm):
     tables = rng.integers(0, 1000, (5, 64)).astype(np.uint64)
     assert [int(x) for x in bwtm.fold_offsets(tables)] == fold_offsets(tables)
     assert bwtm.slice_bounds(5000, 3, 1) == (1536, 3072) and bwtm.slice_bounds(300, 4, 0) == (0, 0) and bwtm.slice_bounds(300, 4, 3) == (0, 300)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The sliced frontier search (bwt-merge_amd/dist.py: search_sliced, include/bwtm.h: bwtm_fslice_*) as a plain CPU model: every part
+# advances a contiguous slice of the sorted frontier and the next frontier is read in the order (class, part, position inside the
+# part's output).  The claim the GPU code rests on: that order IS the suffix order, so the union of the parts' emits is the rank array.
+
+def test_sliced_frontier_model_on_cpu(oracle):
+    from bwt_merge_amd.dist import shard_range, slice_range
+    ta = oracle.generate_reads(1001, 50, 30)
+    tb = np.concatenate([oracle.generate_reads(1002 + k, 12, n) for k, n in enumerate([1, 7, 19, 40, 33])])
+    a, b = oracle.FMI.from_text(ta), oracle.FMI.from_text(tb)
+    ranks, counts, _ = oracle.search(a, b, threads=1)
+    expect = oracle.ra_from_runs(ranks, counts)
+    for parts in (1, 2, 3, 7):
+        # outputs of "step -1": every part's block of sequences, in class 0
+        outputs = [[[] for _ in range(6)] for _ in range(parts)]
+        for g in range(parts):
+            first, last = shard_range(b.sequences, g, parts)
+            outputs[g][0] = [(j, a.sequences) for j in range(first, last + 1)]
+        got = np.zeros(b.bases, dtype=np.uint64)
+        seen = np.zeros(b.bases, dtype=bool)
+        while True:
+            frontier = [e for c in range(6) for g in range(parts) for e in outputs[g][c]]        # logical order: (class, part, inside)
+            if not frontier:
+                break
+            assert all(frontier[k][0] < frontier[k + 1][0] and frontier[k][1] <= frontier[k + 1][1] for k in range(len(frontier) - 1))   # sorted by suffix
+            outputs = [[[] for _ in range(6)] for _ in range(parts)]
+            for g in range(parts):
+                lo, hi = slice_range(len(frontier), g, parts)
+                for i, r in frontier[lo:hi]:                                                  # one LF step on the slice, stable split by class
+                    assert not seen[i]
+                    got[i] = r; seen[i] = True
+                    nxt, c = b.LF(i)
+                    if c != 0:
+                        outputs[g][c].append((nxt, a.LF(r, c)))
+        assert seen.all() and np.array_equal(got, expect), parts
