@@ -92,6 +92,29 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
   if(distinct && G > 1) { std::cerr << "mergeMultiGPU(): built without RCCL, cannot combine rank arrays across devices" << std::endl; std::exit(EXIT_FAILURE); }
 #endif
 
+#ifdef BWTM_WITH_RCCL
+  if(distinct && G > 1 && sliced)
+  {
+    // the sliced search reads its peers' frontier buffers directly (plain hipMalloc memory, bwtm_fslice_export): peers must be mapped
+    for(size_type i = 0; i < G; i++)
+    {
+      for(size_type j = 0; j < G; j++)
+      {
+        if(i == j) { continue; }
+        int can = 0;
+        if(hipSetDevice(devices[i]) != hipSuccess || hipDeviceCanAccessPeer(&can, devices[i], devices[j]) != hipSuccess || !can)
+        {
+          std::cerr << "mergeMultiGPU(): GPU " << devices[i] << " cannot access GPU " << devices[j] << ": the sliced search needs peer access" << std::endl;
+          std::exit(EXIT_FAILURE);
+        }
+        hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+        if(e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { std::cerr << "mergeMultiGPU(): hipDeviceEnablePeerAccess failed: " << hipGetErrorString(e) << std::endl; std::exit(EXIT_FAILURE); }
+        (void)hipGetLastError();
+      }
+    }
+  }
+#endif
+
   // What the threads share.
   ThreadBarrier barrier(G);
   std::vector<void*> bits(G, nullptr); std::vector<uint64_t> bits_bytes(G, 0);
