@@ -31,6 +31,11 @@ def shim():
     L.shim_encode_runs.restype = u64; L.shim_encode_runs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u64, C.c_void_p]
     L.shim_deposit64.argtypes = [u64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.shim_run_decode.restype = u64; L.shim_run_decode.argtypes = [C.c_void_p, u64, C.c_void_p, C.c_void_p]
+    L.shim_view_build.restype = C.c_int; L.shim_view_build.argtypes = [C.c_void_p, u32, C.c_void_p, C.c_void_p]
+    L.shim_view_symbol.restype = u32; L.shim_view_symbol.argtypes = [C.c_void_p, u32]
+    L.shim_view_count.restype = u32; L.shim_view_count.argtypes = [C.c_void_p, u32, u32]
+    L.shim_view_header.restype = u32; L.shim_view_header.argtypes = [C.c_void_p, u32]
+    L.shim_view_overflow.restype = C.c_int; L.shim_view_overflow.argtypes = [C.c_void_p]
     return L
 
 
@@ -79,6 +84,34 @@ def test_record_helpers(shim):
                 assert shim.shim_rec_count(w.ctypes.data, c, j) == int(np.sum(sym[:j] == c))
             if j < 128:
                 assert shim.shim_rec_symbol(w.ctypes.data, j) == sym[j]
+
+
+def test_search_view_record_helpers(shim):
+    """The two-plane search view (bwtm_device.h): symbol and rank at every position of records with 0 .. 7 exceptions (endmarkers
+    and N in any mix, also at positions 0 and 159), the header fields, and the overflow flag from the eighth exception on."""
+    rng = np.random.default_rng(3)
+    for trial in range(300):
+        count = 160 if trial % 5 else int(rng.integers(1, 161))                      # the last record of an index is shorter
+        sym = rng.integers(1, 5, 160).astype(np.uint8)
+        nexc = int(rng.integers(0, 10)) if trial % 3 else int(rng.integers(0, 8))
+        where = rng.choice(count, size=min(nexc, count), replace=False)
+        if trial % 7 == 0 and count == 160 and nexc >= 2:
+            where[0], where[1] = 0, 159
+        sym[where] = rng.choice([0, 5], size=where.size)
+        rel = np.zeros(6, dtype=np.uint32); rel[1:] = rng.integers(0, 1 << 25, 5)
+        v = np.zeros(16, dtype=np.uint32)
+        got_exc = shim.shim_view_build(sym.ctypes.data, count, rel.ctypes.data, v.ctypes.data)
+        true_exc = int(np.sum((sym[:count] == 0) | (sym[:count] == 5)))
+        assert got_exc == true_exc and shim.shim_view_overflow(v.ctypes.data) == (1 if true_exc > 7 else 0)
+        for c in range(1, 6):
+            assert shim.shim_view_header(v.ctypes.data, c) == rel[c]
+        if true_exc > 7:
+            continue                                                                    # such records are answered by the ordinary ones
+        for j in range(count + 1):
+            for c in range(1, 6):
+                assert shim.shim_view_count(v.ctypes.data, c, j) == int(np.sum(sym[:j] == c)), (trial, j, c)
+            if j < count:
+                assert shim.shim_view_symbol(v.ctypes.data, j) == sym[j], (trial, j)
 
 
 def test_range_mask(shim):
