@@ -22,7 +22,7 @@
 
 constexpr u32 RANGE_INLINE_WORDS = 4;          // runs that touch at most this many 32-bit words are set by the node's own lane
 constexpr u32 RANGE_PIECE_WORDS = 2048;        // longer runs: pieces of at most this many words, one workgroup each
-constexpr u32 RANGE_EXPAND_INLINE = 16;        // nodes of at most this many sequences are expanded by their own lane
+constexpr u32 RANGE_EXPAND_INLINE = 48;        // nodes of at most this many sequences are expanded by their own lane
 constexpr u32 RANGE_EXPAND_PIECE = 1024;
 
 // A long run of bits (or of elements) cut into pieces: [first, first + count) in units of bits (elements); `aux` = r for k_range_expand.
