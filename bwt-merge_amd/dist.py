@@ -84,10 +84,9 @@ def exchange_encoder_carries(lasthead, size_table_fn, rank, world, dist, torch, 
     return heads_before, offsets[rank], offsets[world]
 
 
-def upload_sharded(pkg, host_array, sequences, bases, rank, world, dist, torch, device):
-    """BWT::load of one input on `world` GPUs with every native byte crossing PCIe ONCE: this rank copies its 1 / world of the
-    page-locked bytes to its GPU, the parts are all-gathered over xGMI (RCCL) into every rank's full-size buffer, and the rank
-    decodes / transcodes its complete device copy.  Returns (index, bytes this rank received from the host)."""
+def gather_native_bytes(host_array, rank, world, dist, torch, device):
+    """Every rank copies its 1 / world of the page-locked native bytes to its device and the parts are all-gathered in place (RCCL over
+    xGMI; gloo in the CPU tests): returns (the full-size buffer: the whole stream followed by zeros, bytes this rank took from the host)."""
     nbytes = int(host_array.size)
     chunk = ((nbytes + world - 1) // world + 255) // 256 * 256
     full = torch.empty(chunk * world + 16, dtype=torch.uint8, device=device)
@@ -96,10 +95,17 @@ def upload_sharded(pkg, host_array, sequences, bases, rank, world, dist, torch, 
     if length > 0:
         full[off: off + length].copy_(torch.from_numpy(host_array[off: off + length]), non_blocking=True)
     if dist is not None and world > 1:
-        dist.all_gather_into_tensor(full[: chunk * world], full[rank * chunk: (rank + 1) * chunk])     # in place
+        dist.all_gather_into_tensor(full[: chunk * world], full[rank * chunk: (rank + 1) * chunk].clone() if full.device.type == "cpu" else full[rank * chunk: (rank + 1) * chunk])
     full[nbytes:].zero_()                                    # the borrowed form wants readable zeros behind the stream
+    return full, length
+
+
+def upload_sharded(pkg, host_array, sequences, bases, rank, world, dist, torch, device):
+    """BWT::load of one input on `world` GPUs with every native byte crossing PCIe ONCE (gather_native_bytes), then every rank decodes /
+    transcodes its complete device copy.  Returns (index, bytes this rank received from the host)."""
+    full, length = gather_native_bytes(host_array, rank, world, dist, torch, device)
     torch.cuda.synchronize()
-    ix = pkg.Index.from_device(full.data_ptr(), nbytes, sequences, bases, borrow=True)
+    ix = pkg.Index.from_device(full.data_ptr(), int(host_array.size), sequences, bases, borrow=True)
     ix.drop_native()                                         # synchronizes: `full` may go
     del full
     return ix, length

@@ -187,3 +187,37 @@ def test_sliced_frontier_model_on_cpu(oracle):
                     if c != 0:
                         outputs[g][c].append((nxt, a.LF(r, c)))
         assert seen.all() and np.array_equal(got, expect), parts
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Sharded upload (bwt-merge_amd/dist.py: gather_native_bytes): every rank contributes its part of the native bytes, all end up with the whole.
+
+def _gather_worker(rank, world, port, result_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import _pkg
+    _pkg.load()
+    from bwt_merge_amd.dist import gather_native_bytes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = []
+    for n in (0, 1, 255, 256, 257, 100003):
+        data = (np.arange(n, dtype=np.uint64) * 2654435761 % 251).astype(np.uint8)
+        mine = data.copy()
+        chunk = ((n + world - 1) // world + 255) // 256 * 256
+        own = slice(min(rank * chunk, n), min((rank + 1) * chunk, n))
+        mask = np.ones(n, dtype=bool); mask[own] = False
+        mine[mask] = 0xEE
+        full, took = gather_native_bytes(mine, rank, world, dist, torch, "cpu")
+        got = full.numpy()
+        out.append(bool(np.array_equal(got[:n], data) and not got[n:].any() and took == own.stop - own.start and got.size >= n + 16))
+    np.save(os.path.join(result_dir, "gather_%d.npy" % rank), np.array(out))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_upload_gathers_the_whole_stream(tmp_path):
+    world = 2
+    mp.start_processes(_gather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    for r in range(world):
+        assert np.load(tmp_path / ("gather_%d.npy" % r)).all()
