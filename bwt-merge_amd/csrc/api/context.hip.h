@@ -112,6 +112,7 @@ thread_local bwtm_context* t_ctx = nullptr;          // the context of the API c
 
 void vmm_setup(bwtm_context* c);
 void pool_trim(bwtm_context* c);
+void apply_env_tuning();
 
 int context_setup(bwtm_context* c, int device)
 {
@@ -120,6 +121,7 @@ int context_setup(bwtm_context* c, int device)
   if(e != hipSuccess || count <= 0) { return fail(BWTM_ENODEV, "no HIP device available (%s)", hipGetErrorString(e)); }
   if(device < 0 || device >= count) { return fail(BWTM_EINVAL, "device %d out of range (%d devices)", device, count); }
   HIP_TRY(hipSetDevice(device));
+  apply_env_tuning();
   c->device = device;
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
@@ -602,6 +604,34 @@ extern "C" void bwtm_context_destroy(bwtm_context* context)
 }
 
 extern "C" const char* bwtm_last_error(void) { return g_error.c_str(); }
+
+namespace
+{
+// BWTM_TUNE="key=value,key=value" in the environment: knobs applied once, when the first context is set up (whole test-suites run with
+// another default this way, e.g. BWTM_TUNE=search_view=1 or range_ratio=1; bwtm_tune() calls still override).
+void apply_env_tuning()
+{
+  static std::once_flag once;
+  std::call_once(once, []
+  {
+    const char* env = std::getenv("BWTM_TUNE");
+    if(!env) { return; }
+    std::string all(env);
+    size_t pos = 0;
+    while(pos < all.size())
+    {
+      size_t end = all.find(',', pos); if(end == std::string::npos) { end = all.size(); }
+      const std::string item = all.substr(pos, end - pos);
+      const size_t eq = item.find('=');
+      if(eq != std::string::npos)
+      {
+        if(bwtm_tune(item.substr(0, eq).c_str(), std::atoll(item.c_str() + eq + 1)) != BWTM_OK) { fprintf(stderr, "[bwtm] BWTM_TUNE: %s\n", g_error.c_str()); }
+      }
+      pos = end + 1;
+    }
+  });
+}
+} // namespace
 
 extern "C" int bwtm_tune(const char* key, long long value)
 {
