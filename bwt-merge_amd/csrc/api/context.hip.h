@@ -511,19 +511,6 @@ int fetch_u64(const u64* device_src, u32 slot, u32 count = 1)
   return BWTM_OK;
 }
 
-// Joins the copy stream into the compute stream (work queued later on the compute stream, including the reuse of
-// pooled buffers, waits for the copies queued so far).
-int join_copy_stream()
-{
-  hipEvent_t ev;
-  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  hipError_t e = hipEventRecord(ev, CTX.copy_stream);
-  if(e == hipSuccess) { e = hipStreamWaitEvent(CTX.stream, ev, 0); }
-  (void)hipEventDestroy(ev);
-  if(e != hipSuccess) { return fail(BWTM_ENODEV, "joining the copy stream failed: %s", hipGetErrorString(e)); }
-  return BWTM_OK;
-}
-
 // The copy stream waits for everything queued so far on the compute stream.
 int fork_copy_stream()
 {

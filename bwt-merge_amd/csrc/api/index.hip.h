@@ -420,7 +420,7 @@ int samples_width(bwtm_index* x, int* width)
   *width = 1;
   if(x->nblocks == 0) { return BWTM_OK; }
   DevBuf m; TRY(m.alloc(sizeof(u64), true));
-  LAUNCH("block_field_max", k_block_field_max, std::min<u64>(div_up(x->nblocks, BLOCK_THREADS), 2048), BLOCK_THREADS, x->view(), x->block_start.as<const u64>(), x->nblocks,
+  LAUNCH("block_field_max", k_block_field_max, std::min<u64>(div_up(x->nblocks, BLOCK_THREADS), 2048), BLOCK_THREADS, x->block_start.as<const u64>(), x->nblocks,
     m.as<unsigned long long>());
   TRY(fetch_u64(m.as<u64>(), 0));
   HIP_TRY(hipStreamSynchronize(CTX.stream));

@@ -527,7 +527,7 @@ __device__ inline void block_fields(const IndexView& x, const u64* block_start, 
   for(int c = 1; c < 6; c++) { f[c] = r1[c] - r0[c]; at[c] = r0[c]; }
 }
 
-__global__ void __launch_bounds__(BLOCK_THREADS) k_block_field_max(IndexView x, const u64* block_start, u64 nblocks, unsigned long long* out_max)
+__global__ void __launch_bounds__(BLOCK_THREADS) k_block_field_max(const u64* block_start, u64 nblocks, unsigned long long* out_max)
 {
   // grid-stride: one atomic per wave of a few thousand waves (one per 64 blocks of the stream was two million atomics on ONE address,
   // 10 - 17 ms at config 2 -- more than the download of the fields it sizes)
