@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--readlen", type=int, default=100)
     ap.add_argument("--leaf-reads", type=int, default=1 << 19)
     ap.add_argument("--torch-leaves", action="store_true", help="build the inputs' leaves with tensor ops instead of the library's builder (cross-check)")
-    ap.add_argument("--cpu-sample-reads", type=int, default=0, help="reads per set for the CPU baseline sample (0 = auto)")
+    ap.add_argument("--cpu-sample-reads", type=int, default=0, help="reads per set for the CPU baseline's large sample (0 = auto)")
     ap.add_argument("--workload", choices=("iid", "genome", "mixed"), default="iid",
                     help="iid = the headline distribution; genome = reads from a shared random genome, 30x coverage, 1 %% substitutions "
                          "(SURVEY 8(d), secondary); mixed = iid reads of 100 and 150 bp, half of the bases each (BASELINE config 5)")
@@ -69,6 +69,11 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (process group, caller-owned bitvector, all-reduce, output slices) even with one rank: "
                          "a smoke test of that path on a 1-GPU box")
+    ap.add_argument("--target", choices=("auto", "on", "off"), default="auto",
+                    help="after the configured workload, measure the north star's target size (two sets of --target-reads reads on ONE GPU) and add it to "
+                         "the line as `target`; auto = when this is the default single-GPU config-2 run and the device has the memory for it")
+    ap.add_argument("--target-reads", type=int, default=500_000_000, help="reads per set of the target measurement (5e8 x 100 bp = 50.5 Gbase)")
+    ap.add_argument("--target-steps", type=int, default=2)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -86,6 +91,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
+    import types
     import numpy as np
     import torch
     import _pkg
@@ -106,6 +112,62 @@ def main():
     for kv in args.tune:
         key, _, value = kv.partition("=")
         pkg.tune(key, int(value))
+
+    env = types.SimpleNamespace(pkg=pkg, synth=synth, np=np, torch=torch, dist=dist, dev=dev, rank=rank, world=world, sharded=sharded)
+    out = measure(env, args)
+
+    # ---------------------------------------------------------------- the north star's target size on ONE GPU
+    # "2 x 50 Gbase synthetic 100 bp reads at 1 MI355X" (BASELINE.json north_star): measured in the same run, after the configured
+    # workload has released everything, so that the driver's line carries it.  Not a second bench line: `value` stays config 2's.
+    default_shape = (args.reads == 50_000_000 and not args.reads_a and args.readlen == 100 and args.workload == "iid" and args.chain == 2
+                     and not args.torch_leaves and not args.tune)
+    want_target = (args.target == "on" or (args.target == "auto" and default_shape)) and world == 1 and not args.force_dist
+    if want_target and rank == 0:
+        free_b, total_b = torch.cuda.mem_get_info()
+        need = 230e9 * (args.target_reads / 5e8)
+        if total_b < need:
+            out["target"] = {"skipped": "the device has %.0f GB of memory, the target size needs %.0f GB" % (total_b / 1e9, need / 1e9)}
+        else:
+            out["target"] = target_record(env, args, out)
+    if rank == 0:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def target_record(env, args, base):
+    """The target-size measurement as a record of the line: resident value, host to host (full + compact), verification, roofline of
+    the dominant kernel, and the ratio to the CPU baseline of the same run."""
+    import copy
+    t_args = copy.copy(args)
+    t_args.reads, t_args.reads_a = args.target_reads, 0
+    t_args.steps, t_args.warmup, t_args.host_steps = max(1, args.target_steps), 1, 1
+    t_args.no_cpu_baseline, t_args.is_target = True, True
+    t0 = time.time()
+    try:
+        full = measure(env, t_args)
+    except Exception as e:                                   # the configured workload's numbers must survive a failure here
+        log("target measurement failed: %r" % (e,))
+        return {"failed": repr(e), "seconds": round(time.time() - t0, 1)}
+    rec = {k: full[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "job_roofline", "kernel_ms_per_step",
+                                "host_to_host", "peak_device_bytes", "verified", "verification")}
+    rec["fits_in_driver_run"] = True
+    rec["seconds"] = round(time.time() - t0, 1)
+    cpu = base.get("cpu_baseline")
+    if cpu and cpu.get("value"):
+        h2h = full.get("host_to_host") or {}
+        rec["vs_cpu_baseline"] = {"cpu_value": cpu["value"], "cpu_cores": cpu["cores"], "resident": round(full["value"] / cpu["value"], 1),
+                                  "host_to_host": (round(h2h["value"] / cpu["value"], 1) if h2h.get("value") else None),
+                                  "host_to_host_compact": (round(h2h["compact_samples"]["value"] / cpu["value"], 1) if h2h.get("compact_samples") else None),
+                                  "north_star": ">= 30 x the reference CPU Gbases/s at this size on one GPU"}
+    return rec
+
+
+def measure(env, args):
+    """One workload: inputs, timed steps, roofline, verification, host to host, CPU baseline.  Returns the line's dict on rank 0."""
+    pkg, synth, np, torch, dist, dev, rank, world, sharded = env.pkg, env.synth, env.np, env.torch, env.dist, env.dev, env.rank, env.world, env.sharded
+    is_target = bool(getattr(args, "is_target", False))
 
     def barrier():
         pkg.synchronize()
@@ -237,18 +299,15 @@ def main():
     avg_launch_s = (dom_ms / 1e3 / dom_launches) if dom_launches else float("nan")
     units_per_launch = units_per_search / launches_per_search if launches_per_search else 0
     achieved = SEARCH_BYTES_PER_BASE * units_per_launch / avg_launch_s / 1e9 if dom_launches else 0.0
-    traffic, traffic_source, traffic_gbs = None, None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "search_kernel_traffic.json")) as f:
-            t = json.load(f)
-        if (t["kernel"] == dom and t["config"]["reads_per_set"] == args.reads and not args.reads_a and t["config"]["read_length"] == args.readlen
-                and args.workload == "iid" and world == 1 and nsets == 2 and abs(t["launches_per_search"] - launches_per_search) < 0.5):
-            # per launch over ALL launches of a search (it ends with a few empty ones: the host learns the frontier size with a delay),
-            # like avg_launch_ms; traffic_GBs = bytes of a search / kernel time of a search
-            traffic, traffic_source = t["hbm_bytes_per_launch"], t["source"]
-            traffic_gbs = t["hbm_bytes_per_search"] / (dom_ms / searches / 1e3) / 1e9
-    except (OSError, KeyError, ValueError):
-        pass
+    # HBM bytes of the dominant kernel from the stored PMC passes -- used only when they were collected on THIS code (hash of the kernel's
+    # sources), with the same knobs, for the same workload, and the run reproduces the launches and LF steps of the profiled search.
+    traffic, traffic_source, traffic_gbs, traffic_why = None, None, None, None
+    entry, traffic_why = stored_traffic(dom, args, world, nsets, launches_per_search, units_per_search)
+    if entry is not None:
+        # per launch over ALL launches of a search (it ends with a few empty ones: the host learns the frontier size with a delay),
+        # like avg_launch_ms; traffic_GBs = bytes of a search / kernel time of a search
+        traffic, traffic_source = entry["hbm_bytes_per_launch"], entry["source"]
+        traffic_gbs = entry["hbm_bytes_per_search"] / (dom_ms / searches / 1e3) / 1e9
     # What this design must move per launch at the least (the "design floor"): 22 bytes of coordinates and emit per element (10 in,
     # 10 out, 2 emit; 18 without the high bytes) + the DISTINCT 64-byte records of both indexes that hold an element.  Along the
     # sorted frontier N elements spread over R records touch R (1 - exp(-N / R)) of them (0.72 R at config 2).  HBM traffic above
@@ -267,9 +326,10 @@ def main():
     # `algorithmic_frac` is the contract's figure (SURVEY 8(d)'s 160 B per LF step / measured duration): it exceeds the real
     # utilisation -- and can pass 1.0 -- because the sorted frontier shares records between neighbouring elements.
     if traffic_gbs:
-        frac, basis = traffic_gbs / HBM_PEAK_GBS, "measured HBM traffic (rocprofv3 PMC passes: FETCH_SIZE, WRITE_SIZE with the gfx950 corrections) / duration measured in this run"
+        frac, basis = traffic_gbs / HBM_PEAK_GBS, ("HBM bytes of a stored PMC profile of this code and configuration (rocprofv3 passes: FETCH_SIZE, WRITE_SIZE with the gfx950 "
+                                                   "corrections; code hash, knobs, launches and LF steps checked) / duration measured live in this run")
     elif floor_bytes:
-        frac, basis = floor_bytes / avg_launch_s / 1e9 / HBM_PEAK_GBS, "design floor bytes (no PMC pass for this configuration) / duration measured in this run"
+        frac, basis = floor_bytes / avg_launch_s / 1e9 / HBM_PEAK_GBS, "design floor bytes (no usable PMC profile: %s) / duration measured in this run" % traffic_why
     else:
         frac, basis = achieved / HBM_PEAK_GBS, "algorithmic bytes (SURVEY 8(d): 160 B per LF step; the per-chain walk fetches exactly these) / duration measured in this run"
     roofline = {"bound": "hbm", "kernel": "k_" + dom + ("_binned" if dom == "lf_walk" else ""),
@@ -282,6 +342,8 @@ def main():
                 "algorithmic_bytes_per_launch": SEARCH_BYTES_PER_BASE * units_per_launch,
                 "design_floor_bytes_per_launch": (round(floor_bytes) if floor_bytes else None),
                 "traffic_over_design_floor": (round(traffic / floor_bytes, 3) if traffic and floor_bytes else None),
+                "traffic_over_algorithmic": (round(traffic / (SEARCH_BYTES_PER_BASE * units_per_launch), 3) if traffic and units_per_launch else None),
+                "traffic_profile_check": ("matched" if traffic else traffic_why),
                 "copy_ceiling_GBs": 6290.0, "frac_of_copy_ceiling": round(frac * HBM_PEAK_GBS / 6290.0, 4),
                 "node_levels": round(node_levels, 2), "lf_steps_of_this_kernel_per_step": int(units_per_search),
                 "launches_per_step": round(launches_per_search, 2), "avg_launch_ms": round(avg_launch_s * 1e3, 4),
@@ -340,29 +402,85 @@ def main():
         one_t = torch.ones(1, dtype=torch.int64, device=dev)
         dist.all_reduce(one_t, op=dist.ReduceOp.SUM)                       # counted by the collective itself, not read from the environment
         rccl_ranks = int(one_t.item())
-    if rank == 0:
-        wname = {"iid": "sigma=6", "genome": "reads from a shared random genome, %dx coverage, %d%% substitutions" % (args.coverage, args.error_percent),
-                 "mixed": "sigma=6, 100 / 150 bp mixed"}[args.workload]
-        out = {
-            "metric": "merged Gbases/sec (input1+input2), bit-exact native BWT",
-            "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(sec_per_step * 1e3, 2), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%s Gbase synthetic %d bp read sets (%s)%s, native format, inputs resident in HBM" %
-                       (" + ".join("%.3g" % (mt["bases"] / 1e9) for mt in meta), args.readlen, wname,
-                        ", chained merge in command-line order (value = bases through all merges / time)" if nsets > 2 else ""),
-                       "reads_per_set": args.reads, "reads_input1": reads_per_set[0], "read_length": args.readlen,
-                       "bases": [mt["bases"] for mt in meta], "native_bytes": [mt["nbytes"] for mt in meta] + [out_bytes],
-                       "parallelism": "sequence blocks of input2 sharded over %d GPU(s)%s" %
-                       (world, ", RCCL all-reduce of the rank-array bitvector, result sharded by output range" if sharded else "")},
-            "roofline": roofline, "job_roofline": job, "kernel_ms_per_step": kernel_ms,
-            "host_to_host": host, "peak_device_bytes": peak_device,
-            "cpu_baseline": cpu, "verified": verified, "verification": checks,
-        }
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    for hb in host_in:
+        hb.free()
+    host_in.clear()
+    torch.cuda.empty_cache(); pkg.trim()
+    if rank != 0:
+        return None
+    wname = {"iid": "sigma=6", "genome": "reads from a shared random genome, %dx coverage, %d%% substitutions" % (args.coverage, args.error_percent),
+             "mixed": "sigma=6, 100 / 150 bp mixed"}[args.workload]
+    return {
+        "metric": "merged Gbases/sec (input1+input2), bit-exact native BWT",
+        "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(sec_per_step * 1e3, 2), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "%s Gbase synthetic %d bp read sets (%s)%s, native format, inputs resident in HBM" %
+                   (" + ".join("%.3g" % (mt["bases"] / 1e9) for mt in meta), args.readlen, wname,
+                    ", chained merge in command-line order (value = bases through all merges / time)" if nsets > 2 else ""),
+                   "reads_per_set": args.reads, "reads_input1": reads_per_set[0], "read_length": args.readlen,
+                   "bases": [mt["bases"] for mt in meta], "native_bytes": [mt["nbytes"] for mt in meta] + [out_bytes],
+                   "parallelism": "sequence blocks of input2 sharded over %d GPU(s)%s" %
+                   (world, ", RCCL all-reduce of the rank-array bitvector, result sharded by output range" if sharded else "")},
+        "roofline": roofline, "job_roofline": job, "kernel_ms_per_step": kernel_ms,
+        "host_to_host": host, "peak_device_bytes": peak_device,
+        "cpu_baseline": cpu, "verified": verified, "verification": checks,
+    }
+
+
+SEARCH_KERNEL_SOURCES = ("bwt-merge_amd/csrc/kernels/search_frontier.hip.h", "bwt-merge_amd/csrc/kernels/search_walk.hip.h",
+                         "bwt-merge_amd/csrc/kernels/common.hip.h", "bwt-merge_amd/csrc/bwtm_device.h")
+
+
+def search_code_hash():
+    """sha256 over the sources the search kernels are compiled from: a stored PMC profile describes exactly this code."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in SEARCH_KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(rel.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()
+
+
+def effective_tune(args):
+    """The knobs this run changed: --tune arguments plus the BWTM_TUNE environment of the library."""
+    knobs = sorted(kv for kv in args.tune)
+    if os.environ.get("BWTM_TUNE"):
+        knobs.append("env:" + os.environ["BWTM_TUNE"])
+    return knobs
+
+
+def stored_traffic(dom, args, world, nsets, launches_per_search, units_per_search):
+    """(entry, None) of profiles/search_kernel_traffic.json that describes this run, or (None, why not)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "search_kernel_traffic.json")) as f:
+            stored = json.load(f)
+    except (OSError, ValueError) as e:
+        return None, "profiles/search_kernel_traffic.json unreadable (%s)" % e.__class__.__name__
+    if args.workload != "iid" or world != 1 or nsets != 2 or args.reads_a:
+        return None, "no PMC passes for this workload"
+    why = "no PMC passes for %d reads of %d bp" % (args.reads, args.readlen)
+    try:
+        code = search_code_hash()
+    except OSError:
+        return None, "kernel sources not readable"
+    for e in stored.get("entries", []):
+        try:
+            if e["kernel"] != dom or e["config"]["reads_per_set"] != args.reads or e["config"]["read_length"] != args.readlen:
+                continue
+            if e.get("code_hash") != code:
+                why = "the kernel sources changed since the PMC passes (code hash differs)"
+            elif e.get("tune", []) != effective_tune(args):
+                why = "the PMC passes ran with other knobs (%s)" % (e.get("tune") or "defaults")
+            elif abs(e["launches_per_search"] - launches_per_search) >= 0.5:
+                why = "%.1f launches per search, the PMC passes saw %d" % (launches_per_search, e["launches_per_search"])
+            elif abs(e.get("lf_steps_per_search", units_per_search) - units_per_search) > 1e-6 * max(1.0, units_per_search):
+                why = "the PMC passes covered another number of LF steps"
+            else:
+                return e, None
+        except (KeyError, TypeError):
+            why = "malformed entry"
+    return None, why
 
 
 def launch_ranks(world):
@@ -507,16 +625,18 @@ def host_to_host(pkg, np, torch, dev, host_in, meta, args):
         if best is None or dt <= min(times):
             best = dict(res.times)
     t_data, t_compact, compact_phases, width = [], [], None, None
-    for _ in range(2):
+    quick = bool(getattr(args, "is_target", False))                      # the target-size record: one call less of each kind (seconds each)
+    for _ in range(1 if quick else 2):
         t0 = time.perf_counter()
         r2 = pkg.merge_host(a, b, samples=False, buffers=buffers)
         t_data.append(time.perf_counter() - t0)
-    for k in range(3):                                                   # the first call allocates the buffers of the compact form
+    for k in range(2 if quick else 3):                                   # the first call allocates the buffers of the compact form
         t0 = time.perf_counter()
         r3 = pkg.merge_host(a, b, samples=2, buffers=buffers)
         if k > 0:
             t_compact.append(time.perf_counter() - t0)
         compact_phases, width = dict(r3.times), r3.out.sample_width
+        log("host to host, compact samples, call %d: %s" % (k + 1, {kk: round(v, 1) for kk, v in r3.times.items()}))
     # PCIe calibration: plain page-locked copies of the same buffers
     hip = ctypes.CDLL("libamdhip64.so.7")
     hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
@@ -668,37 +788,57 @@ def cpu_model():
 
 
 def cpu_baseline(pkg, synth, torch, np, dev, args):
-    """Times the CPU oracle (port of the reference algorithm, all host cores, reference default
-    buffer sizes) on a bounded sample of the same workload and checks the GPU result on it."""
+    """Times the CPU oracle (port of the reference algorithm, reference default buffer sizes) on bounded samples of the same workload:
+    a sweep over thread counts on a small sample, then the best thread count on a large one (the reported value), and BASELINE
+    config 1 on one thread.  The GPU result on the large sample is compared with the oracle's byte for byte."""
     from oracle import oracle as orc
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    n = args.cpu_sample_reads or int(min(1 << 21, max(1 << 16, cores * (1 << 14))))
-    n = min(n, args.reads)
+
+    def sample(n):
+        return [orc.FMI.from_symbols(synth.leaf_symbols(args.workload, seed, 0, n, args.readlen, n, dev).cpu().numpy()) for seed in (1001, 1002)]
+
+    # (1) thread sweep: the reference's thread / merge-buffer hierarchy stops scaling long before 256 threads
+    # (profiles/r01g_cpu_baseline_threads.log), so "all cores" is not the best the CPU path can do
     t0 = time.time()
-    fm = []
-    for seed in (1001, 1002):
-        sym = synth.leaf_symbols(args.workload, seed, 0, n, args.readlen, n, dev).cpu().numpy()
-        fm.append(orc.FMI.from_symbols(sym))
-    a, b = fm
+    n_sweep = min(1 << 19, args.reads)
+    candidates = sorted(set(t for t in (16, 32, 64, cores) if t <= cores)) or [cores]
+    a_s, b_s = sample(n_sweep)
+    bases_s = a_s.bases + b_s.bases
+    sweep = []
+    for th in candidates:
+        t1 = time.perf_counter()
+        _, secs = orc.merge(a_s.clone(), b_s.clone(), threads=th)
+        dt = time.perf_counter() - t1
+        sweep.append({"threads": th, "seconds": round(dt, 3), "search_seconds": round(secs[0], 3), "value": round(bases_s / 1e9 / dt, 6)})
+        log("cpu baseline sweep, %d threads: %.2f s (%.4f Gbases/s) on 2 x %d reads" % (th, dt, sweep[-1]["value"], n_sweep))
+    del a_s, b_s
+    best = max(sweep, key=lambda s: s["value"])["threads"]
+
+    # (2) the reported value: the best thread count on the large sample
+    n = args.cpu_sample_reads or (1 << 22 if cores >= 16 else 1 << 18)
+    n = min(n, args.reads)
+    a, b = sample(n)
     A = pkg.Index.upload(a.data, a.sequences, a.bases)
     B = pkg.Index.upload(b.data, b.sequences, b.bases)
     M = pkg.merge(A, B)
     gpu_bytes = M.data()
-    log("cpu baseline sample: 2 x %d reads prepared in %.1f s; running the oracle on %d threads" % (n, time.time() - t0, cores))
-    t0 = time.perf_counter()
+    M.free(); A.free(); B.free()
+    log("cpu baseline sample: 2 x %d reads prepared (%.1f s since the start of the baseline); running the oracle on %d threads" % (n, time.time() - t0, best))
+    t1 = time.perf_counter()
     merged = a.bases + b.bases
-    m, secs = orc.merge(a, b, threads=cores)
-    dt = time.perf_counter() - t0
+    m, secs = orc.merge(a, b, threads=best)
+    dt = time.perf_counter() - t1
     ok = bool(np.array_equal(gpu_bytes, m.data))
+    del m, gpu_bytes
     log("cpu baseline: %.2f s (search %.2f s, interleave %.2f s), parity with GPU on the sample: %s" % (dt, secs[0], secs[1], ok))
-    # BASELINE config 1 (two sets of 10^5 reads) on ONE thread: the reference's `bwt_merge -t 1` plumbing case (SURVEY 8(d))
+    # (3) BASELINE config 1 (two sets of 10^5 reads) on ONE thread: the reference's `bwt_merge -t 1` plumbing case (SURVEY 8(d))
     one = None
     if not args.no_config1:
         n1 = min(100000, args.reads)
-        fm1 = [orc.FMI.from_symbols(synth.leaf_symbols(args.workload, seed, 0, n1, args.readlen, n1, dev).cpu().numpy()) for seed in (1001, 1002)]
+        fm1 = sample(n1)
         bases1 = fm1[0].bases + fm1[1].bases
         t1 = time.perf_counter()
         _, secs1 = orc.merge(fm1[0], fm1[1], threads=1)
@@ -707,10 +847,14 @@ def cpu_baseline(pkg, synth, torch, np, dev, args):
                "sample": "BASELINE config 1: two sets of %d synthetic reads (%.3g Gbase merged), oracle merge with 1 thread (bwt_merge -t 1), "
                          "timer around the merging constructor as in bwt_merge.cpp:290-297" % (n1, bases1 / 1e9)}
         log("cpu baseline, config 1 on one thread: %.2f s (%.4f Gbases/s)" % (dt1, one["value"]))
-    return {"value": round(merged / 1e9 / dt, 6), "unit": "Gbases/s", "cores": cores, "cpu_model": cpu_model(), "config1_one_thread": one, "kind": "port",
-            "sample": "two sets of %d synthetic reads of the same workload (%.3g Gbase merged), oracle merge with %d threads, reference default buffers" %
-                      (n, merged / 1e9, cores),
-            "seconds": round(dt, 3), "gpu_parity_on_sample": ok}
+    return {"value": round(merged / 1e9 / dt, 6), "unit": "Gbases/s", "cores": best, "cores_available": cores, "cpu_model": cpu_model(),
+            "thread_sweep": {"sample": "two sets of %d reads (%.3g Gbase merged)" % (n_sweep, bases_s / 1e9), "runs": sweep, "best_threads": best},
+            "config1_one_thread": one, "kind": "port",
+            "sample": "two sets of %d synthetic reads of the same workload (%.3g Gbase merged), oracle merge with %d threads (the best of the sweep %s), "
+                      "reference default buffers" % (n, merged / 1e9, best, candidates),
+            "seconds": round(dt, 3), "search_seconds": round(secs[0], 3), "gpu_parity_on_sample": ok,
+            "context": "the paper reports 8.3 - 9.4 Mbp/s INSERTED on 32 cores for real read sets (paper.tex:266), i.e. the same order of magnitude "
+                       "as this port on synthetic reads; baseline only"}
 
 
 if __name__ == "__main__":

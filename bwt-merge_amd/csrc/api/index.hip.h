@@ -430,19 +430,24 @@ int samples_width(bwtm_index* x, int* width)
 }
 
 // Compact samples to the host, chunked through two staging buffers like download_samples.
+// A chunk is 32 MiB per field row (2^25 blocks of 1-byte fields): the staging buffers are then large enough to be MAPPED blocks of the
+// pool, and a result of 10^9 blocks travels in ~40 chunks of 12 copies.  The first version staged 4 Mi blocks per chunk in buffers of
+// 24 MiB + 3 MiB, i.e. small blocks that come from hipMalloc: at 2 x 50 Gbase, with the device nearly full, those allocations (and 3420
+// copies of 0.5 - 4 MiB) made the phase take 586 ms for 8.4 GB, four times the link's time.
 template<class T>
 int download_samples_compact(bwtm_index* x, T* fields, u64* anchors)
 {
   const u64 nb = x->nblocks, nanch = div_up(nb, 64);
   if(nb == 0) { return BWTM_OK; }
-  const u64 CH = 1ull << 22;                                  // blocks per chunk (a multiple of 64)
-  DevBuf stage_f[2], stage_a[2];
+  const u64 CH = std::min<u64>((32ull << 20) / sizeof(T), div_up(nb, 64) * 64);      // blocks per chunk (a multiple of 64)
+  const u64 field_bytes = 6 * CH * sizeof(T);                                         // a multiple of 64 bytes: the anchors behind them stay aligned
+  DevBuf stage[2];
   hipEvent_t filled[2] = {nullptr, nullptr}, drained[2] = {nullptr, nullptr};
   auto body = [&]() -> int
   {
-    for(int k = 0; k < 2; k++)
+    for(int k = 0; k < 2 && (k == 0 || nb > CH); k++)
     {
-      TRY(stage_f[k].alloc(6 * CH * sizeof(T))); TRY(stage_a[k].alloc(6 * (CH / 64) * sizeof(u64)));
+      TRY(stage[k].alloc(field_bytes + 6 * (CH / 64) * sizeof(u64)));
       HIP_TRY(hipEventCreateWithFlags(&filled[k], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&drained[k], hipEventDisableTiming));
     }
@@ -451,15 +456,17 @@ int download_samples_compact(bwtm_index* x, T* fields, u64* anchors)
     {
       const int k = (int)(round & 1);
       const u64 cnt = std::min(CH, nb - b0), na = div_up(cnt, 64);
+      T* sf = stage[k].as<T>();
+      u64* sa = (u64*)(stage[k].as<u8>() + field_bytes);
       if(round >= 2) { HIP_TRY(hipStreamWaitEvent(CTX.stream, drained[k], 0)); }
       LAUNCH("block_fields", k_block_fields<T>, div_up(cnt, BLOCK_THREADS), BLOCK_THREADS, x->view(), x->block_start.as<const u64>(), b0, cnt,
-        stage_f[k].as<T>(), CH, stage_a[k].as<u64>(), CH / 64);
+        sf, CH, sa, CH / 64);
       HIP_TRY(hipEventRecord(filled[k], CTX.stream));
       HIP_TRY(hipStreamWaitEvent(CTX.copy_stream, filled[k], 0));
       for(u64 c = 0; c < 6; c++)
       {
-        HIP_TRY(hipMemcpyAsync(fields + c * nb + b0, stage_f[k].as<T>() + c * CH, cnt * sizeof(T), hipMemcpyDeviceToHost, CTX.copy_stream));
-        HIP_TRY(hipMemcpyAsync(anchors + c * nanch + b0 / 64, stage_a[k].as<u64>() + c * (CH / 64), na * sizeof(u64), hipMemcpyDeviceToHost, CTX.copy_stream));
+        HIP_TRY(hipMemcpyAsync(fields + c * nb + b0, sf + c * CH, cnt * sizeof(T), hipMemcpyDeviceToHost, CTX.copy_stream));
+        HIP_TRY(hipMemcpyAsync(anchors + c * nanch + b0 / 64, sa + c * (CH / 64), na * sizeof(u64), hipMemcpyDeviceToHost, CTX.copy_stream));
       }
       HIP_TRY(hipEventRecord(drained[k], CTX.copy_stream));
     }
