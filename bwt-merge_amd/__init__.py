@@ -10,5 +10,8 @@ from .capi import (FSlice, FSliceView, Builder, BwtmError, Context, HostBuffer, 
                    ra_buffer_bytes, synchronize, trim, tune)
 
 
-def build(force=False, verbose=False):
-    return _build.build(force=force, verbose=verbose)
+from .capi import experimental, EXPERIMENTAL_LIB_PATH      # noqa: F401
+
+
+def build(force=False, verbose=False, experimental=False):
+    return _build.build(force=force, verbose=verbose, experimental=experimental)

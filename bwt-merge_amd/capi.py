@@ -101,13 +101,6 @@ SYMBOLS = [
     ("bwtm_search", C.c_int, [vp, vp, u64, u64, vp]),
     ("bwtm_ra_device_buffer", C.c_int, [vp, C.POINTER(vp), p_u64]),
     ("bwtm_ra_finalize", C.c_int, [vp]),
-    ("bwtm_fslice_create", C.c_int, [vp, vp, vp, u64, C.c_int, C.POINTER(vp)]),
-    ("bwtm_fslice_free", None, [vp]),
-    ("bwtm_fslice_seed", C.c_int, [vp, u64, u64]),
-    ("bwtm_fslice_export", C.c_int, [vp, vp]),
-    ("bwtm_fslice_gather", C.c_int, [vp, vp, C.c_int, u64, u64]),
-    ("bwtm_fslice_advance", C.c_int, [vp]),
-    ("bwtm_fslice_finish", C.c_int, [vp]),
     ("bwtm_ra_subset_check", C.c_int, [vp, vp, p_u64, p_u64]),
     ("bwtm_ra_values", u64, [vp]),
     ("bwtm_ra_download", C.c_int, [vp, p_u64, u64]),
@@ -125,6 +118,20 @@ SYMBOLS = [
     ("bwtm_profile_reset", C.c_int, []),
     ("bwtm_profile_read", C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), p_u64, C.c_int]),
 ]
+
+
+# Every symbol include/bwtm_experimental.h declares: exported only by libbwtm_experimental.so (-DBWTM_EXPERIMENTAL), which the tests of
+# these features select with BWTM_LIB
+EXPERIMENTAL_SYMBOLS = [
+    ("bwtm_fslice_create", C.c_int, [vp, vp, vp, u64, C.c_int, C.POINTER(vp)]),
+    ("bwtm_fslice_free", None, [vp]),
+    ("bwtm_fslice_seed", C.c_int, [vp, u64, u64]),
+    ("bwtm_fslice_export", C.c_int, [vp, vp]),
+    ("bwtm_fslice_gather", C.c_int, [vp, vp, C.c_int, u64, u64]),
+    ("bwtm_fslice_advance", C.c_int, [vp]),
+    ("bwtm_fslice_finish", C.c_int, [vp]),
+]
+EXPERIMENTAL_LIB_PATH = os.path.join(HERE, "libbwtm_experimental.so")
 
 
 class BwtmError(RuntimeError):
@@ -153,8 +160,29 @@ def lib():
             f = getattr(L, name)       # AttributeError if the library does not export it
             f.restype = res
             f.argtypes = args
+        global _experimental
+        _experimental = hasattr(L, EXPERIMENTAL_SYMBOLS[0][0])
+        if _experimental:
+            for name, res, args in EXPERIMENTAL_SYMBOLS:
+                f = getattr(L, name)
+                f.restype = res
+                f.argtypes = args
         _lib = L
     return _lib
+
+
+_experimental = False
+
+
+def experimental():
+    """True when the loaded library is the experimental build (include/bwtm_experimental.h)."""
+    lib()
+    return _experimental
+
+
+def need_experimental(what):
+    if not experimental():
+        raise BwtmError("%s is not part of libbwtm.so: load the experimental build (BWTM_LIB=%s)" % (what, EXPERIMENTAL_LIB_PATH))
 
 
 def check(rc):
@@ -696,6 +724,7 @@ class FSlice:
     """One GPU's state of the sliced frontier search (bwtm_fslice; include/bwtm.h)."""
 
     def __init__(self, a, b, ra, capacity, parts):
+        need_experimental("the sliced frontier search")
         out = vp()
         check(lib().bwtm_fslice_create(a.h, b.h, ra.h, capacity, parts, C.byref(out)))
         self.h = out

@@ -78,13 +78,15 @@ struct Tuning
   long long l1_cap = 0;           // tests: entries per level-1 region / emit capacity (0 = sized from the input): forces the exact fallbacks
   long long emit_path = 0;        // 0 = partitioned emit (default), 1 = atomicOr on the bitvector (the exact fallback, first version)
   long long round_emits = 1ll << 33;      // upper bound of emits partitioned per round of the walk (bounds the temporary regions)
-  long long emit_budget = 16ll << 30;     // bytes of dense emits the frontier search keeps before it builds tiles (one epoch)
+  long long emit_budget = 0;              // bytes of dense emits the frontier search keeps before it builds tiles (one epoch); 0 = from the free memory (16 - 64 GB)
   long long frontier_epoch = 512;         // upper bound of steps per epoch (tests use small values)
   long long eager_cum_budget = 16ll << 30; // bwtm_index_encode materializes the samples' cumulative counts when they take at most this many bytes
   long long upload_chunk = 256ll << 20;   // bytes per H2D chunk of the pipelined upload (64 MiB: 141.8 ms for 7.64 GB, 256 MiB and 1 GiB: 140.3)
   long long download_chunk = 128ll << 20; // approximate bytes per D2H chunk of the pipelined download
   long long range_ratio = 8;              // frontier search: levels with at most (sequences / range_ratio) trie nodes are processed as nodes (k_range_*); 0 = never, 1 = as long as possible
+#ifdef BWTM_EXPERIMENTAL
   long long search_view = 0;              // the frontier search reads the two-plane search view: 0 = never (default: it saves 14 % of the HBM reads and no time), 1 = always, 2 = by size
+#endif
   long long frontier_parts = 0;           // > 1: every step of the frontier search as this many launches over slices of the frontier (a measurement, same results)
   long long ingest_verify = 0;            // 1 = the builder checks every leaf's suffix order against the reads (one extra pass of gathers per leaf)
 #ifdef BWTM_DIAGNOSTICS
@@ -594,45 +596,20 @@ extern "C" const char* bwtm_last_error(void) { return g_error.c_str(); }
 
 namespace
 {
-// BWTM_TUNE="key=value,key=value" in the environment: knobs applied once, when the first context is set up (whole test-suites run with
-// another default this way, e.g. BWTM_TUNE=search_view=1 or range_ratio=1; bwtm_tune() calls still override).
-void apply_env_tuning()
+int tune_set(const char* key, long long value)
 {
-  static std::once_flag once;
-  std::call_once(once, []
-  {
-    const char* env = std::getenv("BWTM_TUNE");
-    if(!env) { return; }
-    std::string all(env);
-    size_t pos = 0;
-    while(pos < all.size())
-    {
-      size_t end = all.find(',', pos); if(end == std::string::npos) { end = all.size(); }
-      const std::string item = all.substr(pos, end - pos);
-      const size_t eq = item.find('=');
-      if(eq != std::string::npos)
-      {
-        if(bwtm_tune(item.substr(0, eq).c_str(), std::atoll(item.c_str() + eq + 1)) != BWTM_OK) { fprintf(stderr, "[bwtm] BWTM_TUNE: %s\n", g_error.c_str()); }
-      }
-      pos = end + 1;
-    }
-  });
-}
-} // namespace
-
-extern "C" int bwtm_tune(const char* key, long long value)
-{
-  if(!key) { return fail(BWTM_EINVAL, "bwtm_tune: null key"); }
   std::string k(key);
   if(k == "search_algo") { g_tune.search_algo = value; }
   else if(k == "frontier_unfused") { g_tune.frontier_unfused = value; }
   else if(k == "l1_cap") { g_tune.l1_cap = value; }
   else if(k == "emit_path") { g_tune.emit_path = value; }
   else if(k == "round_emits") { g_tune.round_emits = (value > 0 ? value : 1); }
-  else if(k == "emit_budget") { g_tune.emit_budget = (value > 0 ? value : (16ll << 30)); }
+  else if(k == "emit_budget") { g_tune.emit_budget = (value > 0 ? value : 0); }
   else if(k == "frontier_epoch") { g_tune.frontier_epoch = (value > 0 ? value : 512); }
   else if(k == "range_ratio") { g_tune.range_ratio = (value >= 0 ? value : 8); }
+#ifdef BWTM_EXPERIMENTAL
   else if(k == "search_view") { g_tune.search_view = (value >= 0 && value <= 2 ? value : 0); }
+#endif
   else if(k == "frontier_parts") { g_tune.frontier_parts = (value > 0 ? value : 0); }
   else if(k == "ingest_verify") { g_tune.ingest_verify = (value != 0); }
   else if(k == "eager_cum_budget") { g_tune.eager_cum_budget = (value > 0 ? value : (16ll << 30)); }
@@ -648,6 +625,41 @@ extern "C" int bwtm_tune(const char* key, long long value)
 #endif
   else { return fail(BWTM_EINVAL, "bwtm_tune: unknown key %s", key); }
   return BWTM_OK;
+}
+
+// BWTM_TUNE="key=value,key=value" in the environment: knobs applied ONCE, before the first bwtm_tune() call takes effect or the first
+// context is set up, whichever comes first -- so a bwtm_tune() call always overrides the environment, also when it is made before any
+// GPU call (whole test-suites run with another default this way, e.g. BWTM_TUNE=range_ratio=1).
+void apply_env_tuning()
+{
+  static std::mutex mu;
+  static bool done = false;
+  std::lock_guard<std::mutex> lock(mu);            // a concurrent caller waits until the environment has been applied
+  if(done) { return; }
+  done = true;
+  const char* env = std::getenv("BWTM_TUNE");
+  if(!env) { return; }
+  std::string all(env);
+  size_t pos = 0;
+  while(pos < all.size())
+  {
+    size_t end = all.find(',', pos); if(end == std::string::npos) { end = all.size(); }
+    const std::string item = all.substr(pos, end - pos);
+    const size_t eq = item.find('=');
+    if(eq != std::string::npos)
+    {
+      if(tune_set(item.substr(0, eq).c_str(), std::atoll(item.c_str() + eq + 1)) != BWTM_OK) { fprintf(stderr, "[bwtm] BWTM_TUNE: %s\n", g_error.c_str()); }
+    }
+    pos = end + 1;
+  }
+}
+} // namespace
+
+extern "C" int bwtm_tune(const char* key, long long value)
+{
+  if(!key) { return fail(BWTM_EINVAL, "bwtm_tune: null key"); }
+  apply_env_tuning();
+  return tune_set(key, value);
 }
 
 extern "C" int bwtm_trim(void)

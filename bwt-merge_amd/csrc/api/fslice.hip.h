@@ -90,7 +90,7 @@ extern "C" int bwtm_fslice_create(const bwtm_index* a, const bwtm_index* b, bwtm
     HIP_TRY(hipHostMalloc((void**)&fs->host_pieces, (u64)fs->max_pieces * sizeof(SlicePiece), hipHostMallocDefault));
     // dense emits of an epoch of steps, as in search_frontier()
     const u64 per_seq = b->n / (b->m > 0 ? b->m : 1) + 1;
-    fs->emit_cap = std::min<u64>((u64)g_tune.emit_budget / sizeof(unsigned short), 2 * capacity * per_seq + (1ull << 20));
+    fs->emit_cap = std::min<u64>((u64)(g_tune.emit_budget > 0 ? g_tune.emit_budget : (16ll << 30)) / sizeof(unsigned short), 2 * capacity * per_seq + (1ull << 20));
     if(fs->emit_cap < capacity) { fs->emit_cap = capacity; }
     fs->EPOCH = std::max<u64>(1, std::min<u64>((u64)std::max<long long>(1, g_tune.frontier_epoch), fs->emit_cap / capacity));
     const u64 bound_budget = 2ull << 30;

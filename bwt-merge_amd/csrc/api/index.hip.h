@@ -26,8 +26,11 @@ struct bwtm_index
   DevBuf gcum; u64 ngroups = 0;       // 6 x (ngroups + 1) u64: cumulative symbol counts at the starts of the 62-block groups
   DevBuf cum;                         // 6 x (nblocks + 1) u64: cumulative symbol counts at block starts (built on demand)
   DevBuf flags;                       // k_block_len's verdict on the stream (read by upload_validate)
+#ifdef BWTM_EXPERIMENTAL
   mutable DevBuf sview, vsup;         // the search view (built on demand by the frontier search, dropped with the records)
   mutable u64 nview = 0;
+  mutable bool view_ready = false;    // set after both kernels that fill the view were queued
+#endif
 
   IndexView view() const
   {
@@ -35,7 +38,9 @@ struct bwtm_index
     v.recs = recs.as<const uint4>(); v.sup = sup.as<const u64>();
     v.n = n; v.m = m; v.nrecs = nrecs;
     for(int c = 0; c < 8; c++) { v.C[c] = C[c]; }
-    v.view = sview.as<const uint4>(); v.vsup = vsup.as<const u64>(); v.nview = (sview.p ? nview : 0);
+#ifdef BWTM_EXPERIMENTAL
+    v.view = (view_ready ? sview.as<const uint4>() : nullptr); v.vsup = (view_ready ? vsup.as<const u64>() : nullptr); v.nview = (view_ready ? nview : 0);
+#endif
     return v;
   }
 };
@@ -72,6 +77,7 @@ int alloc_native(DevBuf& buf, u64 nbytes)
 struct UploadEvents
 {
   std::vector<hipEvent_t> ev;
+  u64 groups_per_chunk = 0;              // the chunking the copies were queued with (the upload_chunk knob may change before they are consumed)
   UploadEvents() {}
   UploadEvents(const UploadEvents&) = delete; UploadEvents& operator=(const UploadEvents&) = delete;
   ~UploadEvents() { for(hipEvent_t e : ev) { (void)hipEventDestroy(e); } }
@@ -104,6 +110,7 @@ int upload_copies(bwtm_index* x, const u8* host_src, UploadEvents& events)
 {
   const u64 group_bytes = (u64)GROUP * RLE_BLOCK;
   const u64 groups_per_chunk = upload_groups_per_chunk(x, true);
+  events.groups_per_chunk = groups_per_chunk;
   for(u64 g0 = 0; g0 < x->ngroups; g0 += groups_per_chunk)
   {
     const u64 g1 = std::min(x->ngroups, g0 + groups_per_chunk);
@@ -125,7 +132,8 @@ int upload_copies(bwtm_index* x, const u8* host_src, UploadEvents& events)
 int upload_decode(bwtm_index* x, const UploadEvents* events)
 {
   const u64 gstride = x->ngroups + 1;
-  const u64 groups_per_chunk = upload_groups_per_chunk(x, events != nullptr);
+  const u64 groups_per_chunk = (events && events->groups_per_chunk > 0 ? events->groups_per_chunk : upload_groups_per_chunk(x, events != nullptr));
+  if(events && events->ev.size() != div_up(x->ngroups, groups_per_chunk)) { return fail(BWTM_EINVAL, "upload: %zu chunk events for %llu chunks", events->ev.size(), (unsigned long long)div_up(x->ngroups, groups_per_chunk)); }
   u64 chunk = 0;
   for(u64 g0 = 0; g0 < x->ngroups; g0 += groups_per_chunk, chunk++)
   {
@@ -236,21 +244,30 @@ int ensure_block_cum(bwtm_index* x)
   return BWTM_OK;
 }
 
-// The search view of an index (bwtm_device.h, kernels/search_view.hip.h): built when the frontier search first wants it, kept with
-// the records (a chained merge searches the same first input again), released with the handle.
+#ifdef BWTM_EXPERIMENTAL
+// The search view of an index (bwtm_view.h, kernels/search_view.hip.h): built when the frontier search first wants it, kept with
+// the records (a chained merge searches the same first input again), released with the handle.  A launch that fails leaves no
+// half-built view behind: the buffers are released and the search goes on with the ordinary records.
 int ensure_view(const bwtm_index* x)
 {
-  if(x->sview.p) { return BWTM_OK; }
+  if(x->view_ready) { return BWTM_OK; }
   x->nview = num_view_records(x->n);
   const u64 nvsup = num_view_supers(x->n);
-  TRY(x->vsup.alloc(nvsup * SUP_STRIDE * sizeof(u64)));
-  int rc = x->sview.alloc(x->nview * 64);
-  if(rc != BWTM_OK) { x->vsup.release(); return rc; }
-  IndexView v = x->view(); v.view = nullptr; v.nview = 0;
-  LAUNCH("view_sup", k_view_sup, div_up(nvsup, BLOCK_THREADS), BLOCK_THREADS, v, x->vsup.as<u64>(), nvsup);
-  LAUNCH("view_build", k_view_build, div_up(x->nview, BLOCK_THREADS), BLOCK_THREADS, v, x->vsup.as<const u64>(), x->sview.as<uint4>(), x->nview);
+  auto build = [&]() -> int
+  {
+    TRY(x->vsup.alloc(nvsup * SUP_STRIDE * sizeof(u64)));
+    TRY(x->sview.alloc(x->nview * 64));
+    IndexView v = x->view();
+    LAUNCH("view_sup", k_view_sup, div_up(nvsup, BLOCK_THREADS), BLOCK_THREADS, v, x->vsup.as<u64>(), nvsup);
+    LAUNCH("view_build", k_view_build, div_up(x->nview, BLOCK_THREADS), BLOCK_THREADS, v, x->vsup.as<const u64>(), x->sview.as<uint4>(), x->nview);
+    return BWTM_OK;
+  };
+  const int rc = build();
+  if(rc != BWTM_OK) { x->sview.release(); x->vsup.release(); return rc; }
+  x->view_ready = true;
   return BWTM_OK;
 }
+#endif
 
 //------------------------------------------------------------------------------
 // Encoder: records -> native bytes (RunBuffer + Run::write) + block starts (BWT::build).
@@ -291,12 +308,15 @@ int encode_size(bwtm_index* x, EncodePlan& plan)
 
 // Emit pass.  With `host_out` the bytes of every finished range of segments are copied to the host on the copy stream
 // while the next range is being written (the caller joins the copy stream).
-int encode_emit(bwtm_index* x, EncodePlan& plan, u8* host_out)
+int encode_emit(bwtm_index* x, EncodePlan& plan, u8* host_out, bool with_cum = false)
 {
   const u64 total = plan.total;
   x->nbytes = total;
   x->nblocks = div_up(total, RLE_BLOCK);
   TRY(alloc_native(x->data, total));
+  x->gcum.release(); x->ngroups = 0; x->cum.release();
+  const u64 cum_stride = x->nblocks + 1;
+  if(with_cum) { TRY(x->cum.alloc(6 * cum_stride * sizeof(u64))); }
   // k_enc_emit records the position at which every 64-byte block starts; the entry after the last block is n
   TRY(x->block_start.alloc((x->nblocks + 1) * sizeof(u64)));
   CTX.host_scratch[63] = x->n;
@@ -312,8 +332,16 @@ int encode_emit(bwtm_index* x, EncodePlan& plan, u8* host_out)
     const u64 s0 = g0 * FOLD_GROUP, s1 = std::min(plan.nseg, g1 * FOLD_GROUP);
     auto launch = [&]() -> int
     {
-      LAUNCH("enc_emit", k_enc_emit, div_up((s1 - s0) * WAVE, BLOCK_THREADS), BLOCK_THREADS, x->recs.as<const uint4>(), x->nrecs, x->n, plan.ntiles, s0, s1,
-        plan.lasthead.as<const u64>(), (u64)0, plan.seg_base.as<const u64>(), x->data.as<u8>(), x->block_start.as<u64>());
+      if(with_cum)
+      {
+        LAUNCH("enc_emit", k_enc_emit<true>, div_up((s1 - s0) * WAVE, BLOCK_THREADS), BLOCK_THREADS, x->recs.as<const uint4>(), x->nrecs, x->n, plan.ntiles, s0, s1,
+          plan.lasthead.as<const u64>(), (u64)0, plan.seg_base.as<const u64>(), x->data.as<u8>(), x->block_start.as<u64>(), x->view(), x->cum.as<u64>(), cum_stride);
+      }
+      else
+      {
+        LAUNCH("enc_emit", k_enc_emit<false>, div_up((s1 - s0) * WAVE, BLOCK_THREADS), BLOCK_THREADS, x->recs.as<const uint4>(), x->nrecs, x->n, plan.ntiles, s0, s1,
+          plan.lasthead.as<const u64>(), (u64)0, plan.seg_base.as<const u64>(), x->data.as<u8>(), x->block_start.as<u64>(), x->view(), (u64*)nullptr, (u64)0);
+      }
       return BWTM_OK;
     };
     rc = launch();
@@ -328,7 +356,16 @@ int encode_emit(bwtm_index* x, EncodePlan& plan, u8* host_out)
     g0 = g1;
   }
   if(ev) { (void)hipEventDestroy(ev); }
-  x->gcum.release(); x->ngroups = 0; x->cum.release();
+  if(rc == BWTM_OK && with_cum)
+  {
+    // the entry behind the last block: the counts at n (every block's own entry was stored by the lane that opened it)
+    auto last = [&]() -> int
+    {
+      LAUNCH("block_cum", k_block_cum, 1, BLOCK_THREADS, x->view(), x->block_start.as<const u64>(), x->nblocks, (u64)1, x->cum.as<u64>() + x->nblocks, cum_stride);
+      return BWTM_OK;
+    };
+    rc = last();
+  }
   x->has_native = true;
   return rc;
 }
@@ -341,7 +378,12 @@ int encode_blocking(bwtm_index* x)
   {
     EncodePlan plan;
     TRY(encode_size(x, plan));
-    TRY(encode_emit(x, plan, nullptr));
+    // BWT::build, bwt.cpp:476-512: the samples of the new stream.  block_start is always there; the six cumulative count arrays are
+    // answered by the rank structure and materialized -- by the emit pass itself -- only when they are small enough to sit next to
+    // everything else (a 2 x 50 Gbase result has 57 GB of them: produced in chunks when downloaded).
+    const u64 blocks = div_up(plan.total, RLE_BLOCK);
+    TRY(encode_emit(x, plan, nullptr, 6 * (blocks + 1) * sizeof(u64) <= (u64)g_tune.eager_cum_budget));
+    return BWTM_OK;
   }
   else
   {
@@ -350,10 +392,7 @@ int encode_blocking(bwtm_index* x)
     x->gcum.release(); x->ngroups = 0; x->cum.release();
     x->has_native = true;
   }
-  // BWT::build, bwt.cpp:476-512: the samples of the new stream.  block_start is always there; the six cumulative count
-  // arrays are answered by the rank structure (k_block_cum) and materialized now only when they are small enough to
-  // sit next to everything else (a 2 x 50 Gbase result has 57 GB of them: produced in chunks when downloaded).
-  if(6 * (x->nblocks + 1) * sizeof(u64) <= (u64)g_tune.eager_cum_budget) { TRY(ensure_block_cum(x)); }
+  if(6 * (x->nblocks + 1) * sizeof(u64) <= (u64)g_tune.eager_cum_budget) { TRY(ensure_block_cum(x)); }      // the empty index: one entry
   return BWTM_OK;
 }
 

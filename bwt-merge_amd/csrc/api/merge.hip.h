@@ -326,7 +326,8 @@ extern "C" int bwtm_merge_host_pipelined(bwtm_index* a_device, const bwtm_host_i
     return fail(BWTM_EINVAL, "bwtm_merge_host_pipelined: exactly one form of each input is required (and `keep` for a result that stays on the device)");
   }
   if(next_pending) { *next_pending = nullptr; }
-  ENTER(a_device ? a_device->ctx : (b_pending && b_pending->x ? b_pending->x->ctx : nullptr));
+  Scope scope_(a_device ? a_device->ctx : (b_pending && b_pending->x ? b_pending->x->ctx : nullptr));
+  if(scope_.rc != BWTM_OK) { bwtm_index_free(a_device); bwtm_upload_free(b_pending); return scope_.rc; }      // consumed on every exit path
   return merge_host_impl(a_device, a_host, b_host, b_pending, next, next_pending, alloc, user, want_samples, out, keep);
 }
 
@@ -369,6 +370,8 @@ extern "C" void bwtm_upload_free(bwtm_upload* upload)
 {
   if(!upload) { return; }
   Scope scope(upload->x ? upload->x->ctx : nullptr);
-  if(scope.rc == BWTM_OK) { (void)hipStreamSynchronize(CTX.copy_stream); }       // queued copies still read the caller's buffer
+  // queued copies still read the caller's buffer: drain the copy stream, or the whole device when the context cannot be entered
+  if(scope.rc == BWTM_OK) { (void)hipStreamSynchronize(CTX.copy_stream); }
+  else { (void)hipDeviceSynchronize(); }
   delete upload;
 }

@@ -235,6 +235,8 @@ struct RangeLevels
   u64 N = 0, alive = 0, levels = 0;
   u32 piece_cap = 0;
   int cur = 0;
+  // stream ordered: the kernels queued so far still read the buffers, later allocations may take them over
+  void release() { for(int k = 0; k < 2; k++) { sp[k].release(); r[k].release(); cnt[k].release(); } flags.release(); pieces.release(); npieces.release(); }
 };
 
 int range_phase(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64 count, bwtm_ra* ra, u64 limit, RangeLevels& L)
@@ -300,7 +302,10 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   const bool node_phase = (g_tune.range_ratio > 0);
   if(node_phase)
   {
-    const u64 limit = std::max<u64>(1, std::min<u64>(count / (u64)g_tune.range_ratio, 1ull << 24));
+    // The cap bounds the level tables (7 arrays of 5 x limit + 1 words: 9.4 GB at 2^25, released before the step loop starts).  2^25
+    // and not 2^24 because level 12 of a read collection has 4^12 = 2^24 nodes plus the few that N adds: at 5 x 10^8 sequences the ratio
+    // rule allows that level (a node level there costs ~2 ms, the element step it replaces 9.5 ms), and 2^24 cut it off by a hair.
+    const u64 limit = std::max<u64>(1, std::min<u64>(count / (u64)g_tune.range_ratio, 1ull << 25));
     TRY(range_phase(a, b, seq_first, count, ra, limit, levels));
     if(levels.N == 0) { return BWTM_OK; }
     TRY(range_alive(levels, node_offsets));
@@ -316,7 +321,18 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   // step): a step emits at most `count` values (the frontier only shrinks), so an epoch of k steps needs room for k * count
   // emits.  At config 2 (5e7 sequences of 101 symbols) one epoch holds the whole search; a 50 Gbase input takes seven.
   const u64 per_seq = b->n / (b->m > 0 ? b->m : 1) + 1;
-  u64 emit_cap = (u64)g_tune.emit_budget / sizeof(unsigned short);
+  // Budget of the dense emits: a third of the memory that is free now (pool included), between 16 and 64 GB, unless the caller fixed it.
+  // Every epoch ends with a tile build that reads and rewrites the whole bitvector: at 2 x 50 Gbase a fixed 16 GB meant 7 epochs
+  // (43.7 ms of tile builds per merge), while 130 GB were free during the search.
+  u64 emit_budget = (u64)g_tune.emit_budget;
+  if(emit_budget == 0)
+  {
+    emit_budget = 16ull << 30;
+    size_t free_b = 0, total_b = 0;
+    if(hipMemGetInfo(&free_b, &total_b) == hipSuccess) { emit_budget = std::min<u64>(std::max<u64>(emit_budget, ((u64)free_b + CTX.cached_bytes) / 3), 64ull << 30); }
+    else { (void)hipGetLastError(); }
+  }
+  u64 emit_cap = emit_budget / sizeof(unsigned short);
   if(emit_cap > b->n + 64) { emit_cap = b->n + 64; }              // a search never emits more than one value per position of b
   if(emit_cap > 2 * count * per_seq + (1ull << 20)) { emit_cap = 2 * count * per_seq + (1ull << 20); }   // a shard of the sequences: far less
   if(emit_cap < count) { emit_cap = count; }                      // at least one step per epoch
@@ -357,6 +373,7 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   {
     TRY(range_expand(levels, node_offsets, lo[0].as<uint2>(), hi[0].as<unsigned short>()));
     LAUNCH("frontier_init", k_frontier_init_tables, div_up(nseg + 1, BLOCK_THREADS), BLOCK_THREADS, seg_len[0].as<u64>(), seg_phys[0].as<u64>(), nb_max, count);
+    levels.release(); node_offsets.release();                       // up to 10 GB at 5 x 10^8 sequences: not held through the step loop
   }
   else
   {
@@ -367,6 +384,7 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   int cur = 0;
   u64 in_epoch = 0;
   u64 alive_bound = count, epoch_used = 0;                         // N_t <= alive_bound; emits reserved in this epoch so far
+#ifdef BWTM_EXPERIMENTAL
   // The search view (two bit-planes + exceptions, 0.4 instead of 0.5 bytes per base): worth building when the search will stream the
   // indexes often enough -- long frontiers of many steps -- and memory allows; search_view: 0 = never, 1 = always (tests), 2 = by size.
   bool use_view = (g_tune.search_view == 1);
@@ -384,6 +402,7 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
     if(rc_view == BWTM_OK) { rc_view = ensure_view(b); }
     if(rc_view != BWTM_OK) { use_view = false; }                  // no room: the ordinary records do
   }
+#endif
   // Blocks launched per step: the frontier only shrinks, and blocks past its end would only publish empty segments.  The grid
   // follows the (delayed) size when at least a quarter of it would be idle (reads of mixed lengths: after the short ones have ended);
   // the segment entries a buffer still holds from the wider grid that wrote it last are cleared then.
@@ -456,8 +475,10 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
         else { LAUNCH(label, (k_frontier_step<0, false>), nb_part, FR_BLOCK, a->view(), b->view(), f); }
       }
     }
+#ifdef BWTM_EXPERIMENTAL
     else if(use_view && wide) { LAUNCH("frontier_step", (k_frontier_step<0, true, true>), grid, FR_BLOCK, a->view(), b->view(), f); }
     else if(use_view) { LAUNCH("frontier_step", (k_frontier_step<0, false, true>), grid, FR_BLOCK, a->view(), b->view(), f); }
+#endif
     else if(wide) { LAUNCH("frontier_step", (k_frontier_step<0, true>), grid, FR_BLOCK, a->view(), b->view(), f); }
     else { LAUNCH("frontier_step", (k_frontier_step<0, false>), grid, FR_BLOCK, a->view(), b->view(), f); }
     // the size of step t reaches the host behind step t's kernels: recorded AFTER the step kernel, so that reduce, scan and step

@@ -47,7 +47,9 @@ struct bwtm_slice
     v.recs = recs_virtual(); v.sup = sup.as<const u64>();
     v.n = n; v.m = m; v.nrecs = nrecs_total;
     for(int c = 0; c < 8; c++) { v.C[c] = C[c]; }
+#ifdef BWTM_EXPERIMENTAL
     v.view = nullptr; v.vsup = nullptr; v.nview = 0;
+#endif
     return v;
   }
 };
@@ -211,9 +213,9 @@ extern "C" int bwtm_slice_encode(bwtm_slice* s, uint64_t byte_offset)
     s->nblocks = div_up(s->byte_end, RLE_BLOCK) - s->block_first;
     TRY(alloc_native(s->data, s->byte_end - base));
     TRY(s->block_start.alloc((s->nblocks + 1) * sizeof(u64), true));
-    LAUNCH("enc_emit", k_enc_emit, div_up(nseg * WAVE, BLOCK_THREADS), BLOCK_THREADS, s->recs_virtual(), s->nrecs_total, s->n, ntiles, s->seg_first, s->seg_end,
+    LAUNCH("enc_emit", k_enc_emit<false>, div_up(nseg * WAVE, BLOCK_THREADS), BLOCK_THREADS, s->recs_virtual(), s->nrecs_total, s->n, ntiles, s->seg_first, s->seg_end,
       s->lasthead.as<const u64>() - s->seg_first, s->head_carry, s->seg_base.as<const u64>() - s->seg_first, s->data.as<u8>() - base,
-      s->block_start.as<u64>() - s->block_first);
+      s->block_start.as<u64>() - s->block_first, s->view(), (u64*)nullptr, (u64)0);
   }
   else
   {

@@ -6,7 +6,7 @@
     api/context.hip.h   contexts (device, streams, memory pool), errors, launch macros, profiling, scans
     api/index.hip.h     device index: pipelined upload + transcode, canonical encoder + pipelined download, queries
     api/search.hip.h    rank array: frontier search / per-chain walk, finalize, downloads
-    api/fslice.hip.h    one GPU's state of the sliced frontier search (dense multi-GPU form, prototype)
+    api/fslice.hip.h    one GPU's state of the sliced frontier search (only with -DBWTM_EXPERIMENTAL; include/bwtm_experimental.h)
     api/merge.hip.h     interleave, whole-path entry points (device-resident, consuming, host-to-host)
     api/slices.hip.h    output-range-sharded interleave + encode (one slice per GPU)
 */
@@ -33,7 +33,10 @@ using namespace bwtm;
 #include "api/context.hip.h"
 #include "api/index.hip.h"
 #include "api/search.hip.h"
+#ifdef BWTM_EXPERIMENTAL
+#include "../../include/bwtm_experimental.h"
 #include "api/fslice.hip.h"
+#endif
 #include "api/merge.hip.h"
 #include "api/slices.hip.h"
 #include "api/ingest.hip.h"

@@ -16,6 +16,8 @@
     k_lf_walk_binned, k_lf_walk_quad, k_part_*, k_tile_build
                        the same two stages in per-chain form (small shards, long sequences, > 40-bit coordinates)
     kernels/diagnostics.hip.h (only with -DBWTM_DIAGNOSTICS): timing-only and A/B variants, not in the product
+    kernels/search_view.hip.h, k_frontier_step<.., VIEW>, k_frontier_gather (only with -DBWTM_EXPERIMENTAL): the two-plane search
+                       view and the sliced frontier search -- exact, tested, measured, not in the product (include/bwtm_experimental.h)
     k_chunk_popc       RA finalize (prefix counts of the interleaving bitvector)
     k_interleave_*     mergeBWT                                     bwt.cpp:215-282
     k_enc_*            RunBuffer + Run::write, block starts of BWT::build
@@ -28,6 +30,9 @@
 
 #include <hip/hip_runtime.h>
 #include "bwtm_device.h"
+#ifdef BWTM_EXPERIMENTAL
+#include "bwtm_view.h"
+#endif
 
 namespace bwtm
 {
@@ -44,9 +49,11 @@ struct IndexView
   u64 m;                 // sequences
   u64 nrecs;
   u64 C[8];              // C[c] = number of symbols smaller than c
-  const uint4* view;     // the search view (4 x uint4 per 160 positions; null unless built: bwtm_device.h)
+#ifdef BWTM_EXPERIMENTAL
+  const uint4* view;     // the search view (4 x uint4 per 160 positions; null unless built: bwtm_view.h)
   const u64* vsup;
   u64 nview;
+#endif
 };
 
 #include "kernels/common.hip.h"
@@ -56,7 +63,9 @@ struct IndexView
 #ifdef BWTM_DIAGNOSTICS
 #include "kernels/diagnostics.hip.h"
 #endif
+#ifdef BWTM_EXPERIMENTAL
 #include "kernels/search_view.hip.h"
+#endif
 #include "kernels/search_frontier.hip.h"
 #include "kernels/search_range.hip.h"
 #include "kernels/interleave.hip.h"

@@ -29,8 +29,11 @@ static void printUsage()
   std::cerr << "  -g N[,M,...]  Use GPU N (default: 0), or one host thread per listed GPU: the sequences of the increment are" << std::endl;
   std::cerr << "                sharded over them and every GPU produces its range of the output" << std::endl;
   std::cerr << "                (the buffer options have no effect on the device)" << std::endl;
+#ifdef BWTM_EXPERIMENTAL
   std::cerr << "  -S            With several GPUs: sliced search (every GPU advances a contiguous slice of the sorted frontier" << std::endl;
-  std::cerr << "                instead of a block of sequences; prototype)" << std::endl << std::endl;
+  std::cerr << "                instead of a block of sequences; experimental build only)" << std::endl;
+#endif
+  std::cerr << std::endl;
   printFormats(std::cerr);
 }
 
@@ -107,7 +110,13 @@ int main(int argc, char** argv)
   MergeParameters parameters;
   std::string pattern_name, output_format;
   std::vector<std::string> input_formats;
-  while((c = getopt(argc, argv, "b:m:r:s:t:d:v:i:o:g:S")) != -1)
+  while((c = getopt(argc, argv,
+#ifdef BWTM_EXPERIMENTAL
+    "b:m:r:s:t:d:v:i:o:g:S"
+#else
+    "b:m:r:s:t:d:v:i:o:g:"
+#endif
+    )) != -1)
   {
     switch(c)
     {
@@ -123,7 +132,9 @@ int main(int argc, char** argv)
         for(std::string token; std::getline(ss, token, ','); ) { devices.push_back(std::stoi(token)); }
       }
       break;
+#ifdef BWTM_EXPERIMENTAL
     case 'S': sliced_search = true; break;
+#endif
     case 'v': pattern_name = optarg; verify = true; break;
     case 'i':
       {
@@ -185,20 +196,21 @@ int main(int argc, char** argv)
     bytes_added += increment.size();
     verifyFMI(increment, "Input", patterns, pre_results);
     FMI next;
-    if(input + 1 < inputs)
+    const bool prefetch = (input + 1 < inputs && devices.size() == 1);
+    if(prefetch)
     {
+      // one GPU: the next input is read early so that its bytes can travel under this merge's search; this merge's own inputs go
+      // first on the link (the first merge of a chain uploads both of them)
       load(next, argv[optind + input + 1], input_formats[input + 1]);
-      if(devices.size() == 1)
-      {
-        // this merge's own inputs go first on the link (the first merge of a chain uploads both of them)
-        index.bwt.onDevice(index.alpha.C); increment.bwt.onDevice(increment.alpha.C);
-        next.bwt.prefetchDevice(next.alpha.C);
-      }
+      index.bwt.onDevice(index.alpha.C); increment.bwt.onDevice(increment.alpha.C);
+      next.bwt.prefetchDevice(next.alpha.C);
     }
     // Intermediate results of a chain are only ever the next merge's first input: they stay on the device.  The last
     // merge produces the host-resident FMI inside its timer, like the reference's.
     MergeParameters p = parameters; p.lazy_host = (input + 1 < inputs);
     merge(index, increment, p, devices);
+    // several GPUs: nothing overlaps with the load, so the next input is read only now (one input less in host memory during the merge)
+    if(input + 1 < inputs && !prefetch) { load(next, argv[optind + input + 1], input_formats[input + 1]); }
     increment.swap(next);
   }
 

@@ -162,6 +162,7 @@ int main(int argc, char** argv)
     }
   }
 
+#ifdef BWTM_EXPERIMENTAL
   // The same with the sliced frontier search: three contexts, each advancing a slice of the sorted frontier.
   {
     FMI sliced; MultiGPUTimes times;
@@ -170,6 +171,7 @@ int main(int argc, char** argv)
     CHECK(sliced.bwt.blockEnds() == merged.bwt.blockEnds());
     for(size_type c = 0; c < 6; c++) { CHECK(sliced.bwt.cumulative(c) == merged.bwt.cumulative(c)); }
   }
+#endif
 
   // Native file round trip.
   {

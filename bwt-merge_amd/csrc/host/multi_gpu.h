@@ -26,6 +26,9 @@
 #include <thread>
 
 #include "fmi.h"
+#ifdef BWTM_EXPERIMENTAL
+#include "bwtm_experimental.h"
+#endif
 
 #ifdef BWTM_WITH_RCCL
 #include <hip/hip_runtime_api.h>
@@ -59,10 +62,10 @@ struct MultiGPUTimes
 };
 
 // Merges a and b (both consumed) into `result` using the given devices.
-// sliced = false: GPU g searches block g of b's sequences (bwtm_search).  sliced = true: the sliced frontier search (bwtm_fslice_*,
-// include/bwtm.h): GPU g advances slice g of the sorted frontier and pulls its next slice from all GPUs' outputs -- every GPU
-// then streams 1 / G of both rank structures per LF step instead of a thinned 100 % (prototype: contexts of one GPU, or devices
-// with peer access).
+// sliced = false: GPU g searches block g of b's sequences (bwtm_search).  sliced = true (only in builds with -DBWTM_EXPERIMENTAL against
+// libbwtm_experimental.so): the sliced frontier search (bwtm_fslice_*, include/bwtm_experimental.h): GPU g advances slice g of the sorted
+// frontier and pulls its next slice from all GPUs' outputs -- every GPU then streams 1 / G of both rank structures per LF step
+// instead of a thinned 100 % (contexts of one GPU, or devices with peer access).
 inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& result, MultiGPUTimes* times = nullptr, bool sliced = false)
 {
   if(a.alpha != b.alpha)
@@ -92,7 +95,10 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
   if(distinct && G > 1) { std::cerr << "mergeMultiGPU(): built without RCCL, cannot combine rank arrays across devices" << std::endl; std::exit(EXIT_FAILURE); }
 #endif
 
-#ifdef BWTM_WITH_RCCL
+#ifndef BWTM_EXPERIMENTAL
+  if(sliced) { std::cerr << "mergeMultiGPU(): the sliced search is not part of this build" << std::endl; std::exit(EXIT_FAILURE); }
+#endif
+#if defined(BWTM_WITH_RCCL) && defined(BWTM_EXPERIMENTAL)
   if(distinct && G > 1 && sliced)
   {
     // the sliced search reads its peers' frontier buffers directly (plain hipMalloc memory, bwtm_fslice_export): peers must be mapped
@@ -120,7 +126,9 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
   std::vector<void*> bits(G, nullptr); std::vector<uint64_t> bits_bytes(G, 0);
   std::vector<uint64_t> heads(G, 0), tables(G * 64, 0), offsets(G + 1, 0), first_block_start(G, ~(uint64_t)0);
   std::vector<uint64_t> block_first(G, 0), block_count(G, 0);
+#ifdef BWTM_EXPERIMENTAL
   std::vector<bwtm_fslice_view> views(G);
+#endif
   BWT& out = result.bwt;
   double t0 = readTimer();
   MultiGPUTimes local;
@@ -206,6 +214,7 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
 #endif
     }
     else { gpuCheck(bwtm_ra_create(A, B, &ra), "mergeMultiGPU()"); }
+#ifdef BWTM_EXPERIMENTAL
     if(sliced && b.sequences() > 0)
     {
       const uint64_t capacity = (b.sequences() + G - 1) / G + 1;
@@ -229,7 +238,9 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
       gpuCheck(bwtm_fslice_finish(fs), "mergeMultiGPU()");
       bwtm_fslice_free(fs);
     }
-    else if(g < blocks.size()) { gpuCheck(bwtm_search(A, B, blocks[g].first, blocks[g].second, ra), "mergeMultiGPU()"); }
+    else
+#endif
+    if(g < blocks.size()) { gpuCheck(bwtm_search(A, B, blocks[g].first, blocks[g].second, ra), "mergeMultiGPU()"); }
     gpuCheck(bwtm_ra_device_buffer(ra, &bits[g], &bits_bytes[g]), "mergeMultiGPU()");      // synchronizes: the search is done
     if(g == 0) { local.search = readTimer() - t0 - local.upload; }
 

@@ -9,6 +9,16 @@
 
 __device__ inline u32 lane_id() { return threadIdx.x & 63u; }
 
+// Issue-slack experiment (never in the product build): N extra dependent VALU instructions at a point of a kernel's hot loop, through
+// tools/build_variant.sh <name> "" -DBWTM_SLACK_<KERNEL>=N.  The instructions feed nothing, so results are unchanged; a kernel whose
+// time grows with N is bound by instruction issue, one whose time stays is bound by memory.
+template<int N>
+__device__ inline void valu_slack(u32& x)
+{
+#pragma unroll
+  for(int k = 0; k < N; k++) { asm volatile("v_add_u32 %0, %0, 1" : "+v"(x)); }
+}
+
 __device__ inline u64 shfl_u64(u64 v, int src)
 {
   u32 lo = (u32)__shfl((int)(u32)v, src, WAVE);

@@ -95,19 +95,22 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_lasthead(const uint4* rec
 {
   u64 seg = seg_first + (((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6);
   if(seg >= seg_end) { return; }
-  u64 first = seg * SEG_TILES;
-  u32 carry = (first == 0 ? 0u : symbol_at(recs, (first << 6) - 1));
+  const u64 first = seg * SEG_TILES;
+  // From the segment's last chunk backwards: the first chunk that holds a head has the answer, and unless the segment ends inside a run
+  // of more than 4096 positions that is the very first one looked at -- one chunk read per segment instead of sixteen (the forward
+  // pass was a full read of the records, 0.8 ms at config 2, for a number that sits in the last tile of almost every segment).
+  const u64 tiles_here = (ntiles - first < SEG_TILES ? ntiles - first : SEG_TILES);   // > 0: every segment of the launch has tiles
   u64 best = NONE;
-  for(int k = 0; k < SEG_CHUNKS; k++)
+  for(int k = (int)((tiles_here - 1) >> 6); k >= 0; k--)
   {
-    u64 ft = first + (u64)k * 64;
-    if(ft >= ntiles) { break; }
+    const u64 ft = first + (u64)k * 64;
+    const u32 carry = (ft == 0 ? 0u : symbol_at(recs, (ft << 6) - 1));
     TileInfo ti;
-    carry = chunk_tiles(recs, nrecs, ft, n, carry, ti);
-    u64 T = ft + lane_id();
-    u64 mine = (ti.H != 0 && T < ntiles ? (T << 6) + (63 - (u64)__builtin_clzll(ti.H)) + 1 : NONE);
-    u64 m = shfl_u64(wave_incl_last(mine), WAVE - 1);                // the last head of the chunk
-    if(m > best) { best = m; }
+    (void)chunk_tiles(recs, nrecs, ft, n, carry, ti);
+    const u64 T = ft + lane_id();
+    const u64 mine = (ti.H != 0 && T < ntiles ? (T << 6) + (63 - (u64)__builtin_clzll(ti.H)) + 1 : NONE);
+    const u64 m = shfl_u64(wave_incl_last(mine), WAVE - 1);                // the last head of the chunk
+    if(m != NONE) { best = m; break; }
   }
   if(lane_id() == 0) { lasthead[seg] = best; }
 }
@@ -251,10 +254,21 @@ __global__ void __launch_bounds__(WAVE) k_fold_seg(const u32* table, u64 nseg, c
   for(u64 s = s0; s < s1; s++) { seg_base[s] = off; off += table[s * 64 + (off & 63)]; }
 }
 
+// cum[c * stride + b] = occurrences of c before the start of block b (samples[c] of BWT::build, bwt.cpp:489-511), stored by the lane
+// that opens block b: the record of that position has just been read by this wave, so the rank query is served by the caches
+// (the separate pass over all block starts, k_block_cum, read the records a second time: 2.0 - 2.4 ms at config 2).
+__device__ inline void store_block_cum(const IndexView& X, u64 block, u64 p, u64* cum, u64 stride)
+{
+  u64 r[6]; index_ranks(X, p, r);
+  cum[0 * stride + block] = p - (r[1] + r[2] + r[3] + r[4] + r[5]);
+  cum[1 * stride + block] = r[1]; cum[2 * stride + block] = r[2]; cum[3 * stride + block] = r[3]; cum[4 * stride + block] = r[4]; cum[5 * stride + block] = r[5];
+}
+
 // The launch covers the segments [seg_first, seg_end): the pipelined download copies the bytes of one range to the
-// host while the next range is written.
+// host while the next range is written.  CUM: also the samples' cumulative counts at every block start (X = the index being encoded).
+template<bool CUM>
 __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 seg_first, u64 seg_end,
-  const u64* prevhead, u64 head_carry, const u64* seg_base, u8* out, u64* block_start)
+  const u64* prevhead, u64 head_carry, const u64* seg_base, u8* out, u64* block_start, IndexView X, u64* cum, u64 cum_stride)
 {
   __shared__ __attribute__((aligned(16))) u8 stage[BLOCK_THREADS / WAVE][4096 + 32];
   u64 seg = seg_first + (((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6);
@@ -355,6 +369,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
             u32 byte;                                                     // run_sym + 6 (length - 1): Run::encodeBasic, support.h:231-234
             asm("v_mad_u32_u24 %0, %1, 6, %2" : "=v"(byte) : "v"(len1), "v"(run_sym));   // (the compiler picks the quarter-rate v_mad_u64_u32 here)
             lds[idx++] = (u8)byte;
+#ifdef BWTM_SLACK_ENC_EMIT
+            { u32 slack = byte; valu_slack<BWTM_SLACK_ENC_EMIT>(slack); }
+#endif
             run_sym = __builtin_amdgcn_ubfe(q0, bb, 1u) | (__builtin_amdgcn_ubfe(q1, bb, 1u) << 1) | (__builtin_amdgcn_ubfe(q2, bb, 1u) << 2);
             prev_bit = bit;
           };
@@ -365,7 +382,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
             if(hh) { event((u32)__builtin_ctz(hh)); hh &= hh - 1; }
           }
         }
-        if(open_prev != NO_OPEN) { block_start[(off - a + opens) >> 6] = tb + (u64)(long long)open_prev; }
+        if(open_prev != NO_OPEN)
+        {
+          const u64 blk = (off - a + opens) >> 6, p = tb + (u64)(long long)open_prev;
+          block_start[blk] = p;
+          if(CUM) { store_block_cum(X, blk, p, cum, cum_stride); }
+        }
       }
       flush_chunk(lds, a, a + (u32)chunk_events, off - a);
       off += chunk_events;
@@ -402,11 +424,19 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
           const u64 pos = tb + b, len = pos + 1 - prev1;
           if((long_mask >> b) & 1)
           {
-            idx += (u32)long_run_write(lds, origin + idx, run_sym, len, block_start, prev1 - 1, origin);
+            idx += (u32)long_run_write_cb(lds, origin + idx, run_sym, len, prev1 - 1, origin, [&](u64 blk, u64 p)
+            {
+              block_start[blk] = p;
+              if(CUM) { store_block_cum(X, blk, p, cum, cum_stride); }
+            });
           }
           else
           {
-            if(((origin + idx) & (RLE_BLOCK - 1)) == 0) { block_start[(origin + idx) >> 6] = prev1 - 1; }
+            if(((origin + idx) & (RLE_BLOCK - 1)) == 0)
+            {
+              block_start[(origin + idx) >> 6] = prev1 - 1;
+              if(CUM) { store_block_cum(X, (origin + idx) >> 6, prev1 - 1, cum, cum_stride); }
+            }
             lds[idx++] = (u8)(run_sym + 6 * (len - 1));
           }
           run_sym = (u32)((ti.p0 >> b) & 1) | ((u32)((ti.p1 >> b) & 1) << 1) | ((u32)((ti.p2 >> b) & 1) << 2);

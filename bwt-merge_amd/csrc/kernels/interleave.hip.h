@@ -149,31 +149,47 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_interleave_sup(IndexView A, I
 // the 32-bit windows at its two cursors from there.
 constexpr u32 IL_WORDS = 2 * CHUNK_WORDS + 8;            // 264 staged words per plane
 
-// The staged words of one source: every thread takes word t and (threads 0 .. 7 really, the others re-read the last one) word
-// 256 + t.  The loads are unconditional, from clamped indexes, and issued for BOTH sources before anything is written to LDS:
-// written as a loop with a predicated load per source, the compiler put a full wait after each of them -- three memory round
-// trips in a row at the start of every workgroup.
-struct StagedLoad { uint4 v0, v1; bool z0, z1; };
+// Staging.  A chunk of 8192 output positions takes na of them from A and nb = 8192 - na from B, so the 16-byte words it needs from both
+// sources together are 256 (+ up to 6 for alignment and the look-ahead word of the 32-bit windows): thread t takes word t of the
+// COMBINED list (A's words first, then B's) and the first threads a second one.  (The first version staged 264 words of EACH source
+// whatever the split -- 1.86 x the algorithmic read traffic in the PMC counters, and twice the LDS writes.)  The loads are
+// unconditional, from clamped indexes, and issued before anything is written to LDS: written as a loop with a predicated load per
+// source, the compiler put a full wait after each of them -- three memory round trips in a row at the start of every workgroup.
+struct StagedLoad { uint4 v0, v1; u32 k0, k1; bool z0, z1, b0, b1, have1; };
 
-__device__ inline StagedLoad stage_issue(const IndexView& x, u64 first_word)
+__device__ inline void stage_pick(const IndexView& A, const IndexView& B, u64 wa0, u64 wb0, u32 na_words, u32 j, uint4& v, bool& z, bool& from_b, u32& k)
 {
+  from_b = (j >= na_words);
+  k = (from_b ? j - na_words : j);
+  const IndexView& x = (from_b ? B : A);
   const u64 last = 4 * x.nrecs;                                       // > 0: an index has at least one record
-  const u32 k1 = (threadIdx.x + BLOCK_THREADS < IL_WORDS ? threadIdx.x + BLOCK_THREADS : IL_WORDS - 1);
-  const u64 w0 = first_word + threadIdx.x, w1 = first_word + k1;
+  const u64 w = (from_b ? wb0 : wa0) + k;
+  z = (w >= last);
+  v = (from_b ? B.recs : A.recs)[z ? last - 1 : w];
+}
+
+__device__ inline StagedLoad stage_issue(const IndexView& A, const IndexView& B, u64 wa0, u64 wb0, u32 na_words, u32 total_words)
+{
   StagedLoad s;
-  s.z0 = (w0 >= last); s.z1 = (w1 >= last);
-  s.v0 = x.recs[s.z0 ? last - 1 : w0];
-  s.v1 = x.recs[s.z1 ? last - 1 : w1];
+  const u32 j0 = (threadIdx.x < total_words ? threadIdx.x : total_words - 1);
+  const u32 j1 = (threadIdx.x + BLOCK_THREADS < total_words ? threadIdx.x + BLOCK_THREADS : total_words - 1);
+  s.have1 = (threadIdx.x + BLOCK_THREADS < total_words);
+  stage_pick(A, B, wa0, wb0, na_words, j0, s.v0, s.z0, s.b0, s.k0);
+  stage_pick(A, B, wa0, wb0, na_words, j1, s.v1, s.z1, s.b1, s.k1);
   return s;
 }
 
-__device__ inline void stage_store(const StagedLoad& s, u32 (*planes)[IL_WORDS])
+__device__ inline void stage_store(const StagedLoad& s, u32 total_words, u32 (*planes_a)[IL_WORDS], u32 (*planes_b)[IL_WORDS])
 {
-  const u32 t = threadIdx.x;
-  planes[0][t] = (s.z0 ? 0u : s.v0.x); planes[1][t] = (s.z0 ? 0u : s.v0.y); planes[2][t] = (s.z0 ? 0u : s.v0.z);
-  if(t + BLOCK_THREADS < IL_WORDS)
+  if(threadIdx.x < total_words)
   {
-    planes[0][t + BLOCK_THREADS] = (s.z1 ? 0u : s.v1.x); planes[1][t + BLOCK_THREADS] = (s.z1 ? 0u : s.v1.y); planes[2][t + BLOCK_THREADS] = (s.z1 ? 0u : s.v1.z);
+    u32 (*p)[IL_WORDS] = (s.b0 ? planes_b : planes_a);
+    p[0][s.k0] = (s.z0 ? 0u : s.v0.x); p[1][s.k0] = (s.z0 ? 0u : s.v0.y); p[2][s.k0] = (s.z0 ? 0u : s.v0.z);
+  }
+  if(s.have1)
+  {
+    u32 (*p)[IL_WORDS] = (s.b1 ? planes_b : planes_a);
+    p[0][s.k1] = (s.z1 ? 0u : s.v1.x); p[1][s.k1] = (s.z1 ? 0u : s.v1.y); p[2][s.k1] = (s.z1 ? 0u : s.v1.z);
   }
 }
 
@@ -201,9 +217,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_interleave(IndexView A, Index
   const u64 b_chunk = chunk_base[chunk];
   const u64 a_chunk = (chunk << (REC_SHIFT + 6)) - b_chunk;
   const u64 wa0 = a_chunk >> 5, wb0 = b_chunk >> 5;
-  const StagedLoad sa = stage_issue(A, wa0), sb = stage_issue(B, wb0);
-  __builtin_amdgcn_sched_barrier(0);                              // all four loads leave before the first LDS write
-  stage_store(sa, planes_a); stage_store(sb, planes_b);
+  // positions the chunk takes from B = ones of its 8192 bits (chunk_base has an entry behind the last chunk); words that hold
+  // them and the A positions, each with the look-ahead word a 32-bit window may touch
+  const u32 nb_pos = (u32)(chunk_base[chunk + 1] - b_chunk), na_pos = (u32)(64 * REC_POS) - nb_pos;
+  const u32 na_words = (u32)(((a_chunk + na_pos + 31) >> 5) - wa0) + 1, nb_words = (u32)(((b_chunk + nb_pos + 31) >> 5) - wb0) + 1;
+  const u32 total_words = na_words + nb_words;                     // <= 256 + 6
+  const StagedLoad st = stage_issue(A, B, wa0, wb0, na_words, total_words);
+  __builtin_amdgcn_sched_barrier(0);                              // both loads leave before the first LDS write
+  stage_store(st, total_words, planes_a, planes_b);
   if(t == 0)
   {
     u64 ra[6], rb[6];
@@ -223,6 +244,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_interleave(IndexView A, Index
   u32 a0, a1, a2, b0, b1, b2;
   window32(planes_a, wa0, a_off, a0, a1, a2); window32(planes_b, wb0, b_off, b0, b1, b2);
   const ExpandMasks eb = expand_masks(m), ea = expand_masks(~m);
+#ifdef BWTM_SLACK_INTERLEAVE
+  { u32 slack = m; valu_slack<BWTM_SLACK_INTERLEAVE>(slack); }
+#endif
   const u32 o0 = expand32(b0, eb) | expand32(a0, ea);
   const u32 o1 = expand32(b1, eb) | expand32(a1, ea);
   const u32 o2 = expand32(b2, eb) | expand32(a2, ea);

@@ -121,8 +121,8 @@ __device__ inline u64 ordinary_lf(const IndexView& X, u64 pos, u32& c, bool want
   return X.sup[(pos >> SUPER_SHIFT) * SUP_STRIDE + c] + ((u32)v & FIELD_MASK) + total;
 }
 
-// VIEW: the records come from the search view (160 positions per 64 bytes, bwtm_device.h); an element whose view record has overflowed
-// its exception slots reads the ordinary record of its position instead.
+// VIEW (instantiated only with -DBWTM_EXPERIMENTAL): the records come from the search view (160 positions per 64 bytes, bwtm_view.h); an
+// element whose view record has overflowed its exception slots reads the ordinary record of its position instead.
 template<int EMIT, bool HI, bool VIEW = false>
 __global__ void __launch_bounds__(FR_BLOCK, (VIEW ? 6 : 8)) k_frontier_step(IndexView A, IndexView B, FrontierView f)
 {
@@ -213,6 +213,7 @@ __global__ void __launch_bounds__(FR_BLOCK, (VIEW ? 6 : 8)) k_frontier_step(Inde
       tile_first = (u32)my_tile;                                  // meaningful in lane 0
       tile_last = (u32)shfl_u64(my_tile, (int)last_lane);
     }
+#ifdef BWTM_EXPERIMENTAL
     if(VIEW)
     {
       // The same step on the view records.  Position p sits in view record p / 160 (a multiply-high), at p - 160 (p / 160).
@@ -269,6 +270,7 @@ __global__ void __launch_bounds__(FR_BLOCK, (VIEW ? 6 : 8)) k_frontier_step(Inde
       }
     }
     else
+#endif
     {
       u32 wb[16];
       const u64 rec_b = (active ? i : li) >> REC_SHIFT, rec_a = (active ? r : lr) >> REC_SHIFT;
@@ -608,6 +610,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_tile_build_frontier(const uns
   }
 }
 
+#ifdef BWTM_EXPERIMENTAL
 //------------------------------------------------------------------------------
 // Sliced frontier (the dense multi-GPU form of the search).  The sorted frontier F_t is cut into G contiguous
 // slices, one per GPU: a slice touches a contiguous range of B's AND of A's records (both coordinates are monotone along the
@@ -646,3 +649,4 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_gather(const SlicePi
   lo_in[j] = pc.lo[at];
   if(hi_in) { hi_in[j] = pc.hi[at]; }
 }
+#endif // BWTM_EXPERIMENTAL

@@ -172,6 +172,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_block_len(const u8* data, u64
       if(!cont && long_heads == 0 && (u32)(4 * w + 3) < valid)
       {
         acc += tab[word & 0xFF] + tab[(word >> 8) & 0xFF] + tab[(word >> 16) & 0xFF] + tab[word >> 24];
+#ifdef BWTM_SLACK_BLOCK_LEN
+        { u32 slack = word; valu_slack<BWTM_SLACK_BLOCK_LEN>(slack); }
+#endif
       }
       else
       {
@@ -376,6 +379,9 @@ __global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64
         if(!cont && big == 0)
         {
           // four one-byte runs of 1 .. 31: straight-line, no per-byte checks
+#ifdef BWTM_SLACK_BUILD_RECS
+          { u32 slack = word; valu_slack<BWTM_SLACK_BUILD_RECS>(slack); }
+#endif
 #pragma unroll
           for(int k = 0; k < 4; k++)
           {

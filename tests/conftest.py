@@ -9,6 +9,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# tests/experimental/ needs libbwtm_experimental.so (BWTM_LIB): collected only in the child process tests/test_gpu_experimental.py starts
+collect_ignore_glob = [] if os.environ.get("BWTM_EXPERIMENTAL_TESTS") else ["experimental/*"]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

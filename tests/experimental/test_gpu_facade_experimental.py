@@ -1,0 +1,52 @@
+"""The C++ host built against libbwtm_experimental.so: `bwt_merge -S` and the sliced section of host_api_test."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+HOST = os.path.join(ROOT, "bwt-merge_amd", "csrc", "host")
+CHARS = np.frombuffer(b"$ACGTN", dtype=np.uint8)
+pytestmark = pytest.mark.gpu
+
+
+def build_host(bwtm):
+    bwtm.build(experimental=True)
+    subprocess.check_call(["make", "-C", HOST, "-s"])
+    subprocess.check_call(["make", "-C", HOST, "-s", "experimental"])
+
+
+def write_plain(path, fmi):
+    CHARS[fmi.symbols].tofile(path)
+
+
+def test_api_test_with_the_sliced_section(bwtm, oracle, tmp_path):
+    build_host(bwtm)
+    ta = oracle.generate_reads(1001, 700, 60); tb = oracle.generate_reads(1002, 500, 80)
+    a = oracle.FMI.from_text(ta); b = oracle.FMI.from_text(tb)
+    write_plain(tmp_path / "a.plain", a); write_plain(tmp_path / "b.plain", b)
+    m, _ = oracle.merge(a.clone(), b.clone(), threads=2)
+    m.data.tofile(tmp_path / "expected.bin")
+    out = subprocess.run([os.path.join(HOST, "host_api_test_experimental"), str(tmp_path / "a.plain"), str(tmp_path / "b.plain"),
+                          str(tmp_path / "expected.bin"), str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_cli_sliced_search_equals_the_product_tool(bwtm, oracle, tmp_path):
+    """bwt_merge_experimental -g 0,0,0 -S == bwt_merge -g 0 on a chained merge of three inputs."""
+    build_host(bwtm)
+    sets = [oracle.generate_reads(4100 + k, 2500 + 300 * k, 100) for k in range(3)]
+    names = []
+    for k, t in enumerate(sets):
+        names.append(str(tmp_path / ("in%d.plain" % k)))
+        write_plain(names[-1], oracle.FMI.from_text(t))
+    outs = {}
+    for label, exe, extra in (("one", "bwt_merge", ["-g", "0"]), ("sliced", "bwt_merge_experimental", ["-g", "0,0,0", "-S"])):
+        out = subprocess.run([os.path.join(HOST, exe)] + extra + ["-i", "plain_default", names[0], names[1], names[2], str(tmp_path / (label + ".native"))],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        outs[label] = np.fromfile(tmp_path / (label + ".native"), dtype=np.uint8)
+    assert np.array_equal(outs["one"], outs["sliced"])
+    direct = oracle.FMI.from_text(np.concatenate(sets))
+    assert np.array_equal(outs["sliced"][32:32 + direct.nbytes], direct.data)

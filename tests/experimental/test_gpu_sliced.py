@@ -1,4 +1,4 @@
-"""The sliced frontier search (dense multi-GPU form of buildRA, include/bwtm.h: bwtm_fslice_*): G contexts of one GPU stand in for
+"""The sliced frontier search (dense multi-GPU form of buildRA, include/bwtm_experimental.h: bwtm_fslice_*): G contexts of one GPU stand in for
 G GPUs, each advancing a contiguous slice of the sorted frontier and pulling its next slice from all the others' outputs.
 The union of their rank arrays must be the oracle's rank array, bit for bit."""
 import numpy as np
@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def gpu(bwtm):
     bwtm.init(0)
+    assert bwtm.experimental(), "these tests need BWTM_LIB=libbwtm_experimental.so"
     yield bwtm
     bwtm.make_default_current()
     bwtm.trim()

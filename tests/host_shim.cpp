@@ -2,6 +2,7 @@
 // (compiled with g++; no HIP runtime involved).
 #include <cstring>
 #include "../bwt-merge_amd/csrc/bwtm_device.h"
+#include "../bwt-merge_amd/csrc/bwtm_view.h"       // the experimental search view's record helpers (pure functions)
 using namespace bwtm;
 extern "C"
 {

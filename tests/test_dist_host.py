@@ -153,7 +153,7 @@ def test_fold_offsets_binding_matches_host_logic(bwtm):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# The sliced frontier search (bwt-merge_amd/dist.py: search_sliced, include/bwtm.h: bwtm_fslice_*) as a plain CPU model: every part
+# The sliced frontier search (bwt-merge_amd/dist.py: search_sliced, include/bwtm_experimental.h: bwtm_fslice_*) as a plain CPU model: every part
 # advances a contiguous slice of the sorted frontier and the next frontier is read in the order (class, part, position inside the
 # part's output).  The claim the GPU code rests on: that order IS the suffix order, so the union of the parts' emits is the rank array.
 

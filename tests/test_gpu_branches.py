@@ -35,15 +35,15 @@ def upload(gpu, f):
     return gpu.Index.upload(f.data, f.sequences, f.bases)
 
 
-def search_runs(gpu, A, B, b, algo, range_ratio=-1, view=-1):
-    gpu.tune("search_algo", algo); gpu.tune("range_ratio", range_ratio); gpu.tune("search_view", view)   # -1 = the defaults
+def search_runs(gpu, A, B, b, algo, range_ratio=-1):
+    gpu.tune("search_algo", algo); gpu.tune("range_ratio", range_ratio)   # -1 = the default
     gpu.profile_enable(True); gpu.profile_reset()
     ra = gpu.RankArray(A, B)
     ra.search(A, B, 0, b.sequences - 1)
     ra.finalize()
     prof = gpu.profile_read()
     gpu.profile_enable(False)
-    gpu.tune("search_algo", 0); gpu.tune("range_ratio", -1); gpu.tune("search_view", -1)
+    gpu.tune("search_algo", 0); gpu.tune("range_ratio", -1)
     assert ra.values == b.bases
     ranks, counts = ra.runs()
     ra.free()
@@ -63,8 +63,8 @@ def test_coordinates_beyond_32_bits(gpu, oracle):
     # the frontier search alone (one element per sequence), the node phase alone (every level of this collection has at most 4096
     # trie nodes: fmi.cpp:304-322, the reference's own form), five levels of nodes expanded into 4.3e7 elements, and the walk
     for algo, kernel, ratio, absent in ((2, "frontier_step", 0, "range_step"), (2, "range_step", -1, "frontier_step"), (2, "frontier_step", 71680, None),
-                                        (2, "view_build", 0, "range_step"), (1, "lf_walk", -1, "range_step")):
-        ranks, counts, prof = search_runs(gpu, A, B, b, algo, ratio, view=(1 if kernel == "view_build" else 0))
+                                        (1, "lf_walk", -1, "range_step")):
+        ranks, counts, prof = search_runs(gpu, A, B, b, algo, ratio)
         assert prof.get(kernel, (0, 0))[1] > 0, (algo, sorted(prof))
         assert absent is None or absent not in prof, (algo, ratio, sorted(prof))
         if ratio == 71680:

@@ -308,13 +308,10 @@ def test_partitioned_emit_rounds_fallbacks_and_variants(gpu, oracle):
                         # the node phase (fmi.cpp:304-322): never, for every level it can take (ratio 1: the whole search on trie nodes when
                         # no level has more nodes than sequences), a few levels then elements, with short epochs behind it
                         dict(search_algo=2, range_ratio=0), dict(search_algo=2, range_ratio=1), dict(search_algo=2, range_ratio=40),
-                        dict(search_algo=2, range_ratio=3, frontier_epoch=9), dict(search_algo=2, range_ratio=2, l1_cap=5000),
-                        # the two-plane search view (160 positions per 64 bytes), with and without the node phase in front of it
-                        dict(search_algo=2, search_view=1), dict(search_algo=2, search_view=1, range_ratio=0), dict(search_algo=2, search_view=0),
-                        dict(search_algo=2, search_view=1, frontier_epoch=9, range_ratio=40)]
+                        dict(search_algo=2, range_ratio=3, frontier_epoch=9), dict(search_algo=2, range_ratio=2, l1_cap=5000)]
             for st in settings:
-                for k in ("round_emits", "emit_path", "l1_cap", "search_algo", "frontier_unfused", "frontier_epoch", "emit_budget", "range_ratio", "search_view"):
-                    gpu.tune(k, {"round_emits": 1 << 33, "range_ratio": -1, "search_view": -1}.get(k, 0))
+                for k in ("round_emits", "emit_path", "l1_cap", "search_algo", "frontier_unfused", "frontier_epoch", "emit_budget", "range_ratio"):
+                    gpu.tune(k, {"round_emits": 1 << 33, "range_ratio": -1}.get(k, 0))
                 for k, v in st.items():
                     gpu.tune(k, v)
                 ra = gpu.RankArray(A, B)
@@ -326,7 +323,7 @@ def test_partitioned_emit_rounds_fallbacks_and_variants(gpu, oracle):
     finally:
         for k in ("emit_path", "l1_cap", "frontier_unfused", "frontier_epoch", "emit_budget"):
             gpu.tune(k, 0)
-        gpu.tune("round_emits", 1 << 33); gpu.tune("range_ratio", -1); gpu.tune("search_view", -1)
+        gpu.tune("round_emits", 1 << 33); gpu.tune("range_ratio", -1)
         gpu.tune("search_algo", 2)
 
 
@@ -353,42 +350,6 @@ def test_frontier_grid_follows_a_shrinking_frontier(gpu, oracle, ratio):
     finally:
         gpu.tune("range_ratio", -1)
     for x in (ra, M, A, B):
-        x.free()
-
-
-@pytest.mark.parametrize("ratio", [0, -1])
-def test_search_view_exceptions_and_overflow(gpu, oracle, ratio):
-    """The search view stores endmarkers and N as exceptions, seven per 160 positions: collections of very short reads (a quarter of
-    the BWT is endmarkers), reads that are mostly N, and ordinary reads next to them -- view records without exceptions, with a few, and
-    overflowed ones (their elements read the ordinary records) in one search; positions at the very end of an index."""
-    rng = np.random.default_rng(78)
-    def reads(n, length, p_n):
-        out = []
-        for _ in range(n):
-            r = rng.integers(1, 5, length)
-            r[rng.random(length) < p_n] = 5
-            out.append(np.concatenate([r, [0]]))
-        return np.concatenate(out).astype(np.uint8)
-    tb = np.concatenate([reads(900, 3, 0.0), reads(300, 80, 0.7), reads(1200, 100, 0.004), reads(5, 159, 0.0), reads(1, 160, 1.0)])
-    ta = np.concatenate([reads(700, 2, 0.1), reads(1500, 90, 0.01), reads(200, 120, 0.5)])
-    a, b = oracle.FMI.from_text(ta), oracle.FMI.from_text(tb)
-    ranks, counts, _ = oracle.search(a, b, threads=2)
-    A = gpu.Index.upload(a.data, a.sequences, a.bases); B = gpu.Index.upload(b.data, b.sequences, b.bases)
-    gpu.tune("range_ratio", ratio); gpu.tune("search_view", 1)
-    try:
-        ra = gpu.RankArray(A, B)
-        ra.search(A, B, 0, b.sequences - 1)
-        ra.finalize()
-        assert ra.values == b.bases
-        assert np.array_equal(ra.download(), oracle.ra_from_runs(ranks, counts))
-        rb = gpu.RankArray(B, A)                                 # the other way round: A's reads searched in B
-        rb.search(B, A, 0, a.sequences - 1)
-        rb.finalize()
-        r2, c2, _ = oracle.search(b, a, threads=2)
-        assert np.array_equal(rb.download(), oracle.ra_from_runs(r2, c2))
-    finally:
-        gpu.tune("range_ratio", -1); gpu.tune("search_view", -1)
-    for x in (ra, rb, A, B):
         x.free()
 
 

@@ -4,7 +4,7 @@
 names=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do names+=("$1"); shift; done; [ "$1" = "--" ] && shift
 for round in 1 2; do
   for v in "${names[@]}"; do
-    BWTM_LIB=$PWD/bwt-merge_amd/_variants/$v.so timeout 120 python bench.py --steps 6 --warmup 2 --no-host --no-cpu-baseline --no-verify "$@" 2>/dev/null | tail -1 > gpurun_out/tmp_var_$v.json
+    BWTM_LIB=$PWD/bwt-merge_amd/_variants/$v.so timeout 120 python bench.py --steps 6 --warmup 2 --no-host --no-cpu-baseline --no-verify --target off "$@" 2>/dev/null | tail -1 > gpurun_out/tmp_var_$v.json
     python3 - $v <<'PY'
 import json, sys
 d = json.loads(open("gpurun_out/tmp_var_%s.json" % sys.argv[1]).read()); k = d["kernel_ms_per_step"]

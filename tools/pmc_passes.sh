@@ -11,7 +11,7 @@ cd /tmp
 i=0
 for set in "${sets[@]}"; do
   i=$((i+1)); rm -rf /tmp/pmc_$i
-  timeout 900 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc_$i -- python3 $R/bench.py --no-cpu-baseline --no-verify --no-host --steps 1 --warmup 0 > /tmp/pmc_$i.log 2>&1
+  timeout 900 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc_$i -- python3 $R/bench.py --no-cpu-baseline --no-verify --no-host --target off --steps 1 --warmup 0 > /tmp/pmc_$i.log 2>&1
   f=$(find /tmp/pmc_$i -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then python3 $R/tools/pmc_aggregate.py $f >> $out/pmc.txt; else echo "pass $i ($set) failed" >> $out/pmc.txt; tail -5 /tmp/pmc_$i.log >> $out/pmc.txt; fi
 done

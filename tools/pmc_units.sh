@@ -11,7 +11,7 @@ sets=("TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_RE
 i=0
 for set in "${sets[@]}"; do
   i=$((i+1)); rm -rf /tmp/pmc_u
-  timeout -k 5 150 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc_u -- python3 $R/bench.py --no-cpu-baseline --no-verify --no-host --steps 1 --warmup 0 "$@" > /tmp/pmc_u.log 2>&1
+  timeout -k 5 150 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc_u -- python3 $R/bench.py --no-cpu-baseline --no-verify --no-host --target off --steps 1 --warmup 0 "$@" > /tmp/pmc_u.log 2>&1
   f=$(find /tmp/pmc_u -name "*counter_collection.csv" 2>/dev/null | head -1)
   if [ -n "$f" ]; then python3 $R/tools/pmc_aggregate.py $f | grep -E "k_frontier_step" >> $out; else echo "pass $i ($set) failed: $(grep -iE "error code|invalid" /tmp/pmc_u.log | head -1)" >> $out; fi
 done

@@ -3,12 +3,12 @@
 # Usage: bash tools/profile_round.sh <tag>
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; tag=$1; cd /tmp
 rm -rf /tmp/prof_k /tmp/prof_c
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k -- python3 $R/bench.py --no-cpu-baseline --no-verify --no-host --steps 5 --warmup 1 > $R/gpurun_out/${tag}_bench_kernel_trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k -- python3 $R/bench.py --no-cpu-baseline --no-verify --no-host --target off --steps 5 --warmup 1 > $R/gpurun_out/${tag}_bench_kernel_trace.log 2>&1
 f=$(find /tmp/prof_k -name "*kernel_trace.csv" | head -1)
 python3 $R/profiles/summarize_kernel_trace.py $f 5 > $R/gpurun_out/${tag}_config2_summary.md
 s=$(find /tmp/prof_k -name "*kernel_stats.csv" | head -1)
 grep -E "Name|bwtm::" $s | head -40 > $R/gpurun_out/${tag}_config2_rocprofv3_kernel_stats_bwtm.csv
-timeout 900 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/prof_c -- python3 $R/bench.py --no-cpu-baseline --no-verify --steps 1 --warmup 0 --host-steps 1 > $R/gpurun_out/${tag}_bench_copy_trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/prof_c -- python3 $R/bench.py --no-cpu-baseline --no-verify --target off --steps 1 --warmup 0 --host-steps 1 > $R/gpurun_out/${tag}_bench_copy_trace.log 2>&1
 k=$(find /tmp/prof_c -name "*kernel_trace.csv" | head -1); c=$(find /tmp/prof_c -name "*memory_copy_trace.csv" | head -1)
 head -3 $c > $R/gpurun_out/${tag}_memory_copy_trace_head.csv
 python3 - $k $c > $R/gpurun_out/${tag}_trace_inventory.txt <<'PY'

@@ -2,7 +2,7 @@
 # Per-launch durations of k_frontier_step over the last search of a bench run (rocprofv3 kernel trace).
 # Usage: bash tools/step_durations.sh <tag> <bench args...>
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; tag=$1; shift; cd /tmp; rm -rf /tmp/prof_s
-timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_s -- python3 $R/bench.py --no-cpu-baseline --no-verify --no-host --steps 1 --warmup 0 "$@" > /tmp/prof_s.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_s -- python3 $R/bench.py --no-cpu-baseline --no-verify --no-host --target off --steps 1 --warmup 0 "$@" > /tmp/prof_s.log 2>&1
 k=$(find /tmp/prof_s -name "*kernel_trace.csv" | head -1)
 python3 - $k > $R/gpurun_out/${tag}_step_durations.txt <<'PY'
 import csv, sys
