@@ -6,8 +6,8 @@ the reference's native byte format: transcode of both inputs to the device rank 
 LF-walk search, rank-array finalize, interleave, canonical run encoder, sample build
 (the work between the timers of merge(), bwt_merge.cpp:287-299).  At N > 1 the sequences of
 input2 are sharded over the ranks and the rank-array bitvectors are combined with one RCCL
-all-reduce (sum == or: set bits are disjoint); every rank then interleaves and encodes only its
-own range of the output (bwtm_slice_*), so the result is left sharded by byte range.
+reduce-scatter by output range (sum == or: set bits are disjoint); every rank then interleaves and
+encodes only its own range of the output (bwtm_slice_*), so the result is left sharded by byte range.
 
 Prints ONE JSON line on rank 0 (see the contract in the task description), including
   value         the HBM-resident rate (inputs and result stay on the device)
@@ -67,7 +67,7 @@ def main():
                     help="number of input sets; more than 2 = chained merge in command-line order (BASELINE config 5: bwt_merge in1 in2 in3 in4 out), "
                          "intermediate results stay on the device as rank structures, only the last merge encodes")
     ap.add_argument("--force-dist", action="store_true",
-                    help="take the multi-GPU code path (process group, caller-owned bitvector, all-reduce, output slices) even with one rank: "
+                    help="take the multi-GPU code path (process group, caller-owned bitvector, reduce-scatter by output range, output slices) even with one rank: "
                          "a smoke test of that path on a 1-GPU box")
     ap.add_argument("--target", choices=("auto", "on", "off"), default="auto",
                     help="after the configured workload, measure the north star's target size (two sets of --target-reads reads on ONE GPU) and add it to "
@@ -421,7 +421,7 @@ def measure(env, args):
                    "reads_per_set": args.reads, "reads_input1": reads_per_set[0], "read_length": args.readlen,
                    "bases": [mt["bases"] for mt in meta], "native_bytes": [mt["nbytes"] for mt in meta] + [out_bytes],
                    "parallelism": "sequence blocks of input2 sharded over %d GPU(s)%s" %
-                   (world, ", RCCL all-reduce of the rank-array bitvector, result sharded by output range" if sharded else "")},
+                   (world, ", RCCL reduce-scatter of the rank-array bitvector by output range, result sharded by output range" if sharded else "")},
         "roofline": roofline, "job_roofline": job, "kernel_ms_per_step": kernel_ms,
         "host_to_host": host, "peak_device_bytes": peak_device,
         "cpu_baseline": cpu, "verified": verified, "verification": checks,
@@ -678,7 +678,7 @@ def host_to_host(pkg, np, torch, dev, host_in, meta, args):
 def host_to_host_sharded(pkg, np, torch, dev, host_in, meta, args, rank, world, dist):
     """SURVEY 8(d)'s T on N GPUs: page-locked inputs -> this rank's byte range of the native result in page-locked memory.  Every
     native byte crosses PCIe once (each rank uploads 1 / N of both inputs, the parts are all-gathered over xGMI), the sequences
-    of input2 are sharded, the rank arrays are combined by one all-reduce and every rank encodes and downloads its output slice.
+    of input2 are sharded, the rank arrays are combined by one reduce-scatter by output range and every rank encodes and downloads its output slice.
     Data only (the samples of a slice need its successor's first block start; the C++ host downloads them too)."""
     from bwt_merge_amd.dist import merge_sharded, upload_sharded
     torch.cuda.empty_cache(); pkg.trim()
@@ -715,7 +715,7 @@ def host_to_host_sharded(pkg, np, torch, dev, host_in, meta, args, rank, world, 
     merged = meta[0]["bases"] + meta[1]["bases"]
     sec = sum(times) / len(times)
     return {"value": round(merged / 1e9 / sec, 4), "unit": "Gbases/s", "ms_per_step": round(sec * 1e3, 2), "ms_each": [round(x * 1e3, 1) for x in times],
-            "phases_ms": phases, "includes": "sharded H2D of both native inputs (1 / N per link) + all-gather, transcode, sharded search, all-reduce, "
+            "phases_ms": phases, "includes": "sharded H2D of both native inputs (1 / N per link) + all-gather, transcode, sharded search, reduce-scatter, "
             "interleave + encode of the rank's output slice, D2H of the slice; without the samples",
             "bytes": {"h2d_this_rank": int(from_host), "h2d_all_inputs": meta[0]["nbytes"] + meta[1]["nbytes"], "d2h_all_ranks": int(total)}}
 

@@ -48,6 +48,9 @@ SYMBOLS = [
     ("bwtm_merge_consume", C.c_int, [vp, vp, C.POINTER(vp)]),
     ("bwtm_merged_records", u64, [vp, vp]),
     ("bwtm_slice_bounds", C.c_int, [u64, C.c_int, C.c_int, p_u64, p_u64]),
+    ("bwtm_slice_bounds_equal", C.c_int, [u64, C.c_int, C.c_int, p_u64, p_u64, p_u64]),
+    ("bwtm_ra_range_counts", C.c_int, [vp, u64, u64, p_u64, p_u64, p_u64]),
+    ("bwtm_ra_finalize_range", C.c_int, [vp, u64, u64, u64, u64, p_u64, p_u64]),
     ("bwtm_interleave_range", C.c_int, [vp, vp, vp, u64, u64, C.POINTER(vp)]),
     ("bwtm_slice_free", None, [vp]),
     ("bwtm_slice_lasthead", C.c_int, [vp, p_u64]),
@@ -625,6 +628,25 @@ class RankArray:
         check(lib().bwtm_ra_finalize(self.h))
         return self
 
+    def range_counts(self, rec_first, rec_last):
+        """Output-range finalize, step 1: (set bits of the range, per-super local counts [nsup], the words of the range's last chunk [128])."""
+        nsup = (self.n_out >> 25) + 1
+        ones = u64(0)
+        local = np.zeros(nsup, dtype=np.uint64)
+        tail = np.zeros(128, dtype=np.uint64)
+        check(lib().bwtm_ra_range_counts(self.h, rec_first, rec_last, C.byref(ones), local.ctypes.data_as(p_u64), tail.ctypes.data_as(p_u64)))
+        return int(ones.value), local, tail
+
+    def finalize_range(self, rec_first, rec_last, ones_before, ones_total, super_boff, halo_words=None):
+        """Output-range finalize, step 2 (include/bwtm.h: bwtm_ra_finalize_range)."""
+        super_boff = np.ascontiguousarray(super_boff, dtype=np.uint64)
+        assert super_boff.size == (self.n_out >> 25) + 1
+        halo = None if halo_words is None else np.ascontiguousarray(halo_words, dtype=np.uint64)
+        assert halo is None or halo.size == 128
+        check(lib().bwtm_ra_finalize_range(self.h, rec_first, rec_last, ones_before, ones_total, super_boff.ctypes.data_as(p_u64),
+                                           None if halo is None else halo.ctypes.data_as(p_u64)))
+        return self
+
     values = property(lambda s: int(lib().bwtm_ra_values(s.h)))
 
     def download(self):
@@ -764,6 +786,13 @@ def slice_bounds(nrecs, parts, part):
     f, l = u64(0), u64(0)
     check(lib().bwtm_slice_bounds(nrecs, parts, part, C.byref(f), C.byref(l)))
     return int(f.value), int(l.value)
+
+
+def slice_bounds_equal(nrecs, parts, part):
+    """(rec_first, rec_last, bytes of the bitvector per range) of EQUAL output ranges (what a reduce-scatter wants)."""
+    f, l, sb = u64(0), u64(0), u64(0)
+    check(lib().bwtm_slice_bounds_equal(nrecs, parts, part, C.byref(f), C.byref(l), C.byref(sb)))
+    return int(f.value), int(l.value), int(sb.value)
 
 
 def fold_offsets(tables):

@@ -34,15 +34,16 @@ int interleave_impl(const bwtm_index* a, const bwtm_index* b, bwtm_ra* ra, bwtm_
   TRY(x->recs.alloc(x->nrecs * 64));
   TRY(x->sup.alloc(x->nsup * SUP_STRIDE * sizeof(u64)));
   LAUNCH("interleave_sup", k_interleave_sup, div_up(x->nsup, BLOCK_THREADS), BLOCK_THREADS, a->view(), b->view(),
-    ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), x->n, x->sup.as<u64>(), x->nsup);
+    ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), x->n, x->sup.as<u64>(), x->nsup, (const u64*)nullptr);
   LAUNCH("interleave", k_interleave, ra->nchunks, BLOCK_THREADS, a->view(), b->view(),
     ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), (u64)0, ra->nchunks, (u64)0, x->nrecs, x->sup.as<const u64>(), x->recs.as<uint4>());
   return BWTM_OK;
 }
 
-int check_interleave_args(const bwtm_index* a, const bwtm_index* b, const bwtm_ra* ra)
+int check_interleave_args(const bwtm_index* a, const bwtm_index* b, const bwtm_ra* ra, bool allow_ranged = false)
 {
   if(!ra->finalized) { return fail(BWTM_EINVAL, "bwtm_interleave: rank array not finalized"); }
+  if(ra->ranged && !allow_ranged) { return fail(BWTM_EINVAL, "bwtm_interleave: the rank array was finalized for an output range (bwtm_interleave_range takes it)"); }
   if(ra->na != a->n || ra->nb != b->n) { return fail(BWTM_EINVAL, "bwtm_interleave: rank array was created for other inputs"); }
   if(ra->values != b->n) { return fail(BWTM_EINVAL, "bwtm_interleave: rank array holds %llu values, expected %llu", (unsigned long long)ra->values, (unsigned long long)b->n); }
   return BWTM_OK;

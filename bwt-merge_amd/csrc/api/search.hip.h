@@ -19,6 +19,11 @@ struct bwtm_ra
   DevBuf chunk_base;                  // nchunks + 1 u64 (exclusive scan of chunk popcounts)
   bool finalized = false;
   u64 values = 0;
+  // output-range form (bwtm_ra_finalize_range): bits and chunk_base are valid for the chunks of [range_first, range_last) and the one before
+  bool ranged = false;
+  u64 range_first = 0, range_last = 0;
+  DevBuf range_rel;                   // chunk counts of the range, scanned (between bwtm_ra_range_counts and bwtm_ra_finalize_range)
+  DevBuf super_boff;                  // set bits before every super block of the output (ranged form only)
 };
 
 namespace
@@ -302,10 +307,11 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   const bool node_phase = (g_tune.range_ratio > 0);
   if(node_phase)
   {
-    // The cap bounds the level tables (7 arrays of 5 x limit + 1 words: 9.4 GB at 2^25, released before the step loop starts).  2^25
-    // and not 2^24 because level 12 of a read collection has 4^12 = 2^24 nodes plus the few that N adds: at 5 x 10^8 sequences the ratio
-    // rule allows that level (a node level there costs ~2 ms, the element step it replaces 9.5 ms), and 2^24 cut it off by a hair.
-    const u64 limit = std::max<u64>(1, std::min<u64>(count / (u64)g_tune.range_ratio, 1ull << 25));
+    // The cap bounds the level tables (7 arrays of min(5 x limit, count) + 1 words; released before the step loop starts).  2^26 and not
+    // 2^24: at 5 x 10^8 sequences the ratio rule allows level 12, whose 4^12 = 1.7 x 10^7 strings over ACGT are joined by about as many
+    // that hold one N (an N is rare per base, but 12 x 4^11 such strings exist and a third of them occur among 5 x 10^8 reads): 3.7 x 10^7
+    // nodes, a level that costs a quarter of the element step it replaces.
+    const u64 limit = std::max<u64>(1, std::min<u64>(count / (u64)g_tune.range_ratio, 1ull << 26));
     TRY(range_phase(a, b, seq_first, count, ra, limit, levels));
     if(levels.N == 0) { return BWTM_OK; }
     TRY(range_alive(levels, node_offsets));

@@ -84,6 +84,98 @@ extern "C" int bwtm_slice_bounds(uint64_t nrecs, int parts, int part, uint64_t* 
   return BWTM_OK;
 }
 
+extern "C" int bwtm_slice_bounds_equal(uint64_t nrecs, int parts, int part, uint64_t* rec_first, uint64_t* rec_last, uint64_t* shard_bytes)
+{
+  if(parts <= 0 || part < 0 || part >= parts || !rec_first || !rec_last) { return fail(BWTM_EINVAL, "bwtm_slice_bounds_equal: bad argument"); }
+  const u64 nseg = div_up(nrecs, SLICE_ALIGN);
+  const u64 per = std::max<u64>(1, div_up(nseg, (u64)parts)) * SLICE_ALIGN;             // records per range
+  *rec_first = std::min(nrecs, per * (u64)part);
+  *rec_last = std::min(nrecs, per * (u64)(part + 1));
+  if(shard_bytes) { *shard_bytes = per * (REC_POS / 8); }
+  return BWTM_OK;
+}
+
+namespace
+{
+int check_range(const bwtm_ra* ra, u64 rec_first, u64 rec_last, const char* who)
+{
+  const u64 nrecs = ra->nrecs_out;
+  if(rec_first > rec_last || rec_last > nrecs || (rec_first != rec_last && (rec_first % SLICE_ALIGN != 0 || (rec_last % SLICE_ALIGN != 0 && rec_last != nrecs))))
+  {
+    return fail(BWTM_EINVAL, "%s: [%llu, %llu) is not a range of whole %llu-record segments of %llu records", who,
+      (unsigned long long)rec_first, (unsigned long long)rec_last, (unsigned long long)SLICE_ALIGN, (unsigned long long)nrecs);
+  }
+  return BWTM_OK;
+}
+} // namespace
+
+extern "C" int bwtm_ra_range_counts(bwtm_ra* ra, uint64_t rec_first, uint64_t rec_last, uint64_t* ones, uint64_t* super_local, uint64_t* tail_words)
+{
+  if(!ra || !ones) { return fail(BWTM_EINVAL, "bwtm_ra_range_counts: null argument"); }
+  ENTER(ra->ctx);
+  TRY(check_range(ra, rec_first, rec_last, "bwtm_ra_range_counts"));
+  const u64 nsup = num_supers(ra->n_out);
+  *ones = 0;
+  if(super_local) { for(u64 k = 0; k < nsup; k++) { super_local[k] = 0; } }
+  if(tail_words) { for(int k = 0; k < CHUNK_WORDS; k++) { tail_words[k] = 0; } }
+  ra->range_first = rec_first; ra->range_last = rec_last; ra->finalized = false; ra->ranged = false;
+  if(rec_first == rec_last) { ra->range_rel.release(); return BWTM_OK; }
+  const u64 c0 = rec_first >> 6, c1 = div_up(rec_last, 64), nc = c1 - c0;          // rec_first is a multiple of 512: chunk aligned
+  TRY(ra->range_rel.alloc((nc + 1) * sizeof(u64)));
+  HIP_TRY(hipMemsetAsync(ra->range_rel.as<u64>() + nc, 0, sizeof(u64), CTX.stream));
+  LAUNCH("chunk_popc", k_chunk_popc, div_up(nc * WAVE, BLOCK_THREADS), BLOCK_THREADS, ra->bits_as<const u64>() + c0 * CHUNK_WORDS, nc, ra->range_rel.as<u64>());
+  TRY(device_scan<0>(ra->range_rel.as<u64>(), ra->range_rel.as<u64>(), nc + 1));
+  DevBuf sl;
+  if(super_local)
+  {
+    TRY(sl.alloc(nsup * sizeof(u64)));
+    LAUNCH("super_local", k_super_local, div_up(nsup, BLOCK_THREADS), BLOCK_THREADS, ra->range_rel.as<const u64>(), c0, c1, sl.as<u64>(), nsup);
+    HIP_TRY(hipMemcpyAsync(super_local, sl.p, nsup * sizeof(u64), hipMemcpyDeviceToHost, CTX.stream));
+  }
+  if(tail_words) { HIP_TRY(hipMemcpyAsync(tail_words, ra->bits_as<const u64>() + (c1 - 1) * CHUNK_WORDS, CHUNK_WORDS * sizeof(u64), hipMemcpyDeviceToHost, CTX.stream)); }
+  TRY(fetch_u64(ra->range_rel.as<u64>() + nc, 0));
+  HIP_TRY(hipStreamSynchronize(CTX.stream));
+  *ones = CTX.host_scratch[0];
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_ra_finalize_range(bwtm_ra* ra, uint64_t rec_first, uint64_t rec_last, uint64_t ones_before, uint64_t ones_total,
+  const uint64_t* super_boff, const uint64_t* halo_words)
+{
+  if(!ra || !super_boff) { return fail(BWTM_EINVAL, "bwtm_ra_finalize_range: null argument"); }
+  ENTER(ra->ctx);
+  TRY(check_range(ra, rec_first, rec_last, "bwtm_ra_finalize_range"));
+  if(rec_first != ra->range_first || rec_last != ra->range_last || (rec_first != rec_last && !ra->range_rel.p))
+  {
+    return fail(BWTM_EINVAL, "bwtm_ra_finalize_range: call bwtm_ra_range_counts for the same range first");
+  }
+  const u64 nsup = num_supers(ra->n_out);
+  TRY(ra->super_boff.alloc(nsup * sizeof(u64)));
+  // pageable host arrays: staged synchronously by the runtime; a few KB
+  HIP_TRY(hipMemcpyAsync(ra->super_boff.p, super_boff, nsup * sizeof(u64), hipMemcpyHostToDevice, CTX.stream));
+  if(rec_first < rec_last)
+  {
+    const u64 c0 = rec_first >> 6, c1 = div_up(rec_last, 64), nc = c1 - c0;
+    LAUNCH("add_offset", k_add_offset, div_up(nc + 1, BLOCK_THREADS), BLOCK_THREADS, ra->range_rel.as<u64>(), nc + 1, ones_before);
+    HIP_TRY(hipMemcpyAsync(ra->chunk_base.as<u64>() + c0, ra->range_rel.p, (nc + 1) * sizeof(u64), hipMemcpyDeviceToDevice, CTX.stream));
+    if(c0 > 0)
+    {
+      // the chunk before the range (it holds the one record the encoder looks back at): its bits come from the range before
+      u64 halo_ones = 0;
+      if(halo_words) { for(int k = 0; k < CHUNK_WORDS; k++) { halo_ones += (u64)__builtin_popcountll(halo_words[k]); } }
+      if(halo_ones > ones_before) { return fail(BWTM_EINVAL, "bwtm_ra_finalize_range: the halo chunk holds more set bits than all earlier ranges"); }
+      if(halo_words) { HIP_TRY(hipMemcpyAsync(ra->bits_as<u64>() + (c0 - 1) * CHUNK_WORDS, halo_words, CHUNK_WORDS * sizeof(u64), hipMemcpyHostToDevice, CTX.stream)); }
+      else { HIP_TRY(hipMemsetAsync(ra->bits_as<u64>() + (c0 - 1) * CHUNK_WORDS, 0, CHUNK_WORDS * sizeof(u64), CTX.stream)); }
+      CTX.host_scratch[61] = ones_before - halo_ones;
+      HIP_TRY(hipMemcpyAsync(ra->chunk_base.as<u64>() + (c0 - 1), CTX.host_scratch + 61, sizeof(u64), hipMemcpyHostToDevice, CTX.stream));
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(CTX.stream));                       // the caller's arrays have been read
+  ra->range_rel.release();
+  ra->values = ones_total; ra->finalized = true; ra->ranged = true;
+  return BWTM_OK;
+}
+
 extern "C" int bwtm_fold_offsets(const uint64_t* tables, int parts, uint64_t* offsets)
 {
   if(!tables || !offsets || parts < 0) { return fail(BWTM_EINVAL, "bwtm_fold_offsets: bad argument"); }
@@ -98,12 +190,12 @@ extern "C" int bwtm_interleave_range(const bwtm_index* a, const bwtm_index* b, b
   if(!a || !b || !ra || !out) { return fail(BWTM_EINVAL, "bwtm_interleave_range: null argument"); }
   if(a->ctx != ra->ctx || b->ctx != ra->ctx) { return fail(BWTM_EINVAL, "bwtm_interleave_range: handles of different contexts"); }
   ENTER(ra->ctx);
-  TRY(check_interleave_args(a, b, ra));
+  TRY(check_interleave_args(a, b, ra, true));
   const u64 nrecs = ra->nrecs_out;
-  if(rec_first > rec_last || rec_last > nrecs || (rec_first != rec_last && (rec_first % SLICE_ALIGN != 0 || (rec_last % SLICE_ALIGN != 0 && rec_last != nrecs))))
+  TRY(check_range(ra, rec_first, rec_last, "bwtm_interleave_range"));
+  if(ra->ranged && (rec_first != ra->range_first || rec_last != ra->range_last))
   {
-    return fail(BWTM_EINVAL, "bwtm_interleave_range: [%llu, %llu) is not a range of whole %llu-record segments of %llu records",
-      (unsigned long long)rec_first, (unsigned long long)rec_last, (unsigned long long)SLICE_ALIGN, (unsigned long long)nrecs);
+    return fail(BWTM_EINVAL, "bwtm_interleave_range: the rank array was finalized for the records [%llu, %llu)", (unsigned long long)ra->range_first, (unsigned long long)ra->range_last);
   }
   bwtm_slice* s = new bwtm_slice();
   s->ctx = t_ctx;
@@ -118,7 +210,7 @@ extern "C" int bwtm_interleave_range(const bwtm_index* a, const bwtm_index* b, b
     TRY(s->recs.alloc((rec_last - s->rec_halo + 1) * 64));
     TRY(s->sup.alloc(s->nsup * SUP_STRIDE * sizeof(u64)));
     LAUNCH("interleave_sup", k_interleave_sup, div_up(s->nsup, BLOCK_THREADS), BLOCK_THREADS, a->view(), b->view(),
-      ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), s->n, s->sup.as<u64>(), s->nsup);
+      ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), s->n, s->sup.as<u64>(), s->nsup, (ra->ranged ? ra->super_boff.as<const u64>() : (const u64*)nullptr));
     if(rec_last > s->rec_halo)
     {
       const u64 c0 = s->rec_halo >> 6, c1 = div_up(rec_last, 64);

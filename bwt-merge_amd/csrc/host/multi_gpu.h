@@ -7,20 +7,31 @@
        (all-gather over xGMI: the PCIe links carry every byte once instead of G times), then decodes and transcodes the
        complete copy (the indexes are replicated: every LF chain touches arbitrary positions of both);
     2. thread g searches block g of b's sequences (getBounds, utils.cpp:169-187) into its own bitvector;
-    3. ONE exchange: all-reduce (sum == or, the bits are disjoint) of the bitvectors -- RCCL over xGMI, called
-       directly (ncclAllReduce on the buffer bwtm_ra_device_buffer() exposes);
+    3. ONE bulk exchange: reduce-scatter (sum == or, the bits are disjoint) of the bitvectors by equal OUTPUT RANGES -- RCCL over
+       xGMI, called directly (ncclReduceScatter in place on the buffer bwtm_ra_device_buffer() exposes): every GPU receives only the
+       range it will interleave, half the bytes of an all-reduce; the few words a range needs from the others (set bits before
+       it, offsets of the output's super blocks, the chunk of bits before it: bwtm_ra_range_counts / bwtm_ra_finalize_range)
+       cross the threads through shared host variables;
     4. every thread interleaves and encodes only ITS range of the output (bwtm_interleave_range / bwtm_slice_*);
        the two encoder carries (open run, byte offset mod 64) cross the threads through shared host variables;
     5. every thread downloads its slice straight into its place in the result's page-locked arrays
        (eight D2H streams, each 1 / G of the output).
 
   Devices may repeat (e.g. {0, 0}): then the "GPUs" are contexts of one GPU and step 3 uses bwtm_ra_or_from()
-  instead of RCCL -- how the slicing logic is tested on a one-GPU box.
+  instead of RCCL, after which every thread CLEARS the bits outside its own range -- what a reduce-scatter leaves undefined --
+  so that the range logic is tested on a one-GPU box.
+
+  Buffers that RCCL or a peer GPU touches cannot come from the library's pool (its mapped blocks are device-local): the staging
+  buffer of the sharded upload and the bitvector are plain hipMalloc blocks, kept per device in a process-wide cache
+  (DeviceBuffers) and reused by the next merge of a chain instead of being allocated and freed per merge -- a hipMalloc that has
+  to wait for deferred frees takes seconds on MI355X.  Blocks above an eighth of the device's memory (the
+  native bytes of a 200 Gbase input) are released as soon as their phase is over: holding them would not leave room for the records.
 */
 #ifndef BWTM_HOST_MULTI_GPU_H
 #define BWTM_HOST_MULTI_GPU_H
 
 #include <condition_variable>
+#include <map>
 #include <mutex>
 #include <set>
 #include <thread>
@@ -54,6 +65,48 @@ private:
   std::mutex mu; std::condition_variable cv;
   size_type threads, waiting, generation;
 };
+
+#ifdef BWTM_WITH_RCCL
+// Per-device hipMalloc blocks that survive a merge (slot 0 / 1: staging of the two inputs, slot 2: the rank-array bitvector).
+class DeviceBuffers
+{
+public:
+  static DeviceBuffers& instance() { static DeviceBuffers b; return b; }
+  // A block of at least `bytes` on `device` (the current device of the calling thread is set to it); reuses the cached block of the
+  // slot when it is large enough and not more than twice as large.
+  void* get(int device, int slot, size_t bytes)
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    Entry& e = entries[std::make_pair(device, slot)];
+    if(e.p && e.bytes >= bytes && e.bytes <= 2 * bytes + (64u << 20)) { return e.p; }
+    if(hipSetDevice(device) != hipSuccess) { return nullptr; }
+    if(e.p) { (void)hipFree(e.p); e.p = nullptr; e.bytes = 0; }
+    if(hipMalloc(&e.p, bytes) != hipSuccess) { (void)hipGetLastError(); e.p = nullptr; return nullptr; }
+    e.bytes = bytes;
+    return e.p;
+  }
+  // After use: blocks above an eighth of the device's memory go back to the driver, the others stay for the next merge.
+  void done(int device, int slot)
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = entries.find(std::make_pair(device, slot));
+    if(it == entries.end() || !it->second.p) { return; }
+    size_t free_b = 0, total_b = 0;
+    if(hipSetDevice(device) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = 0; }
+    if(total_b == 0 || it->second.bytes > total_b / 8) { (void)hipFree(it->second.p); entries.erase(it); }
+  }
+  void releaseAll()
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    for(auto& kv : entries) { if(kv.second.p && hipSetDevice(kv.first.first) == hipSuccess) { (void)hipFree(kv.second.p); } }
+    entries.clear();
+  }
+private:
+  struct Entry { void* p = nullptr; size_t bytes = 0; };
+  std::mutex mu;
+  std::map<std::pair<int, int>, Entry> entries;
+};
+#endif
 
 struct MultiGPUTimes
 {
@@ -126,6 +179,8 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
   std::vector<void*> bits(G, nullptr); std::vector<uint64_t> bits_bytes(G, 0);
   std::vector<uint64_t> heads(G, 0), tables(G * 64, 0), offsets(G + 1, 0), first_block_start(G, ~(uint64_t)0);
   std::vector<uint64_t> block_first(G, 0), block_count(G, 0);
+  const size_type nsup = ((a.size() + b.size()) >> 25) + 1;                     // super blocks of the output's rank structure
+  std::vector<uint64_t> range_first(G, 0), range_last(G, 0), range_ones(G, 0), super_local(G * nsup, 0), tails(G * 128, 0);
 #ifdef BWTM_EXPERIMENTAL
   std::vector<bwtm_fslice_view> views(G);
 #endif
@@ -137,14 +192,16 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
   // One input, sharded over the links: staging[g] = this GPU's full-size device buffer (hipMalloc: peers and RCCL may touch it).
   std::vector<void*> staging_a(G, nullptr), staging_b(G, nullptr);
   std::vector<uint64_t> host_bytes_per_gpu(G, 0);
-  auto uploadSharded = [&](const BlockArray& data, size_type sequences, size_type bases, const uint64_t* C, size_type g, std::vector<void*>& staging, ncclComm_t comm) -> bwtm_index*
+  auto uploadSharded = [&](const BlockArray& data, size_type sequences, size_type bases, const uint64_t* C, size_type g, std::vector<void*>& staging, int slot, ncclComm_t comm) -> bwtm_index*
   {
     const uint64_t nbytes = data.size();
     const uint64_t chunk = ((nbytes + G - 1) / G + 255) / 256 * 256;          // equal parts (the collective wants them), 256-byte aligned
     const uint64_t off = std::min<uint64_t>(g * chunk, nbytes), len = std::min<uint64_t>(chunk, nbytes - off);
     auto check = [&](hipError_t e, const char* what) { if(e != hipSuccess) { std::cerr << "mergeMultiGPU(): " << what << ": " << hipGetErrorString(e) << std::endl; std::exit(EXIT_FAILURE); } };
     check(hipSetDevice(devices[g]), "hipSetDevice");
-    check(hipMalloc(&staging[g], chunk * G + 16), "hipMalloc of the staging buffer");
+    // contexts of one GPU share the device: every thread needs its own block there, so only distinct devices use the cache
+    if(distinct) { staging[g] = DeviceBuffers::instance().get(devices[g], slot, chunk * G + 16); if(!staging[g]) { check(hipErrorOutOfMemory, "staging buffer"); } }
+    else { check(hipMalloc(&staging[g], chunk * G + 16), "hipMalloc of the staging buffer"); }
     check(hipMemset((char*)staging[g] + nbytes, 0, chunk * G + 16 - nbytes), "hipMemset");      // readable zeros behind the stream
     if(len > 0) { check(hipMemcpy((char*)staging[g] + off, data.data() + off, len, hipMemcpyHostToDevice), "H2D copy of this GPU's part"); }
     host_bytes_per_gpu[g] += len;
@@ -169,7 +226,8 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
     bwtm_index* x = nullptr;
     gpuCheck(bwtm_index_from_device_borrowed(staging[g], nbytes, sequences, bases, C, &x), "mergeMultiGPU()");
     gpuCheck(bwtm_index_drop_native(x), "mergeMultiGPU()");                 // synchronizes: the staging buffer is free again
-    check(hipFree(staging[g]), "hipFree"); staging[g] = nullptr;
+    if(distinct) { DeviceBuffers::instance().done(devices[g], slot); } else { check(hipFree(staging[g]), "hipFree"); }
+    staging[g] = nullptr;
     return x;
   };
 #endif
@@ -186,8 +244,8 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
       // Sharded upload: this GPU's PCIe link carries only 1 / G of each input's native bytes; the other parts arrive from the
       // peers (all-gather over xGMI, or device-to-device copies between contexts of one GPU); every GPU then decodes and
       // transcodes its complete device copy (BWT::load, ~9 ms per 5 Gbase input).
-      A = uploadSharded(adata, a.sequences(), a.size(), ca.data(), g, staging_a, (distinct ? comms[g] : nullptr));
-      B = uploadSharded(bdata, b.sequences(), b.size(), cb.data(), g, staging_b, (distinct ? comms[g] : nullptr));
+      A = uploadSharded(adata, a.sequences(), a.size(), ca.data(), g, staging_a, 0, (distinct ? comms[g] : nullptr));
+      B = uploadSharded(bdata, b.sequences(), b.size(), cb.data(), g, staging_b, 1, (distinct ? comms[g] : nullptr));
     }
     else
 #endif
@@ -199,14 +257,19 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
     }
     if(g == 0) { local.upload = readTimer() - t0; }
 
-    // Across devices the bitvector is handed to ncclAllReduce, which (all ranks in one process) may let a peer GPU read or write the
-    // buffer directly: the library's pooled blocks are mapped for their own device only, so this buffer comes from hipMalloc.
+    // Equal output ranges (the collective wants equal shares): range g = records [rec_first, rec_last), shard_bytes of bitvector each.
+    uint64_t rec_first = 0, rec_last = 0, shard_bytes = 0;
+    gpuCheck(bwtm_slice_bounds_equal(bwtm_merged_records(A, B), (int)G, (int)g, &rec_first, &rec_last, &shard_bytes), "mergeMultiGPU()");
+    range_first[g] = rec_first; range_last[g] = rec_last;
+    // Across devices the bitvector is handed to ncclReduceScatter, which (all ranks in one process) may let a peer GPU read or write the
+    // buffer directly: the library's pooled blocks are mapped for their own device only, so this buffer is a cached hipMalloc block.
     void* shared_bits = nullptr;
     if(distinct && G > 1)
     {
 #ifdef BWTM_WITH_RCCL
-      const uint64_t need = bwtm_ra_buffer_bytes(A, B);
-      if(hipSetDevice(devices[g]) != hipSuccess || hipMalloc(&shared_bits, need) != hipSuccess || hipMemset(shared_bits, 0, need) != hipSuccess)
+      const uint64_t need = G * shard_bytes;                       // >= bwtm_ra_buffer_bytes(A, B): zero words behind the bitvector
+      shared_bits = DeviceBuffers::instance().get(devices[g], 2, need);
+      if(!shared_bits || hipSetDevice(devices[g]) != hipSuccess || hipMemset(shared_bits, 0, need) != hipSuccess)
       {
         std::cerr << "mergeMultiGPU(): cannot allocate the rank-array bitvector" << std::endl; std::exit(EXIT_FAILURE);
       }
@@ -244,7 +307,7 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
     gpuCheck(bwtm_ra_device_buffer(ra, &bits[g], &bits_bytes[g]), "mergeMultiGPU()");      // synchronizes: the search is done
     if(g == 0) { local.search = readTimer() - t0 - local.upload; }
 
-    // The one exchange.
+    // The one bulk exchange: every GPU receives the union of all shards inside ITS output range.
     barrier.wait();
     double t_x = readTimer();
     if(G > 1)
@@ -254,33 +317,63 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
 #ifdef BWTM_WITH_RCCL
         hipStream_t stream = nullptr;
         if(hipSetDevice(devices[g]) != hipSuccess || hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { std::cerr << "mergeMultiGPU(): no stream" << std::endl; std::exit(EXIT_FAILURE); }
-        if(ncclAllReduce(bits[g], bits[g], bits_bytes[g] / sizeof(uint64_t), ncclUint64, ncclSum, comms[g], stream) != ncclSuccess)
+        if(ncclReduceScatter(bits[g], (char*)bits[g] + g * shard_bytes, shard_bytes / sizeof(uint64_t), ncclUint64, ncclSum, comms[g], stream) != ncclSuccess)
         {
-          std::cerr << "mergeMultiGPU(): ncclAllReduce failed" << std::endl; std::exit(EXIT_FAILURE);
+          std::cerr << "mergeMultiGPU(): ncclReduceScatter failed" << std::endl; std::exit(EXIT_FAILURE);
         }
         (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream);
 #endif
       }
       else
       {
-        // contexts of one GPU: thread 0 collects all shards, then everybody takes the union from it
+        // contexts of one GPU: thread 0 collects all shards, everybody takes the union from it -- and then forgets what lies outside
+        // its own range, as after a reduce-scatter
         if(g == 0) { for(size_type h = 1; h < G; h++) { gpuCheck(bwtm_ra_or_from(ra, bits[h], bits_bytes[h]), "mergeMultiGPU()"); } }
         barrier.wait();
         if(g != 0) { gpuCheck(bwtm_ra_or_from(ra, bits[0], bits_bytes[0]), "mergeMultiGPU()"); }
+        barrier.wait();
+#ifdef BWTM_WITH_RCCL
+        // (the share a reduce-scatter would have delivered: [g, g + 1) * shard_bytes; the null stream does not order with the library's
+        // streams, hence the device-wide synchronisation)
+        const uint64_t lo = std::min<uint64_t>(g * shard_bytes, bits_bytes[g]), hi = std::min<uint64_t>((g + 1) * shard_bytes, bits_bytes[g]);
+        if(hipSetDevice(devices[g]) != hipSuccess || hipMemset(bits[g], 0xA5, lo) != hipSuccess ||
+           hipMemset((char*)bits[g] + hi, 0xA5, bits_bytes[g] - hi) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+        {
+          std::cerr << "mergeMultiGPU(): hipMemset failed" << std::endl; std::exit(EXIT_FAILURE);
+        }
+#endif
       }
       barrier.wait();
     }
+    // The small exchange: set bits of every range, local offsets of the supers that start in it, its last chunk of bits.
+    gpuCheck(bwtm_ra_range_counts(ra, rec_first, rec_last, &range_ones[g], super_local.data() + g * nsup, tails.data() + g * 128), "mergeMultiGPU()");
+    barrier.wait();
     if(g == 0) { local.exchange = readTimer() - t_x; }
 
     // This thread's range of the output.
     double t_i = readTimer();
-    gpuCheck(bwtm_ra_finalize(ra), "mergeMultiGPU()");
-    uint64_t rec_first = 0, rec_last = 0;
-    gpuCheck(bwtm_slice_bounds(bwtm_merged_records(A, B), (int)G, (int)g, &rec_first, &rec_last), "mergeMultiGPU()");
+    {
+      uint64_t before = 0, total = 0;
+      for(size_type h = 0; h < G; h++) { if(h < g) { before += range_ones[h]; } total += range_ones[h]; }
+      std::vector<uint64_t> super_boff(nsup, 0);
+      for(size_type sb = 0; sb < nsup; sb++)
+      {
+        const uint64_t q = (uint64_t)sb << 18;                     // the super's first record
+        uint64_t prefix = 0;
+        for(size_type h = 0; h < G; h++)
+        {
+          if(q >= range_first[h] && q < range_last[h]) { super_boff[sb] = prefix + super_local[h * nsup + sb]; break; }
+          prefix += range_ones[h];
+        }
+      }
+      const uint64_t* halo = nullptr;
+      for(size_type h = g; h-- > 0; ) { if(range_last[h] > range_first[h]) { halo = tails.data() + h * 128; break; } }
+      gpuCheck(bwtm_ra_finalize_range(ra, rec_first, rec_last, before, total, super_boff.data(), halo), "mergeMultiGPU()");
+    }
     gpuCheck(bwtm_interleave_range(A, B, ra, rec_first, rec_last, &slice), "mergeMultiGPU()");
     bwtm_ra_free(ra); bwtm_index_free(A); bwtm_index_free(B);
 #ifdef BWTM_WITH_RCCL
-    if(shared_bits) { (void)hipFree(shared_bits); }
+    if(shared_bits) { DeviceBuffers::instance().done(devices[g], 2); }
 #endif
     gpuCheck(bwtm_slice_lasthead(slice, &heads[g]), "mergeMultiGPU()");
     barrier.wait();

@@ -20,6 +20,22 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_chunk_popc(const u64* bits, u
   if(lane_id() == 0) { cnt[chunk] = v; }
 }
 
+// Output-range finalize: p[k] += v for k < n; out[s] = rel[(s << 12) - c0] for the supers that start at a chunk in [c0, c1) (a super
+// starts at record s << 18 = chunk s << 12), zero for the others.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_add_offset(u64* p, u64 n, u64 v)
+{
+  u64 k = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(k < n) { p[k] += v; }
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_super_local(const u64* rel, u64 c0, u64 c1, u64* out, u64 nsup)
+{
+  u64 s = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(s >= nsup) { return; }
+  const u64 c = s << (SUPER_REC_SHIFT - 6);
+  out[s] = (c >= c0 && c < c1 ? rel[c - c0] : 0);
+}
+
 // dst |= src over the words of two interleaving bitvectors (shards of one rank array searched into separate buffers of the same
 // device; the bits of different shards are disjoint).
 __global__ void __launch_bounds__(BLOCK_THREADS) k_bits_or(u64* dst, const u64* src, u64 nwords)
@@ -119,13 +135,15 @@ __device__ inline u64 bits_before_record(const u64* bits, const u64* chunk_base,
 }
 
 // Super table of the output: absolute counts at the start of every super.
+// super_boff (output-range form, bwtm_ra_finalize_range): the set bits before every super are given -- the bitvector of a GPU that
+// took part in a reduce-scatter is complete only inside its own range.
 __global__ void __launch_bounds__(BLOCK_THREADS) k_interleave_sup(IndexView A, IndexView B, const u64* bits, const u64* chunk_base,
-  u64 n_out, u64* sup, u64 nsup)
+  u64 n_out, u64* sup, u64 nsup, const u64* super_boff)
 {
   u64 s = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
   if(s >= nsup) { return; }
   u64 q = s << SUPER_REC_SHIFT;
-  u64 b_off = bits_before_record(bits, chunk_base, q);
+  u64 b_off = (super_boff ? super_boff[s] : bits_before_record(bits, chunk_base, q));
   u64 a_off = (q << REC_SHIFT) - b_off;
   if(a_off > A.n) { a_off = A.n; }
   if(b_off > B.n) { b_off = B.n; }

@@ -3,8 +3,12 @@
 The path shards over the sequences of the second input (every LF chain is independent; the
 reference hands out sequence blocks to threads the same way, fmi.cpp:355-357).  Every rank
 searches its contiguous block, then ONE bulk exchange combines the rank-array shards: each rank
-has set a disjoint subset of the bits of the interleaving bitvector, so an all-reduce with
-SUM over 64-bit words equals the bitwise OR (no carries).
+has set a disjoint subset of the bits of the interleaving bitvector, so SUM over 64-bit words
+equals the bitwise OR (no carries).  Every rank consumes only its own range of the OUTPUT afterwards,
+so the exchange is a REDUCE-SCATTER by output range (exchange_bitvector_ranges): half the bytes of
+the all-reduce of the first versions, and no rank counts bits it never reads; what the ranks need
+from each other beyond their own range -- the number of set bits before it, the offsets of the
+output's super blocks, the one chunk of bits before it -- is a few KB in one small all-reduce.
 
 After the exchange every rank interleaves and encodes only its own range of the OUTPUT (mergeBWT
 cut by output position, bwt.cpp:215-282).  Two facts cross a slice boundary and travel as two tiny
@@ -42,11 +46,64 @@ def shard_range(sequences, rank, world):
 
 
 def exchange_bitvector(words, dist=None):
-    """All-reduce of the rank-array bitvector shards (an int64 tensor viewed as 64-bit words)."""
+    """All-reduce of the rank-array bitvector shards (an int64 tensor viewed as 64-bit words): the form in which EVERY rank ends up
+    with the whole bitvector (kept for callers that want that; the merge uses exchange_bitvector_ranges)."""
     if dist is None:
         import torch.distributed as dist
     dist.all_reduce(words, op=dist.ReduceOp.SUM)
     return words
+
+
+CHUNK_WORDS = 128                  # 64-bit words of the bitvector per chunk of 64 output records (kernels/interleave.hip.h)
+SUPER_SHIFT = 25                   # positions per super block of the rank structure (bwtm_device.h)
+
+
+def exchange_bitvector_ranges(words, shard_words, rank, world, dist, torch):
+    """Reduce-scatter of the bitvector by EQUAL output ranges: `words` (int64, world * shard_words entries, this rank's bits set, zero
+    behind the bitvector) -> afterwards words[rank * shard_words : (rank + 1) * shard_words] holds the sum (= or) over all ranks and
+    the rest of `words` is unspecified.  Every rank sends and receives (world - 1) / world of ONE bitvector: half of an all-reduce."""
+    assert words.numel() == world * shard_words
+    if dist is None or world == 1:
+        return words
+    mine = torch.empty(shard_words, dtype=words.dtype, device=words.device)
+    dist.reduce_scatter_tensor(mine, words, op=dist.ReduceOp.SUM)
+    words[rank * shard_words: (rank + 1) * shard_words].copy_(mine)
+    return words
+
+
+def super_owners(nsup, bounds):
+    """owner[s] = the rank whose range of output records holds the start of super block s (record s << 18); the ranges are consecutive
+    and cover all records, and every super starts at a record below the total."""
+    starts = np.arange(nsup, dtype=np.uint64) << np.uint64(SUPER_SHIFT - 7)
+    owner = np.zeros(nsup, dtype=np.int64)
+    for g, (first, last) in enumerate(bounds):
+        owner[(starts >= np.uint64(first)) & (starts < np.uint64(last))] = g
+    return owner
+
+
+def combine_range_counts(ones, super_local, tail_words, bounds, rank, world, dist, torch, device):
+    """The small exchange behind the reduce-scatter.  ones / super_local / tail_words: what bwtm_ra_range_counts returned for this rank's
+    range; bounds[g] = (rec_first, rec_last) of every rank.  One all-reduce (every entry is written by exactly one rank) of
+    [world range totals | nsup local super offsets | world x 128 tail words] -> (ones_before, ones_total, super_boff[nsup], halo_words or
+    None) for bwtm_ra_finalize_range."""
+    nsup = int(super_local.size)
+    vec = np.zeros(world + nsup + world * CHUNK_WORDS, dtype=np.uint64)
+    vec[rank] = ones
+    vec[world: world + nsup] = super_local
+    vec[world + nsup + rank * CHUNK_WORDS: world + nsup + (rank + 1) * CHUNK_WORDS] = tail_words
+    if dist is not None and world > 1:
+        t = torch.from_numpy(vec.view(np.int64).copy()).to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        vec = t.cpu().numpy().view(np.uint64)
+    totals = vec[:world]
+    prefix = np.concatenate([[0], np.cumsum(totals)]).astype(np.uint64)
+    super_boff = prefix[super_owners(nsup, bounds)] + vec[world: world + nsup]
+    halo = None
+    for g in range(rank - 1, -1, -1):                        # the nearest earlier range that is not empty
+        if bounds[g][1] > bounds[g][0]:
+            halo = vec[world + nsup + g * CHUNK_WORDS: world + nsup + (g + 1) * CHUNK_WORDS].copy()
+            break
+    return int(prefix[rank]), int(prefix[world]), super_boff, halo
 
 
 def fold_offsets(tables):
@@ -159,26 +216,29 @@ def search_sliced(pkg, indexes, ras, sequences, enter=None):
 
 
 def merge_sharded(pkg, A, B, rank, world, dist, torch, device):
-    """FMI::FMI(a, b) on `world` GPUs, as this rank sees it: search of its block of b's sequences, all-reduce of the
-    rank-array bitvector (RCCL over xGMI), then interleave + encode of its own slice of the output.  Returns the
-    encoded pkg.Slice (total_nbytes = size of the whole merged stream)."""
-    nbytes = pkg.ra_buffer_bytes(A, B)
-    buf = torch.zeros(nbytes // 8, dtype=torch.int64, device=device)
+    """FMI::FMI(a, b) on `world` GPUs, as this rank sees it: search of its block of b's sequences, reduce-scatter of the rank-array
+    bitvector by output range (RCCL over xGMI) + one small all-reduce, then interleave + encode of its own range of the output.
+    Returns the encoded pkg.Slice (total_nbytes = size of the whole merged stream)."""
+    nrecs = pkg.merged_records(A, B)
+    bounds = [pkg.slice_bounds_equal(nrecs, world, g) for g in range(world)]
+    rec_first, rec_last, shard_bytes = bounds[rank]
+    assert world * shard_bytes >= pkg.ra_buffer_bytes(A, B)            # equal shares for the collective: zero words behind the bitvector
+    buf = torch.zeros(world * shard_bytes // 8, dtype=torch.int64, device=device)
     torch.cuda.synchronize()
-    ra = pkg.RankArray(A, B, buf.data_ptr(), nbytes)
+    ra = pkg.RankArray(A, B, buf.data_ptr(), buf.numel() * 8)
     first, last = shard_range(B.sequences, rank, world)
     if first <= last:
         ra.search(A, B, first, last)
     pkg.synchronize()
-    if dist is not None:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)              # disjoint bits: sum == or
-        torch.cuda.synchronize()
-    ra.finalize()
-    rec_first, rec_last = pkg.slice_bounds(pkg.merged_records(A, B), world, rank)
+    exchange_bitvector_ranges(buf, shard_bytes // 8, rank, world, dist, torch)
+    torch.cuda.synchronize()
+    ones, local, tail = ra.range_counts(rec_first, rec_last)
+    before, total, super_boff, halo = combine_range_counts(ones, local, tail, [(b[0], b[1]) for b in bounds], rank, world, dist, torch, device)
+    ra.finalize_range(rec_first, rec_last, before, total, super_boff, halo)
     S = pkg.Slice(A, B, ra, rec_first, rec_last)
-    _, offset, total = exchange_encoder_carries(S.lasthead(), S.size_table, rank, world, dist, torch, device)
+    _, offset, total_bytes = exchange_encoder_carries(S.lasthead(), S.size_table, rank, world, dist, torch, device)
     S.encode(offset)
-    S.total_nbytes = total
+    S.total_nbytes = total_bytes
     pkg.synchronize()
     ra.free()
     del buf

@@ -273,7 +273,23 @@ typedef struct bwtm_slice bwtm_slice;
 uint64_t bwtm_merged_records(const bwtm_index* a, const bwtm_index* b);        /* output records of merging a and b */
 /* Part `part` of `parts` near-equal ranges of whole 512-record encoder segments (getBounds, utils.cpp:169-187). */
 int bwtm_slice_bounds(uint64_t nrecs, int parts, int part, uint64_t* rec_first, uint64_t* rec_last);
-/* mergeBWT for the output records [rec_first, rec_last) (bounds from bwtm_slice_bounds). */
+/* The same with EQUAL ranges (the last ones shorter or empty): range g = records [g * R, (g + 1) * R) clipped to nrecs, R a multiple of 512.
+   *shard_bytes = R * 16 = the bytes of the interleaving bitvector one range covers: a buffer of parts * shard_bytes bytes (zero behind
+   bwtm_ra_buffer_bytes()) can be handed to a reduce-scatter, which wants equal shares. */
+int bwtm_slice_bounds_equal(uint64_t nrecs, int parts, int part, uint64_t* rec_first, uint64_t* rec_last, uint64_t* shard_bytes);
+/* Output-range form of bwtm_ra_finalize(), for a rank array whose bitvector is complete only inside [rec_first, rec_last) -- what a
+   REDUCE-SCATTER of the shards' bitvectors by output range leaves on a GPU (half the bytes of an all-reduce, and nobody counts bits it
+   never reads).  Step 1, bwtm_ra_range_counts: *ones = set bits of the range; super_local[s] (nsup = (n_out >> 25) + 1 entries, zero for
+   the others) = set bits between the start of the range and the start of super block s, for the supers that start inside the range;
+   tail_words[128] = the bitvector words of the range's last chunk of 64 records (the next range's encoder needs the one record before
+   its own).  These few KB are what the GPUs exchange.  Step 2, bwtm_ra_finalize_range: ones_before = set bits of all earlier ranges,
+   ones_total = of all ranges, super_boff[s] = set bits before super s for ALL supers (= prefix of its owner + super_local[s]),
+   halo_words = tail_words of the nearest earlier non-empty range (NULL for the first).  Afterwards bwtm_interleave_range() accepts exactly
+   this range. */
+int bwtm_ra_range_counts(bwtm_ra* ra, uint64_t rec_first, uint64_t rec_last, uint64_t* ones, uint64_t* super_local, uint64_t* tail_words);
+int bwtm_ra_finalize_range(bwtm_ra* ra, uint64_t rec_first, uint64_t rec_last, uint64_t ones_before, uint64_t ones_total,
+                           const uint64_t* super_boff, const uint64_t* halo_words);
+/* mergeBWT for the output records [rec_first, rec_last) (bounds from bwtm_slice_bounds / bwtm_slice_bounds_equal). */
 int bwtm_interleave_range(const bwtm_index* a, const bwtm_index* b, bwtm_ra* ra, uint64_t rec_first, uint64_t rec_last,
                           bwtm_slice** out);
 void bwtm_slice_free(bwtm_slice* slice);

@@ -73,6 +73,113 @@ def test_two_rank_exchange_equals_full_rank_array(tmp_path, oracle):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# The exchange as the merge runs it: reduce-scatter of the bitvector by EQUAL output ranges + one small all-reduce
+# (bwt-merge_amd/dist.py: exchange_bitvector_ranges, combine_range_counts), world_size 2 and 3 over gloo.  What the library computes
+# on a GPU for a range (bwtm_ra_range_counts) is restated with numpy here.
+
+def _walk_bits(orc, a, b, first, last):
+    n_out = a.bases + b.bases
+    bits = np.zeros((n_out + 63) // 64, dtype=np.uint64)
+    for j in range(first, last + 1):
+        i, r = j, a.sequences
+        while True:
+            p = i + r
+            bits[p >> 6] |= np.uint64(1) << np.uint64(p & 63)
+            nxt, c = b.LF(i)
+            if c == 0:
+                break
+            i = nxt; r = a.LF(r, c)
+    return bits
+
+
+def _popcount(words):
+    return int(np.unpackbits(np.ascontiguousarray(words).view(np.uint8)).sum())
+
+
+def _range_worker(rank, world, port, result_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import _pkg
+    pkg = _pkg.load()
+    from bwt_merge_amd.dist import combine_range_counts, exchange_bitvector_ranges, shard_range
+    from oracle import oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ta = orc.generate_reads(1001, 900, 100); tb = orc.generate_reads(1002, 700, 100)
+    a = orc.FMI.from_text(ta); b = orc.FMI.from_text(tb)
+    n_out = a.bases + b.bases
+    nrecs = (n_out >> 7) + 1
+    bounds = [pkg.slice_bounds_equal(nrecs, world, g) for g in range(world)]
+    rec_first, rec_last, shard_bytes = bounds[rank]
+    shard_words = shard_bytes // 8
+    first, last = shard_range(b.sequences, rank, world)
+    mine = _walk_bits(orc, a, b, first, last)
+    words = np.zeros(world * shard_words, dtype=np.uint64)
+    words[: mine.size] = mine
+    t = torch.from_numpy(words.view(np.int64).copy())
+    exchange_bitvector_ranges(t, shard_words, rank, world, dist, torch)
+    got = t.numpy().view(np.uint64)
+    own = got[rank * shard_words: (rank + 1) * shard_words]
+    # bwtm_ra_range_counts on this rank's range, in numpy
+    nsup = (n_out >> 25) + 1
+    c0, c1 = rec_first >> 6, -(-rec_last // 64)
+    ones = _popcount(got[2 * rec_first: 128 * c1]) if rec_last > rec_first else 0
+    local = np.zeros(nsup, dtype=np.uint64)                   # super 0 starts at record 0: local offset 0 for its owner
+    tail = (got[128 * (c1 - 1): 128 * c1].copy() if rec_last > rec_first else np.zeros(128, dtype=np.uint64))
+    before, total, super_boff, halo = combine_range_counts(ones, local, tail, [(x[0], x[1]) for x in bounds], rank, world, dist, torch, torch.device("cpu"))
+    np.savez(os.path.join(result_dir, "range_%d.npz" % rank), own=own, rec_first=rec_first, rec_last=rec_last, before=before, total=total,
+             super_boff=super_boff, halo=(halo if halo is not None else np.zeros(0, dtype=np.uint64)), shard_words=shard_words)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_reduce_scatter_by_output_range(tmp_path, oracle, bwtm, world):
+    mp.start_processes(_range_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    ta = oracle.generate_reads(1001, 900, 100); tb = oracle.generate_reads(1002, 700, 100)
+    a = oracle.FMI.from_text(ta); b = oracle.FMI.from_text(tb)
+    ranks, counts, _ = oracle.search(a, b, threads=1)
+    ra = oracle.ra_from_runs(ranks, counts)
+    n_out = a.bases + b.bases
+    expect = np.zeros(((n_out + 63) // 64) * 64, dtype=np.uint8)
+    expect[np.arange(b.bases, dtype=np.uint64) + ra] = 1
+    nonempty = 0
+    for r in range(world):
+        z = np.load(tmp_path / ("range_%d.npz" % r))
+        p0, p1 = int(z["rec_first"]) * 128, min(int(z["rec_last"]) * 128, expect.size)
+        own_bits = np.unpackbits(z["own"].view(np.uint8), bitorder="little")
+        assert np.array_equal(own_bits[: p1 - p0], expect[p0: p1]), r                         # the range holds the union of all shards
+        assert int(z["before"]) == int(expect[: p0].sum()) and int(z["total"]) == b.bases, r   # set bits before the range / of all ranges
+        assert z["super_boff"].size == 1 and int(z["super_boff"][0]) == 0
+        if r > 0 and p1 > p0:
+            halo_bits = np.unpackbits(z["halo"].view(np.uint8), bitorder="little")
+            assert np.array_equal(halo_bits, expect[p0 - 8192: p0]), r                          # the chunk of 64 records before the range
+        nonempty += (p1 > p0)
+    assert nonempty >= 2                                                                        # the input is large enough for two real ranges
+
+
+def test_super_owners_and_equal_bounds(bwtm):
+    """Pure host arithmetic: equal output ranges (what a reduce-scatter wants) and the owner of every super block of the output."""
+    from bwt_merge_amd.dist import super_owners
+    for nrecs, world in ((1, 2), (511, 3), (513, 2), (1 << 20, 8), (789012345, 8), (5 * (1 << 18) + 7, 4)):
+        bounds = [bwtm.slice_bounds_equal(nrecs, world, g) for g in range(world)]
+        assert bounds[0][0] == 0 and bounds[-1][1] == nrecs
+        assert all(bounds[g][1] == bounds[g + 1][0] for g in range(world - 1))
+        assert all(b[0] == b[1] or (b[0] % 512 == 0 and (b[1] % 512 == 0 or b[1] == nrecs)) for b in bounds)
+        assert len({b[2] for b in bounds}) == 1 and world * bounds[0][2] >= -(-nrecs // 64) * 1024    # equal shares cover the bitvector
+        sizes = [b[1] - b[0] for b in bounds]
+        full = bounds[0][2] // 16                                           # records per full range
+        last_nonempty = max(g for g in range(world) if sizes[g] > 0)
+        assert all(sizes[g] == full for g in range(last_nonempty)) and 0 < sizes[last_nonempty] <= full
+        n_out = (nrecs - 1) << 7
+        nsup = (n_out >> 25) + 1
+        owner = super_owners(nsup, [(b[0], b[1]) for b in bounds])
+        for s in range(nsup):
+            q = s << 18
+            assert bounds[owner[s]][0] <= q < bounds[owner[s]][1], (nrecs, world, s)
+
+
+# ---------------------------------------------------------------------------------------------------------
 # The encoder's carries across output slices (bwt-merge_amd/dist.py: exchange_encoder_carries), with a plain CPU
 # statement of what a slice computes: its run heads, the bytes Run::write emits for the runs that END in it.
 

@@ -170,3 +170,36 @@ def test_plain_runs_are_formed_before_mapping(tools, oracle, tmp_path):
     _, flags, sequences, bases, data = native_parts(tmp_path / "m2.native")
     assert (flags & 0xFF, sequences, bases) == (1, 4, 8)
     assert data.tobytes() == bytes(c + 6 * (n - 1) for c, n in [(1, 2), (0, 2), (2, 1), (0, 1), (0, 1), (5, 1)])
+
+
+@pytest.mark.parametrize("which", ["runs", "reads"])
+def test_native_file_through_the_independent_reader(tools, oracle, sample, tmp_path, which):
+    """a22: the native file the facade writes, parsed by a second implementation of the SDSL framing (tests/sdsl_native_reader.py:
+    written from the published container layouts, not from the C++ writer).  Every container is walked by its own size fields, the
+    select supports are checked against the bit vectors they index, the file must end where the alphabet ends, and everything the
+    path computes -- header, data, per-block counts, block boundaries, C -- equals the oracle's.  `reads`: 9000 reads = 2.6 superblocks
+    of 4096 blocks in the select support of block_boundaries."""
+    import sdsl_native_reader as reader
+    sym = sample if which == "runs" else oracle.FMI.from_text(oracle.generate_reads(77, 9000, 100)).symbols
+    f = oracle.FMI.from_symbols(sym)
+    plain, native = tmp_path / "in.plain", tmp_path / "out.native"
+    np.frombuffer(DEFAULT, dtype=np.uint8)[sym].tofile(plain)
+    convert(tools, plain, native, "plain_default", "native")
+    got = reader.parse_native(native)
+    assert (got["flags"] & 0xFF, got["sequences"], got["bases"]) == (0, f.sequences, f.bases)
+    assert np.array_equal(got["data"], f.data)
+    be, cum = f.samples                                                    # block_end [blocks], cum [6][blocks + 1]
+    assert np.array_equal(got["block_end"], be) and got["boundaries_size"] == f.bases
+    assert np.array_equal(got["counts"], np.diff(cum, axis=1))
+    assert np.array_equal(got["C"], f.C) and got["sigma"] == 6
+    assert bytes(got["comp2char"].astype(np.uint8)) == DEFAULT
+    c2c = got["char2comp"]
+    assert c2c.size == 256 and all(c2c[ch] == k for k, ch in enumerate(DEFAULT))
+    for s1, s0 in got["select_supports"]:
+        assert s1["arguments"] == f.blocks                                   # every vector has one 1-bit per block
+    if which == "reads":
+        assert got["select_supports"][-1][0]["superblocks"] == 3
+    # and back: the file the reader accepted loads into the facade again (native -> plain == the input)
+    back = tmp_path / "back.plain"
+    convert(tools, native, back, "native", "plain_default")
+    assert back.read_bytes() == plain.read_bytes()

@@ -68,6 +68,72 @@ def test_sliced_merge_of_read_sets(gpu, oracle, parts):
     ra.free()
 
 
+@pytest.mark.parametrize("parts", [1, 2, 3, 5, 8])
+def test_range_finalize_after_a_reduce_scatter(gpu, oracle, parts):
+    """The exchange the merge runs on several GPUs: every part owns an EQUAL range of the output and a bitvector that is complete only
+    inside it (what a reduce-scatter leaves: here a caller-owned copy of the full bitvector with every byte outside the range
+    overwritten).  bwtm_ra_range_counts of every part -> the small exchange (dist.combine_range_counts' arithmetic) ->
+    bwtm_ra_finalize_range -> bwtm_interleave_range; the slices' bytes and samples equal the oracle's merge.  Large enough for
+    several segments per part."""
+    import torch
+    from bwt_merge_amd.dist import fold_offsets, super_owners
+    ta = oracle.generate_reads(9101, 9000, 100); tb = oracle.generate_reads(9102, 7000, 100)
+    a, b = oracle.FMI.from_text(ta), oracle.FMI.from_text(tb)
+    A = gpu.Index.upload(a.data, a.sequences, a.bases); B = gpu.Index.upload(b.data, b.sequences, b.bases)
+    whole = gpu.RankArray(A, B)
+    whole.search(A, B, 0, b.sequences - 1)
+    full_bits = whole.finalize().bits()                                  # n_out bits as 64-bit words
+    whole.free()
+    nrecs = gpu.merged_records(A, B)
+    bounds = [gpu.slice_bounds_equal(nrecs, parts, g) for g in range(parts)]
+    shard_bytes = bounds[0][2]
+    dev = torch.device("cuda", 0)
+    ras, bufs, counts = [], [], []
+    for g, (first, last, _) in enumerate(bounds):
+        words = np.full(parts * shard_bytes // 8, 0xA5A5A5A5A5A5A5A5, dtype=np.uint64)      # garbage outside the own range
+        lo, hi = first * 2, min(last * 2, full_bits.size)
+        words[first * 2: last * 2] = 0
+        words[lo: hi] = full_bits[lo: hi]
+        t = torch.from_numpy(words.view(np.int64)).to(dev)
+        ra = gpu.RankArray(A, B, t.data_ptr(), t.numel() * 8)
+        counts.append(ra.range_counts(first, last))
+        ras.append(ra); bufs.append(t)
+    totals = [c[0] for c in counts]
+    assert sum(totals) == b.bases
+    nsup = counts[0][1].size
+    owner = super_owners(nsup, [(x[0], x[1]) for x in bounds])
+    prefix = np.concatenate([[0], np.cumsum(totals)]).astype(np.uint64)
+    super_boff = prefix[owner] + sum(c[1] for c in counts)
+    slices = []
+    for g, (first, last, _) in enumerate(bounds):
+        halo = next((counts[h][2] for h in range(g - 1, -1, -1) if bounds[h][1] > bounds[h][0]), None)
+        ras[g].finalize_range(first, last, int(prefix[g]), int(prefix[parts]), super_boff, halo)
+        assert ras[g].values == b.bases
+        with pytest.raises(gpu.BwtmError):
+            gpu.interleave(A, B, ras[g])                                  # a ranged array serves its range only
+        if parts > 1:
+            with pytest.raises(gpu.BwtmError):
+                gpu.Slice(A, B, ras[g], *gpu.slice_bounds(nrecs, parts + 1, 0))
+        slices.append(gpu.Slice(A, B, ras[g], first, last))
+    heads = [s.lasthead() for s in slices]
+    tables = [s.size_table(max(heads[:g], default=0)) for g, s in enumerate(slices)]
+    offsets = fold_offsets(tables)
+    for s, off in zip(slices, offsets):
+        s.encode(off)
+    m, _ = oracle.merge(a, b, threads=2)
+    assert np.array_equal(np.concatenate([s.data() for s in slices]), m.data)
+    starts = [s.first_block_start() for s in slices]
+    be, cum = [], []
+    for g, s in enumerate(slices):
+        nxt = next((p for p in starts[g + 1:] if p is not None), a.bases + b.bases)
+        x, y = s.samples(nxt)
+        be.append(x); cum.append(y)
+    obe, ocum = m.samples
+    assert np.array_equal(np.concatenate(be), obe) and np.array_equal(np.concatenate(cum, axis=1), ocum[:, :-1])
+    for x in slices + ras + [A, B]:
+        x.free()
+
+
 @pytest.mark.parametrize("case", ["long_runs", "one_run", "runs_on_cuts", "tiny"])
 def test_slices_across_long_runs(gpu, oracle, case):
     """Runs that cross one or several slice boundaries (slices without any run head, runs that end exactly at a cut,
