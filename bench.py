@@ -214,6 +214,9 @@ def measure(env, args):
         acc += meta[k]["bases"]; merged_bases += acc
     searched_bases = sum(mt["bases"] for mt in meta[1:])
     if rank == 0:
+        free_b, total_b = torch.cuda.mem_get_info()
+        log("device memory before the first step: %.1f GB free of %.1f; torch holds %.1f GB (reserved), the inputs take %.1f GB, the library's pool %.1f GB" %
+            (free_b / 1e9, total_b / 1e9, torch.cuda.memory_reserved() / 1e9, sum(t.numel() for t in dev_in) / 1e9, pkg.pool_stats().get("held_bytes", 0) / 1e9))
         log("inputs ready in %.0f s: %s bases, %s GB native (%.3f bytes/base)" %
             (time.time() - t_gen, " + ".join(str(mt["bases"]) for mt in meta), " + ".join("%.3f" % (mt["nbytes"] / 1e9) for mt in meta),
              sum(mt["nbytes"] for mt in meta) / sum(mt["bases"] for mt in meta)))
@@ -442,9 +445,15 @@ def search_code_hash():
     return h.hexdigest()
 
 
+# Knobs that cannot change what k_frontier_step reads or writes per launch: the epoch length only decides how often the dense emits are
+# turned into tiles (another kernel); a PMC pass may have needed a smaller emit buffer than the run it describes (the profiler's own
+# device memory left too little for the default budget at 2 x 50 Gbase).
+TRAFFIC_NEUTRAL_KNOBS = ("emit_budget", "frontier_epoch")
+
+
 def effective_tune(args):
-    """The knobs this run changed: --tune arguments plus the BWTM_TUNE environment of the library."""
-    knobs = sorted(kv for kv in args.tune)
+    """The knobs this run changed (--tune arguments plus the BWTM_TUNE environment of the library), without the traffic-neutral ones."""
+    knobs = sorted(kv for kv in args.tune if kv.partition("=")[0] not in TRAFFIC_NEUTRAL_KNOBS)
     if os.environ.get("BWTM_TUNE"):
         knobs.append("env:" + os.environ["BWTM_TUNE"])
     return knobs
@@ -470,7 +479,7 @@ def stored_traffic(dom, args, world, nsets, launches_per_search, units_per_searc
                 continue
             if e.get("code_hash") != code:
                 why = "the kernel sources changed since the PMC passes (code hash differs)"
-            elif e.get("tune", []) != effective_tune(args):
+            elif [kv for kv in e.get("tune", []) if kv.partition("=")[0] not in TRAFFIC_NEUTRAL_KNOBS] != effective_tune(args):
                 why = "the PMC passes ran with other knobs (%s)" % (e.get("tune") or "defaults")
             elif abs(e["launches_per_search"] - launches_per_search) >= 0.5:
                 why = "%.1f launches per search, the PMC passes saw %d" % (launches_per_search, e["launches_per_search"])

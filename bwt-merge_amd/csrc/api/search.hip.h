@@ -307,11 +307,12 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   const bool node_phase = (g_tune.range_ratio > 0);
   if(node_phase)
   {
-    // The cap bounds the level tables (7 arrays of min(5 x limit, count) + 1 words; released before the step loop starts).  2^26 and not
-    // 2^24: at 5 x 10^8 sequences the ratio rule allows level 12, whose 4^12 = 1.7 x 10^7 strings over ACGT are joined by about as many
-    // that hold one N (an N is rare per base, but 12 x 4^11 such strings exist and a third of them occur among 5 x 10^8 reads): 3.7 x 10^7
-    // nodes, a level that costs a quarter of the element step it replaces.
-    const u64 limit = std::max<u64>(1, std::min<u64>(count / (u64)g_tune.range_ratio, 1ull << 26));
+    // The cap of 2^24 nodes bounds the level tables (7 arrays of min(5 x limit, count) + 1 words: 4.7 GB, released before the step loop
+    // starts).  It only binds from ~1.3 x 10^8 sequences on, where the ratio rule would admit one more level; measured at 5 x 10^8
+    // sequences with the cap lifted to 2^26 (round 4, profiles/r04_node_cap_at_target.txt): level 12 has 3.7 x 10^7 nodes there -- the
+    // 4^12 strings over ACGT and about as many that hold one N -- and costs 5.7 ms of node kernels and scans for the 6.0 ms of
+    // k_frontier_step it replaces, with 17.5 GB of tables instead of 4.7.  No gain: the cap stays.
+    const u64 limit = std::max<u64>(1, std::min<u64>(count / (u64)g_tune.range_ratio, 1ull << 24));
     TRY(range_phase(a, b, seq_first, count, ra, limit, levels));
     if(levels.N == 0) { return BWTM_OK; }
     TRY(range_alive(levels, node_offsets));
