@@ -90,9 +90,12 @@ def test_range_finalize_after_a_reduce_scatter(gpu, oracle, parts):
     dev = torch.device("cuda", 0)
     ras, bufs, counts = [], [], []
     for g, (first, last, _) in enumerate(bounds):
-        words = np.full(parts * shard_bytes // 8, 0xA5A5A5A5A5A5A5A5, dtype=np.uint64)      # garbage outside the own range
-        lo, hi = first * 2, min(last * 2, full_bits.size)
-        words[first * 2: last * 2] = 0
+        # what a reduce-scatter delivers: this part's equal share [g, g + 1) x shard_bytes of the summed bitvector (zero behind the
+        # last output position, like everybody's contribution there); everything outside the share is garbage
+        sw = shard_bytes // 8
+        words = np.full(parts * sw, 0xA5A5A5A5A5A5A5A5, dtype=np.uint64)
+        words[g * sw: (g + 1) * sw] = 0
+        lo, hi = min(g * sw, full_bits.size), min((g + 1) * sw, full_bits.size)
         words[lo: hi] = full_bits[lo: hi]
         t = torch.from_numpy(words.view(np.int64)).to(dev)
         ra = gpu.RankArray(A, B, t.data_ptr(), t.numel() * 8)
