@@ -74,6 +74,9 @@ def main():
                          "the line as `target`; auto = when this is the default single-GPU config-2 run and the device has the memory for it")
     ap.add_argument("--target-reads", type=int, default=500_000_000, help="reads per set of the target measurement (5e8 x 100 bp = 50.5 Gbase)")
     ap.add_argument("--target-steps", type=int, default=2)
+    ap.add_argument("--keep-pool", action="store_true",
+                    help="do not return the library's pooled memory to the driver after the inputs are built (under rocprofv3 --pmc memory released "
+                         "with hipMemRelease does not come back: at 2 x 50 Gbase the merge then finds 118 GB less than it should)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -198,7 +201,8 @@ def measure(env, args):
         ix.free()
         host_in.append(hb)
     torch.cuda.empty_cache()
-    pkg.trim()
+    if not args.keep_pool:
+        pkg.trim()
     for hb in host_in:
         t = torch.empty(hb.nbytes + 16, dtype=torch.uint8, device=dev)       # 16 readable bytes after the stream (borrowed form)
         t[: hb.nbytes].copy_(torch.from_numpy(hb.array))

@@ -10,7 +10,7 @@ cd /tmp
 i=0
 for set in "${sets[@]}"; do
   i=$((i+1)); rm -rf /tmp/pmcs_$i
-  timeout 1500 rocprofv3 --pmc $set --kernel-include-regex "k_frontier_step" --output-format csv -d /tmp/pmcs_$i -- python3 $R/bench.py --reads $reads --no-cpu-baseline --no-verify --no-host --target off --steps 1 --warmup 1 "$@" > /tmp/pmcs_$i.json 2> /tmp/pmcs_$i.log
+  timeout 1500 rocprofv3 --pmc $set --kernel-include-regex "k_frontier_step" --output-format csv -d /tmp/pmcs_$i -- python3 $R/bench.py --reads $reads --no-cpu-baseline --no-verify --no-host --target off --keep-pool --steps 1 --warmup 1 "$@" > /tmp/pmcs_$i.json 2> /tmp/pmcs_$i.log
   f=$(find /tmp/pmcs_$i -name "*counter_collection.csv" | head -1)
   n=$(python3 -c "import json,sys; print(int(round(json.loads([l for l in open('/tmp/pmcs_$i.json').read().splitlines() if l.startswith('{\"metric')][-1])['roofline']['launches_per_step'])))" 2>/dev/null)
   if [ -n "$f" ] && [ -n "$n" ]; then python3 $R/tools/pmc_aggregate.py $f --last $n --kernel k_frontier_step >> $out/pmc.txt; else echo "pass $i ($set) failed" >> $out/pmc.txt; tail -5 /tmp/pmcs_$i.log >> $out/pmc.txt; fi
