@@ -9,7 +9,7 @@ LIB = os.path.join(HERE, "libbwtm.so")
 EXPERIMENTAL_LIB = os.path.join(HERE, "libbwtm_experimental.so")   # the same sources with -DBWTM_EXPERIMENTAL (include/bwtm_experimental.h)
 SOURCES = ["bwtm_api.hip"]
 import glob
-DEPS = (["bwtm_api.hip", "bwtm_kernels.hip.h", "bwtm_device.h", "bwtm_view.h", os.path.join("..", "..", "include", "bwtm.h"),
+DEPS = (["bwtm_api.hip", "bwtm_kernels.hip.h", "bwtm_device.h", "bwtm_bitmerge.h", "bwtm_view.h", os.path.join("..", "..", "include", "bwtm.h"),
          os.path.join("..", "..", "include", "bwtm_experimental.h")]
         + [os.path.relpath(f, CSRC) for f in sorted(glob.glob(os.path.join(CSRC, "kernels", "*.hip.h")) + glob.glob(os.path.join(CSRC, "api", "*.hip.h")))])
 

@@ -78,7 +78,7 @@ struct Tuning
   long long l1_cap = 0;           // tests: entries per level-1 region / emit capacity (0 = sized from the input): forces the exact fallbacks
   long long emit_path = 0;        // 0 = partitioned emit (default), 1 = atomicOr on the bitvector (the exact fallback, first version)
   long long round_emits = 1ll << 33;      // upper bound of emits partitioned per round of the walk (bounds the temporary regions)
-  long long emit_budget = 0;              // bytes of dense emits the frontier search keeps before it builds tiles (one epoch); 0 = from the free memory (16 - 64 GB)
+  long long emit_budget = 0;              // bytes of dense emits the frontier search keeps before it builds tiles (one epoch); 0 = half of the free memory, 16 - 64 GB
   long long frontier_epoch = 512;         // upper bound of steps per epoch (tests use small values)
   long long eager_cum_budget = 16ll << 30; // bwtm_index_encode materializes the samples' cumulative counts when they take at most this many bytes
   long long upload_chunk = 256ll << 20;   // bytes per H2D chunk of the pipelined upload (64 MiB: 141.8 ms for 7.64 GB, 256 MiB and 1 GiB: 140.3)

@@ -328,15 +328,15 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   // step): a step emits at most `count` values (the frontier only shrinks), so an epoch of k steps needs room for k * count
   // emits.  At config 2 (5e7 sequences of 101 symbols) one epoch holds the whole search; a 50 Gbase input takes seven.
   const u64 per_seq = b->n / (b->m > 0 ? b->m : 1) + 1;
-  // Budget of the dense emits: a third of the memory that is free now (pool included), between 16 and 64 GB, unless the caller fixed it.
+  // Budget of the dense emits: half of the memory that is free now (pool included), between 16 and 64 GB, unless the caller fixed it.
   // Every epoch ends with a tile build that reads and rewrites the whole bitvector: at 2 x 50 Gbase a fixed 16 GB meant 7 epochs
-  // (43.7 ms of tile builds per merge), while 130 GB were free during the search.
+  // (43.7 ms of tile builds per merge), while 130 GB were free during the search; the buffer is released before the result is allocated.
   u64 emit_budget = (u64)g_tune.emit_budget;
   if(emit_budget == 0)
   {
     emit_budget = 16ull << 30;
     size_t free_b = 0, total_b = 0;
-    if(hipMemGetInfo(&free_b, &total_b) == hipSuccess) { emit_budget = std::min<u64>(std::max<u64>(emit_budget, ((u64)free_b + CTX.cached_bytes) / 3), 64ull << 30); }
+    if(hipMemGetInfo(&free_b, &total_b) == hipSuccess) { emit_budget = std::min<u64>(std::max<u64>(emit_budget, ((u64)free_b + CTX.cached_bytes) / 2), 64ull << 30); }
     else { (void)hipGetLastError(); }
   }
   u64 emit_cap = emit_budget / sizeof(unsigned short);

@@ -30,6 +30,7 @@
 
 #include <hip/hip_runtime.h>
 #include "bwtm_device.h"
+#include "bwtm_bitmerge.h"
 #ifdef BWTM_EXPERIMENTAL
 #include "bwtm_view.h"
 #endif

@@ -261,13 +261,15 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_interleave(IndexView A, Index
 
   u32 a0, a1, a2, b0, b1, b2;
   window32(planes_a, wa0, a_off, a0, a1, a2); window32(planes_b, wb0, b_off, b0, b1, b2);
-  const ExpandMasks eb = expand_masks(m), ea = expand_masks(~m);
+  // the bit merge: displacement planes from one bit-sliced prefix count of the mask word, then pulls stated at the destination
+  // (bwtm_bitmerge.h; the two parallel-suffix expands it replaces were ~230 of the kernel's 500 instructions per word)
+  const MergeMasks mm = merge_masks(m);
 #ifdef BWTM_SLACK_INTERLEAVE
   { u32 slack = m; valu_slack<BWTM_SLACK_INTERLEAVE>(slack); }
 #endif
-  const u32 o0 = expand32(b0, eb) | expand32(a0, ea);
-  const u32 o1 = expand32(b1, eb) | expand32(a1, ea);
-  const u32 o2 = expand32(b2, eb) | expand32(a2, ea);
+  const u32 o0 = bit_merge32(a0, b0, mm);
+  const u32 o1 = bit_merge32(a1, b1, mm);
+  const u32 o2 = bit_merge32(a2, b2, mm);
 
   // symbol counts of this word -> prefixes over the chunk (16-bit fields: a chunk has 8192 positions, and a symbol that fills
   // it completely would need 8192 + ... < 65536)

@@ -2,6 +2,7 @@
 // (compiled with g++; no HIP runtime involved).
 #include <cstring>
 #include "../bwt-merge_amd/csrc/bwtm_device.h"
+#include "../bwt-merge_amd/csrc/bwtm_bitmerge.h"
 #include "../bwt-merge_amd/csrc/bwtm_view.h"       // the experimental search view's record helpers (pure functions)
 using namespace bwtm;
 extern "C"
@@ -54,6 +55,12 @@ u32 shim_view_symbol(const u32* v, u32 j) { u32 below, below_n, at; view_excepti
 u32 shim_view_count(const u32* v, u32 c, u32 j) { u32 below, below_n, at; view_exceptions(v[14], v[15], j, below, below_n, at); return view_count(v, c, j, below, below_n); }
 u32 shim_view_header(const u32* v, u32 c) { return view_header(v, c); }
 int shim_view_overflow(const u32* v) { return view_overflow(v) ? 1 : 0; }
+// the bit merge k_interleave uses since round 4 (bwtm_bitmerge.h): one 32-bit mask word, three planes
+void shim_bit_merge32(u32 mask, const u32* a, const u32* b, u32* o)
+{
+  const MergeMasks e = merge_masks(mask);
+  for(int p = 0; p < 3; p++) { o[p] = bit_merge32(a[p], b[p], e); }
+}
 void shim_deposit64(u64 mask, const u64* a, const u64* b, u64* o) { deposit64(mask, a[0], a[1], a[2], b[0], b[1], b[2], o[0], o[1], o[2]); }
 u64 shim_run_decode(const u8* data, u64 pos, u32* sym, u64* len) { run_decode(data, pos, *sym, *len); return pos; }
 }

@@ -30,6 +30,7 @@ def shim():
     L.shim_range_mask128.argtypes = [u32, u32, C.c_void_p, C.c_void_p]
     L.shim_encode_runs.restype = u64; L.shim_encode_runs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, u64, C.c_void_p]
     L.shim_deposit64.argtypes = [u64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.shim_bit_merge32.argtypes = [u32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.shim_run_decode.restype = u64; L.shim_run_decode.argtypes = [C.c_void_p, u64, C.c_void_p, C.c_void_p]
     L.shim_view_build.restype = C.c_int; L.shim_view_build.argtypes = [C.c_void_p, u32, C.c_void_p, C.c_void_p]
     L.shim_view_symbol.restype = u32; L.shim_view_symbol.argtypes = [C.c_void_p, u32]
@@ -164,6 +165,31 @@ def test_deposit64_is_the_bitwise_interleave(shim):
         for plane in range(3):
             av, bv, expect = int(a[plane]), int(b[plane]), 0
             for t in range(64):
+                if (mask >> t) & 1:
+                    expect |= (bv & 1) << t; bv >>= 1
+                else:
+                    expect |= (av & 1) << t; av >>= 1
+            assert int(o[plane]) == expect, (hex(mask), plane)
+
+
+def test_bit_merge32_is_the_bitwise_interleave(shim):
+    """The bit merge of k_interleave (bwtm_bitmerge.h: bit-sliced prefix counts + five pull rounds stated at the destination) against the
+    definition of mergeBWT on 32 output positions, for every shape of mask: empty, full, single bits, runs, sparse, dense, random."""
+    rng = np.random.default_rng(11)
+    masks = [0, 0xFFFFFFFF, 1, 1 << 31, 0xFFFF, 0xFFFF0000, 0xAAAAAAAA, 0x55555555, 0x7FFFFFFF, 0xFFFFFFFE, 0x80000001]
+    masks += [(1 << k) - 1 for k in range(33)] + [((1 << k) - 1) << (32 - k) for k in range(33)] + [1 << k for k in range(32)]
+    masks += [int(x) for x in rng.integers(0, 1 << 32, 3000, dtype=np.uint64)]
+    masks += [int(x) & int(y) & int(z) for x, y, z in rng.integers(0, 1 << 32, (500, 3), dtype=np.uint64)]
+    masks += [(int(x) | int(y) | int(z)) & 0xFFFFFFFF for x, y, z in rng.integers(0, 1 << 32, (500, 3), dtype=np.uint64)]
+    for mask in masks:
+        mask &= 0xFFFFFFFF
+        a = rng.integers(0, 1 << 32, 3, dtype=np.uint64).astype(np.uint32)
+        b = rng.integers(0, 1 << 32, 3, dtype=np.uint64).astype(np.uint32)
+        o = np.zeros(3, dtype=np.uint32)
+        shim.shim_bit_merge32(mask, a.ctypes.data, b.ctypes.data, o.ctypes.data)
+        for plane in range(3):
+            av, bv, expect = int(a[plane]), int(b[plane]), 0
+            for t in range(32):
                 if (mask >> t) & 1:
                     expect |= (bv & 1) << t; bv >>= 1
                 else:
