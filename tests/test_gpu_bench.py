@@ -34,6 +34,34 @@ def test_bench_single_gpu_small(bwtm):
     assert h["value"] > 0 and h["pcie"]["h2d_GBs"] > 1 and h["bytes"]["d2h_data"] == d["config"]["native_bytes"][2]
 
 
+def test_bench_target_record_and_traffic_check(bwtm):
+    """The `target` record of the default line (the north star's size in the driver's run), exercised at a small size: the second
+    measurement runs after the first has released everything, carries its own verification, roofline and host-to-host leg and the ratio to
+    the CPU baseline; and the stored PMC traffic is refused for a configuration it was not collected for, with the reason in the line."""
+    d = run_bench([sys.executable, "bench.py", "--reads", "3000000", "--steps", "2", "--warmup", "1", "--cpu-sample-reads", "20000", "--no-config1",
+                   "--target", "on", "--target-reads", "4500000", "--target-steps", "1"])
+    t = d["target"]
+    assert d["verified"] is True and t["verified"] is True and t["fits_in_driver_run"] is True
+    assert t["config"]["reads_per_set"] == 4500000 and d["config"]["reads_per_set"] == 3000000
+    assert t["value"] > 0 and t["host_to_host"]["value"] > 0 and t["host_to_host"]["compact_samples"]["value"] > 0
+    assert t["vs_cpu_baseline"]["resident"] > 30 and t["vs_cpu_baseline"]["cpu_cores"] == d["cpu_baseline"]["cores"]
+    assert d["cpu_baseline"]["thread_sweep"]["best_threads"] == d["cpu_baseline"]["cores"] and len(d["cpu_baseline"]["thread_sweep"]["runs"]) >= 1
+    for r in (d["roofline"], t["roofline"]):
+        assert r["traffic"] is None and "no PMC passes for" in r["traffic_profile_check"] and "design floor" in r["frac_basis"] and 0 < r["frac"] <= 1
+
+
+def test_stored_traffic_entries_describe_this_code(bwtm):
+    """CPU-side check run with the GPU suite: every entry of profiles/search_kernel_traffic.json carries the hash of the kernel sources in
+    this tree (a kernel edit without new PMC passes makes bench.py fall back and say so; this test makes the staleness visible earlier)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    stored = json.load(open(os.path.join(ROOT, "profiles", "search_kernel_traffic.json")))
+    assert {e["config"]["reads_per_set"] for e in stored["entries"]} >= {50_000_000, 500_000_000}
+    for e in stored["entries"]:
+        assert e["code_hash"] == bench.search_code_hash(), "PMC passes for %s predate the last edit of the search kernels" % e["config"]
+        assert e["hbm_bytes_per_launch"] > 0 and e["launches_per_search"] > 0 and e["lf_steps_per_search"] > 0
+
+
 def test_bench_mixed_read_lengths(bwtm):
     """BASELINE config 5's read mix (100 / 150 bp, half of the bases each) through ragged leaves."""
     d = run_bench([sys.executable, "bench.py", "--workload", "mixed", "--reads", "150000", "--steps", "1", "--warmup", "1", "--cpu-sample-reads", "10000",
