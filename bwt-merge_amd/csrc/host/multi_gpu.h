@@ -67,7 +67,7 @@ private:
 };
 
 #ifdef BWTM_WITH_RCCL
-// Per-device hipMalloc blocks that survive a merge (slot 0 / 1: staging of the two inputs, slot 2: the rank-array bitvector).
+// Per-device hipMalloc blocks that survive a merge (slot 0: staging of an input's native bytes, slot 2: the rank-array bitvector).
 class DeviceBuffers
 {
 public:
@@ -245,7 +245,7 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
       // peers (all-gather over xGMI, or device-to-device copies between contexts of one GPU); every GPU then decodes and
       // transcodes its complete device copy (BWT::load, ~9 ms per 5 Gbase input).
       A = uploadSharded(adata, a.sequences(), a.size(), ca.data(), g, staging_a, 0, (distinct ? comms[g] : nullptr));
-      B = uploadSharded(bdata, b.sequences(), b.size(), cb.data(), g, staging_b, 1, (distinct ? comms[g] : nullptr));
+      B = uploadSharded(bdata, b.sequences(), b.size(), cb.data(), g, staging_b, 0, (distinct ? comms[g] : nullptr));      // the inputs are staged one after the other: one cached block serves both
     }
     else
 #endif
