@@ -257,11 +257,34 @@ __global__ void __launch_bounds__(WAVE) k_fold_seg(const u32* table, u64 nseg, c
 // cum[c * stride + b] = occurrences of c before the start of block b (samples[c] of BWT::build, bwt.cpp:489-511), stored by the lane
 // that opens block b: the record of that position has just been read by this wave, so the rank query is served by the caches
 // (the separate pass over all block starts, k_block_cum, read the records a second time: 2.0 - 2.4 ms at config 2).
+// Register-light: the record is taken one 16-byte chunk at a time and the counts are stored symbol by symbol (index_ranks keeps the 16 words
+// and six 64-bit results alive at once, which made this call the kernel's register peak: 116 VGPRs = 4 waves per SIMD for a loop that
+// waits on its own dependency chain a third of the time).
 __device__ inline void store_block_cum(const IndexView& X, u64 block, u64 p, u64* cum, u64 stride)
 {
-  u64 r[6]; index_ranks(X, p, r);
-  cum[0 * stride + block] = p - (r[1] + r[2] + r[3] + r[4] + r[5]);
-  cum[1 * stride + block] = r[1]; cum[2 * stride + block] = r[2]; cum[3 * stride + block] = r[3]; cum[4 * stride + block] = r[4]; cum[5 * stride + block] = r[5];
+  const uint4* rec = X.recs + 4 * (p >> REC_SHIFT);
+  const u32 j = (u32)(p & (REC_POS - 1));
+  u32 n1 = 0, n2 = 0, n3 = 0, n4 = 0, n5 = 0, h[4];
+#pragma unroll
+  for(u32 k = 0; k < 4; k++)
+  {
+    const uint4 ch = rec[k];
+    const u32 mask = below_mask(j, k);
+    n1 += (u32)__builtin_popcount(plane_match(ch.x, ch.y, ch.z, 1) & mask); n2 += (u32)__builtin_popcount(plane_match(ch.x, ch.y, ch.z, 2) & mask);
+    n3 += (u32)__builtin_popcount(plane_match(ch.x, ch.y, ch.z, 3) & mask); n4 += (u32)__builtin_popcount(plane_match(ch.x, ch.y, ch.z, 4) & mask);
+    n5 += (u32)__builtin_popcount(plane_match(ch.x, ch.y, ch.z, 5) & mask);
+    h[k] = ch.w;
+  }
+  // the five 25-bit fields of the 128-bit header (rec_header, bwtm_device.h) at their fixed offsets 0, 25, 50, 75, 100
+  const u64 lo = (u64)h[0] | ((u64)h[1] << 32), hi = (u64)h[2] | ((u64)h[3] << 32);
+  const u64* sup = X.sup + (p >> SUPER_SHIFT) * SUP_STRIDE;
+  const u64 r1 = sup[1] + ((u32)lo & FIELD_MASK) + n1;
+  const u64 r2 = sup[2] + ((u32)(lo >> 25) & FIELD_MASK) + n2;
+  const u64 r3 = sup[3] + ((u32)((lo >> 50) | (hi << 14)) & FIELD_MASK) + n3;
+  const u64 r4 = sup[4] + ((u32)(hi >> 11) & FIELD_MASK) + n4;
+  const u64 r5 = sup[5] + ((u32)(hi >> 36) & FIELD_MASK) + n5;
+  cum[1 * stride + block] = r1; cum[2 * stride + block] = r2; cum[3 * stride + block] = r3; cum[4 * stride + block] = r4; cum[5 * stride + block] = r5;
+  cum[0 * stride + block] = p - (r1 + r2 + r3 + r4 + r5);
 }
 
 // The launch covers the segments [seg_first, seg_end): the pipelined download copies the bytes of one range to the
