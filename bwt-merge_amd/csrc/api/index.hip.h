@@ -24,7 +24,8 @@ struct bwtm_index
   const u8* native_bytes() const { return borrowed ? (const u8*)borrowed : data.as<const u8>(); }
   DevBuf block_start;                 // nblocks + 1 u64
   DevBuf gcum; u64 ngroups = 0;       // 6 x (ngroups + 1) u64: cumulative symbol counts at the starts of the 62-block groups
-  DevBuf cum;                         // 6 x (nblocks + 1) u64: cumulative symbol counts at block starts (built on demand)
+  DevBuf cum32;                       // 5 x (nblocks + 1) u32: cumulative counts of 1..5 at the block starts, relative to the super block of the
+                                      // start (kernels/encoder.hip.h); written by the encoder when it fits the budget, else answered by the records
   DevBuf flags;                       // k_block_len's verdict on the stream (read by upload_validate)
 #ifdef BWTM_EXPERIMENTAL
   mutable DevBuf sview, vsup;         // the search view (built on demand by the frontier search, dropped with the records)
@@ -94,7 +95,7 @@ int upload_prepare(bwtm_index* x)
   x->nblocks = div_up(x->nbytes, RLE_BLOCK);
   x->ngroups = std::max<u64>(1, div_up(x->nblocks, (u64)GROUP));
   const u64 gstride = x->ngroups + 1;
-  x->cum.release();
+  x->cum32.release();
   TRY(x->block_start.alloc((x->nblocks + 1) * sizeof(u64)));
   TRY(x->gcum.alloc(6 * gstride * sizeof(u64)));
   TRY(x->flags.alloc(sizeof(u32), true));
@@ -233,14 +234,17 @@ int upload_blocking(bwtm_index* x, const u8* host_src, u64 sequences, u64 bases,
   return BWTM_OK;
 }
 
-// samples[c] at the block starts (bwt.cpp:489-511), from block_start and the rank structure.
+// Bytes of the compact samples (cum32) of an index of `blocks` blocks: what the eager_cum_budget knob is compared with.
+u64 cum32_bytes(u64 blocks) { return 5 * (blocks + 1) * sizeof(u32); }
+
+// samples[c] at the block starts (bwt.cpp:489-511) in the compact form, from block_start and the rank structure.
 int ensure_block_cum(bwtm_index* x)
 {
-  if(x->cum.p) { return BWTM_OK; }
+  if(x->cum32.p) { return BWTM_OK; }
   const u64 stride = x->nblocks + 1;
-  TRY(x->cum.alloc(6 * stride * sizeof(u64)));
-  LAUNCH("block_cum", k_block_cum, div_up(stride, BLOCK_THREADS), BLOCK_THREADS,
-    x->view(), x->block_start.as<const u64>(), (u64)0, stride, x->cum.as<u64>(), stride);
+  TRY(x->cum32.alloc(cum32_bytes(x->nblocks)));
+  LAUNCH("block_cum", k_block_cum32, div_up(stride, BLOCK_THREADS), BLOCK_THREADS,
+    x->recs.as<const uint4>(), x->block_start.as<const u64>(), (u64)0, stride, x->cum32.as<u32>(), stride);
   return BWTM_OK;
 }
 
@@ -314,9 +318,9 @@ int encode_emit(bwtm_index* x, EncodePlan& plan, u8* host_out, bool with_cum = f
   x->nbytes = total;
   x->nblocks = div_up(total, RLE_BLOCK);
   TRY(alloc_native(x->data, total));
-  x->gcum.release(); x->ngroups = 0; x->cum.release();
+  x->gcum.release(); x->ngroups = 0; x->cum32.release();
   const u64 cum_stride = x->nblocks + 1;
-  if(with_cum) { TRY(x->cum.alloc(6 * cum_stride * sizeof(u64))); }
+  if(with_cum) { TRY(x->cum32.alloc(cum32_bytes(x->nblocks))); }
   // k_enc_emit records the position at which every 64-byte block starts; the entry after the last block is n
   TRY(x->block_start.alloc((x->nblocks + 1) * sizeof(u64)));
   CTX.host_scratch[63] = x->n;
@@ -335,12 +339,12 @@ int encode_emit(bwtm_index* x, EncodePlan& plan, u8* host_out, bool with_cum = f
       if(with_cum)
       {
         LAUNCH("enc_emit", k_enc_emit<true>, div_up((s1 - s0) * WAVE, BLOCK_THREADS), BLOCK_THREADS, x->recs.as<const uint4>(), x->nrecs, x->n, plan.ntiles, s0, s1,
-          plan.lasthead.as<const u64>(), (u64)0, plan.seg_base.as<const u64>(), x->data.as<u8>(), x->block_start.as<u64>(), x->view(), x->cum.as<u64>(), cum_stride);
+          plan.lasthead.as<const u64>(), (u64)0, plan.seg_base.as<const u64>(), x->data.as<u8>(), x->block_start.as<u64>(), x->cum32.as<u32>(), cum_stride);
       }
       else
       {
         LAUNCH("enc_emit", k_enc_emit<false>, div_up((s1 - s0) * WAVE, BLOCK_THREADS), BLOCK_THREADS, x->recs.as<const uint4>(), x->nrecs, x->n, plan.ntiles, s0, s1,
-          plan.lasthead.as<const u64>(), (u64)0, plan.seg_base.as<const u64>(), x->data.as<u8>(), x->block_start.as<u64>(), x->view(), (u64*)nullptr, (u64)0);
+          plan.lasthead.as<const u64>(), (u64)0, plan.seg_base.as<const u64>(), x->data.as<u8>(), x->block_start.as<u64>(), (u32*)nullptr, (u64)0);
       }
       return BWTM_OK;
     };
@@ -361,7 +365,7 @@ int encode_emit(bwtm_index* x, EncodePlan& plan, u8* host_out, bool with_cum = f
     // the entry behind the last block: the counts at n (every block's own entry was stored by the lane that opened it)
     auto last = [&]() -> int
     {
-      LAUNCH("block_cum", k_block_cum, 1, BLOCK_THREADS, x->view(), x->block_start.as<const u64>(), x->nblocks, (u64)1, x->cum.as<u64>() + x->nblocks, cum_stride);
+      LAUNCH("block_cum", k_block_cum32, 1, BLOCK_THREADS, x->recs.as<const uint4>(), x->block_start.as<const u64>(), x->nblocks, (u64)1, x->cum32.as<u32>(), cum_stride);
       return BWTM_OK;
     };
     rc = last();
@@ -378,21 +382,21 @@ int encode_blocking(bwtm_index* x)
   {
     EncodePlan plan;
     TRY(encode_size(x, plan));
-    // BWT::build, bwt.cpp:476-512: the samples of the new stream.  block_start is always there; the six cumulative count arrays are
-    // answered by the rank structure and materialized -- by the emit pass itself -- only when they are small enough to sit next to
-    // everything else (a 2 x 50 Gbase result has 57 GB of them: produced in chunks when downloaded).
+    // BWT::build, bwt.cpp:476-512: the samples of the new stream.  block_start is always there; the cumulative counts are answered by
+    // the rank structure and materialized -- by the emit pass itself, in the compact form cum32 -- only when they are small enough to sit
+    // next to everything else (a 2 x 50 Gbase result has 24 GB of them: produced in chunks when downloaded).
     const u64 blocks = div_up(plan.total, RLE_BLOCK);
-    TRY(encode_emit(x, plan, nullptr, 6 * (blocks + 1) * sizeof(u64) <= (u64)g_tune.eager_cum_budget));
+    TRY(encode_emit(x, plan, nullptr, cum32_bytes(blocks) <= (u64)g_tune.eager_cum_budget));
     return BWTM_OK;
   }
   else
   {
     TRY(alloc_native(x->data, 0));
     TRY(x->block_start.alloc(sizeof(u64), true));
-    x->gcum.release(); x->ngroups = 0; x->cum.release();
+    x->gcum.release(); x->ngroups = 0; x->cum32.release();
     x->has_native = true;
   }
-  if(6 * (x->nblocks + 1) * sizeof(u64) <= (u64)g_tune.eager_cum_budget) { TRY(ensure_block_cum(x)); }      // the empty index: one entry
+  if(cum32_bytes(x->nblocks) <= (u64)g_tune.eager_cum_budget) { TRY(ensure_block_cum(x)); }      // the empty index: one entry
   return BWTM_OK;
 }
 
@@ -401,10 +405,6 @@ int encode_blocking(bwtm_index* x)
 int download_samples(bwtm_index* x, u64* block_end, u64* cum)
 {
   const u64 stride = x->nblocks + 1;
-  if(x->cum.p)
-  {
-    HIP_TRY(hipMemcpyAsync(cum, x->cum.p, 6 * stride * sizeof(u64), hipMemcpyDeviceToHost, CTX.stream));
-  }
   const u64 CH = 1ull << 22;                                  // blocks per chunk: 7 x 32 MiB of staging per buffer
   DevBuf stage[2];
   hipEvent_t filled[2] = {nullptr, nullptr}, drained[2] = {nullptr, nullptr};
@@ -426,19 +426,18 @@ int download_samples(bwtm_index* x, u64* block_end, u64* cum)
       u64* st = stage[k].as<u64>();
       if(round >= 2) { HIP_TRY(hipStreamWaitEvent(CTX.stream, drained[k], 0)); }
       if(nbe > 0) { LAUNCH("block_end", k_block_end, div_up(nbe, BLOCK_THREADS), BLOCK_THREADS, x->block_start.as<const u64>(), b0, nbe, st); }
-      if(!x->cum.p)
+      if(x->cum32.p)                                                     // the compact form written by the encoder, expanded chunk by chunk
       {
-        LAUNCH("block_cum", k_block_cum, div_up(cnt, BLOCK_THREADS), BLOCK_THREADS, x->view(), x->block_start.as<const u64>(), b0, cnt, st + CH, CH);
+        LAUNCH("cum_expand", k_cum_expand, div_up(cnt, BLOCK_THREADS), BLOCK_THREADS, x->sup.as<const u64>(), x->block_start.as<const u64>(), x->cum32.as<const u32>(), stride,
+          b0, cnt, st + CH, CH);
       }
+      else { LAUNCH("block_cum", k_block_cum, div_up(cnt, BLOCK_THREADS), BLOCK_THREADS, x->view(), x->block_start.as<const u64>(), b0, cnt, st + CH, CH); }
       HIP_TRY(hipEventRecord(filled[k], CTX.stream));
       HIP_TRY(hipStreamWaitEvent(CTX.copy_stream, filled[k], 0));
       if(nbe > 0) { HIP_TRY(hipMemcpyAsync(block_end + b0, st, nbe * sizeof(u64), hipMemcpyDeviceToHost, CTX.copy_stream)); }
-      if(!x->cum.p)
+      for(u64 c = 0; c < 6; c++)
       {
-        for(u64 c = 0; c < 6; c++)
-        {
-          HIP_TRY(hipMemcpyAsync(cum + c * stride + b0, st + CH + c * CH, cnt * sizeof(u64), hipMemcpyDeviceToHost, CTX.copy_stream));
-        }
+        HIP_TRY(hipMemcpyAsync(cum + c * stride + b0, st + CH + c * CH, cnt * sizeof(u64), hipMemcpyDeviceToHost, CTX.copy_stream));
       }
       HIP_TRY(hipEventRecord(drained[k], CTX.copy_stream));
     }
@@ -625,7 +624,7 @@ extern "C" int bwtm_index_drop_native(bwtm_index* x)
   if(!x) { return fail(BWTM_EINVAL, "null index"); }
   ENTER(x->ctx);
   if(x->borrowed) { HIP_TRY(hipStreamSynchronize(CTX.stream)); x->borrowed = nullptr; }
-  x->data.release(); x->cum.release(); x->gcum.release(); x->block_start.release();
+  x->data.release(); x->cum32.release(); x->gcum.release(); x->block_start.release();
   x->has_native = false; x->nbytes = 0; x->nblocks = 0;
   return BWTM_OK;
 }

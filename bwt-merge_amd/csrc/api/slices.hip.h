@@ -307,7 +307,7 @@ extern "C" int bwtm_slice_encode(bwtm_slice* s, uint64_t byte_offset)
     TRY(s->block_start.alloc((s->nblocks + 1) * sizeof(u64), true));
     LAUNCH("enc_emit", k_enc_emit<false>, div_up(nseg * WAVE, BLOCK_THREADS), BLOCK_THREADS, s->recs_virtual(), s->nrecs_total, s->n, ntiles, s->seg_first, s->seg_end,
       s->lasthead.as<const u64>() - s->seg_first, s->head_carry, s->seg_base.as<const u64>() - s->seg_first, s->data.as<u8>() - base,
-      s->block_start.as<u64>() - s->block_first, s->view(), (u64*)nullptr, (u64)0);
+      s->block_start.as<u64>() - s->block_first, (u32*)nullptr, (u64)0);
   }
   else
   {

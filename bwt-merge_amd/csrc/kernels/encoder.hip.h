@@ -254,44 +254,92 @@ __global__ void __launch_bounds__(WAVE) k_fold_seg(const u32* table, u64 nseg, c
   for(u64 s = s0; s < s1; s++) { seg_base[s] = off; off += table[s * 64 + (off & 63)]; }
 }
 
-// cum[c * stride + b] = occurrences of c before the start of block b (samples[c] of BWT::build, bwt.cpp:489-511), stored by the lane
-// that opens block b: the record of that position has just been read by this wave, so the rank query is served by the caches
-// (the separate pass over all block starts, k_block_cum, read the records a second time: 2.0 - 2.4 ms at config 2).
-// Register-light: the record is taken one 16-byte chunk at a time and the counts are stored symbol by symbol (index_ranks keeps the 16 words
-// and six 64-bit results alive at once, which made this call the kernel's register peak: 116 VGPRs = 4 waves per SIMD for a loop that
-// waits on its own dependency chain a third of the time).
-__device__ inline void store_block_cum(const IndexView& X, u64 block, u64 p, u64* cum, u64 stride)
+// Samples of the result (BWT::build, bwt.cpp:489-511) in the device's compact form: cum32[(c - 1) * stride + b] = occurrences of c (1..5)
+// before the start p of block b MINUS the super table's entry of p's super block, i.e. exactly what a record stores for a position
+// (header field + popcount): 20 bytes per block instead of the 48 of the six u64 arrays, no super-table access when it is produced, and
+// samples[c].sum(b) = sup[8 (p >> 25) + c] + cum32[c - 1][b]  (c = 0: p minus the five).  k_cum_expand turns it into the u64 arrays on request.
+//
+// k_enc_emit produces the values from what its wave holds already (round 5; rounds 1 - 4 ran one rank query per block start, which
+// re-fetched the record and the super row: 1.53 x the kernel's algorithmic read traffic, PMC in profiles/r04_pmc_per_kernel.txt).  Every block
+// start p lies in a run that ENDS at a head h of the lane's own tile, so
+//   rank_c(p) = rank_c(tile start) + #c in [tile start, h) - (c == symbol of the run ? h - p : 0)
+// and rank_c(tile start) = (header of the segment's first record: ONE 64-byte read per 65 536 positions) + the symbol counts of the
+// tiles before it (a running total over the chunks + a wave scan of the tiles' five popcounts, packed two to a register).
+
+// Occurrences of the symbols 1..5 among the positions of a tile selected by the mask m.
+__device__ inline void tile_counts(u64 p0, u64 p1, u64 p2, u64 m, u32& n1, u32& n2, u32& n3, u32& n4, u32& n5)
 {
-  const uint4* rec = X.recs + 4 * (p >> REC_SHIFT);
+  const u64 only0 = p0 & ~p1 & m, only1 = ~p0 & p1 & m, both = p0 & p1 & m, none = ~(p0 | p1) & m;
+  n1 = (u32)__builtin_popcountll(only0 & ~p2); n2 = (u32)__builtin_popcountll(only1 & ~p2); n3 = (u32)__builtin_popcountll(both & ~p2);
+  n4 = (u32)__builtin_popcountll(none & p2);   n5 = (u32)__builtin_popcountll(only0 & p2);
+}
+
+// The five 25-bit fields of a record header (rec_header, bwtm_device.h) from its four words.
+__device__ inline void header_fields(u32 h0, u32 h1, u32 h2, u32 h3, u32 f[6])
+{
+  const u64 lo = (u64)h0 | ((u64)h1 << 32), hi = (u64)h2 | ((u64)h3 << 32);
+  f[0] = 0;
+  f[1] = (u32)lo & FIELD_MASK; f[2] = (u32)(lo >> 25) & FIELD_MASK; f[3] = (u32)((lo >> 50) | (hi << 14)) & FIELD_MASK;
+  f[4] = (u32)(hi >> 11) & FIELD_MASK; f[5] = (u32)(hi >> 36) & FIELD_MASK;
+}
+
+// The general form: one rank query on the records (the entry behind the last block; block starts whose run began in an earlier super
+// block than the segment that encodes it; indexes whose samples are asked for without having been encoded here).
+__device__ inline void block_cum32_query(const uint4* recs, u64 p, u32 r[6])
+{
+  const uint4* rec = recs + 4 * (p >> REC_SHIFT);
   const u32 j = (u32)(p & (REC_POS - 1));
-  u32 n1 = 0, n2 = 0, n3 = 0, n4 = 0, n5 = 0, h[4];
+  u32 n[6] = {0, 0, 0, 0, 0, 0}, h[4];
 #pragma unroll
   for(u32 k = 0; k < 4; k++)
   {
     const uint4 ch = rec[k];
     const u32 mask = below_mask(j, k);
-    n1 += (u32)__builtin_popcount(plane_match(ch.x, ch.y, ch.z, 1) & mask); n2 += (u32)__builtin_popcount(plane_match(ch.x, ch.y, ch.z, 2) & mask);
-    n3 += (u32)__builtin_popcount(plane_match(ch.x, ch.y, ch.z, 3) & mask); n4 += (u32)__builtin_popcount(plane_match(ch.x, ch.y, ch.z, 4) & mask);
-    n5 += (u32)__builtin_popcount(plane_match(ch.x, ch.y, ch.z, 5) & mask);
+#pragma unroll
+    for(u32 c = 1; c < 6; c++) { n[c] += (u32)__builtin_popcount(plane_match(ch.x, ch.y, ch.z, c) & mask); }
     h[k] = ch.w;
   }
-  // the five 25-bit fields of the 128-bit header (rec_header, bwtm_device.h) at their fixed offsets 0, 25, 50, 75, 100
-  const u64 lo = (u64)h[0] | ((u64)h[1] << 32), hi = (u64)h[2] | ((u64)h[3] << 32);
-  const u64* sup = X.sup + (p >> SUPER_SHIFT) * SUP_STRIDE;
-  const u64 r1 = sup[1] + ((u32)lo & FIELD_MASK) + n1;
-  const u64 r2 = sup[2] + ((u32)(lo >> 25) & FIELD_MASK) + n2;
-  const u64 r3 = sup[3] + ((u32)((lo >> 50) | (hi << 14)) & FIELD_MASK) + n3;
-  const u64 r4 = sup[4] + ((u32)(hi >> 11) & FIELD_MASK) + n4;
-  const u64 r5 = sup[5] + ((u32)(hi >> 36) & FIELD_MASK) + n5;
-  cum[1 * stride + block] = r1; cum[2 * stride + block] = r2; cum[3 * stride + block] = r3; cum[4 * stride + block] = r4; cum[5 * stride + block] = r5;
-  cum[0 * stride + block] = p - (r1 + r2 + r3 + r4 + r5);
+  header_fields(h[0], h[1], h[2], h[3], r);
+#pragma unroll
+  for(u32 c = 1; c < 6; c++) { r[c] += n[c]; }
+}
+
+__device__ inline void store_cum32(u32* cum32, u64 stride, u64 block, const u32 r[6])
+{
+  cum32[0 * stride + block] = r[1]; cum32[1 * stride + block] = r[2]; cum32[2 * stride + block] = r[3];
+  cum32[3 * stride + block] = r[4]; cum32[4 * stride + block] = r[5];
+}
+
+// cum32 for the blocks [first, first + count) from block_start and the records (count = 1 at first = nblocks: the entry behind the last block).
+__global__ void __launch_bounds__(BLOCK_THREADS) k_block_cum32(const uint4* recs, const u64* block_start, u64 first, u64 count, u32* cum32, u64 stride)
+{
+  const u64 b = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(b >= count) { return; }
+  u32 r[6]; block_cum32_query(recs, block_start[first + b], r);
+  store_cum32(cum32, stride, first + b, r);
+}
+
+// samples[c] as BWT::build computes them: cum[c * stride + b] = occurrences of c before the start of block first + b, b in [0, count),
+// expanded from the compact form (CumulativeArray::sum(first + b) of samples[c], support.h:338-343).
+__global__ void __launch_bounds__(BLOCK_THREADS) k_cum_expand(const u64* sup, const u64* block_start, const u32* cum32, u64 cstride, u64 first, u64 count,
+  u64* cum, u64 stride)
+{
+  const u64 b = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(b >= count) { return; }
+  const u64 p = block_start[first + b];
+  const u64* s = sup + (p >> SUPER_SHIFT) * SUP_STRIDE;
+  u64 sum = 0;
+#pragma unroll
+  for(u32 c = 1; c < 6; c++) { const u64 r = s[c] + cum32[(u64)(c - 1) * cstride + first + b]; cum[c * stride + b] = r; sum += r; }
+  cum[0 * stride + b] = p - sum;
 }
 
 // The launch covers the segments [seg_first, seg_end): the pipelined download copies the bytes of one range to the
-// host while the next range is written.  CUM: also the samples' cumulative counts at every block start (X = the index being encoded).
+// host while the next range is written.  CUM: also the samples' cumulative counts at every block start, in the compact form cum32 (above);
+// whole-index launches only (`recs` is then the index's own record array).
 template<bool CUM>
 __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 seg_first, u64 seg_end,
-  const u64* prevhead, u64 head_carry, const u64* seg_base, u8* out, u64* block_start, IndexView X, u64* cum, u64 cum_stride)
+  const u64* prevhead, u64 head_carry, const u64* seg_base, u8* out, u64* block_start, u32* cum32, u64 cum_stride)
 {
   __shared__ __attribute__((aligned(16))) u8 stage[BLOCK_THREADS / WAVE][4096 + 32];
   u64 seg = seg_first + (((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6);
@@ -302,6 +350,18 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
   if(head_carry > last) { last = head_carry; }
   u64 off = seg_base[seg];           // wave-uniform byte offset
   u32 seg_head = (u32)(off & 15);    // bytes before the segment's first byte in its 16-byte group: they belong to the segment before
+  // CUM: occurrences of 1..5 before the current chunk, relative to the super block of the segment (a segment is 2^16 positions and starts at
+  // a multiple of that, so it lies inside one super block of 2^25): the header of the segment's first record, then a running total.
+  u32 base1 = 0, base2 = 0, base3 = 0, base4 = 0, base5 = 0;          // wave-uniform (scalar registers)
+  if(CUM)
+  {
+    const uint4* r0 = recs + 4 * (first >> 1);                          // tile T lies in record T >> 1
+    u32 f[6]; header_fields(r0[0].w, r0[1].w, r0[2].w, r0[3].w, f);
+    base1 = (u32)__builtin_amdgcn_readfirstlane((int)f[1]); base2 = (u32)__builtin_amdgcn_readfirstlane((int)f[2]);
+    base3 = (u32)__builtin_amdgcn_readfirstlane((int)f[3]); base4 = (u32)__builtin_amdgcn_readfirstlane((int)f[4]);
+    base5 = (u32)__builtin_amdgcn_readfirstlane((int)f[5]);
+  }
+  const u64 seg_super = (first << 6) >> SUPER_SHIFT;
   for(int k = 0; k < SEG_CHUNKS; k++)
   {
     u64 ft = first + (u64)k * 64;
@@ -354,6 +414,38 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
     u64 ev_incl = (u64)wave_incl_sum32(nev);
     u64 chunk_events = shfl_u64(ev_incl, WAVE - 1);
     bool slow = (__ballot(long_mask != 0) != 0);
+    // CUM: occurrences of 1..5 before this lane's tile = running base + exclusive wave prefix of the tiles' counts (<= 4096 per wave: two per register)
+    u32 ex12 = 0, ex34 = 0, ex5 = 0, tot12 = 0, tot34 = 0, tot5 = 0;
+    if(CUM)
+    {
+      const u64 tb0 = T << 6;
+      const u64 valid = (n >= tb0 + 64 ? ~0ull : (n <= tb0 ? 0ull : ((1ull << (n - tb0)) - 1)));
+      u32 n1, n2, n3, n4, n5; tile_counts(ti.p0, ti.p1, ti.p2, valid, n1, n2, n3, n4, n5);
+      const u32 own12 = n1 | (n2 << 16), own34 = n3 | (n4 << 16);
+      const u32 in12 = wave_incl_sum32(own12), in34 = wave_incl_sum32(own34), in5 = wave_incl_sum32(n5);
+      ex12 = in12 - own12; ex34 = in34 - own34; ex5 = in5 - n5;
+      tot12 = (u32)__builtin_amdgcn_readlane((int)in12, WAVE - 1); tot34 = (u32)__builtin_amdgcn_readlane((int)in34, WAVE - 1);
+      tot5 = (u32)__builtin_amdgcn_readlane((int)in5, WAVE - 1);       // added to the running base at the end of the chunk
+    }
+    // Counts before position tile_start + bit (bit = the in-tile position of a head, 0..63) minus, for the symbol `sym` of the run that ends
+    // there, the part of that run behind position p: the five cum32 values of a block that starts at p (see above).
+    auto store_cum_at = [&](u64 blk, u64 p, u32 bit, u32 sym)
+    {
+      const u64 tb0 = T << 6;
+      u32 r[6];
+      if((p >> SUPER_SHIFT) != seg_super) { block_cum32_query(recs, p, r); }       // the run began in an earlier super block: one rank query
+      else
+      {
+        u32 n1, n2, n3, n4, n5; tile_counts(ti.p0, ti.p1, ti.p2, (bit == 0 ? 0ull : (~0ull >> (64 - bit))), n1, n2, n3, n4, n5);
+        const u32 back = (u32)(tb0 + bit - p);                            // positions of the run between p and the head
+        r[1] = base1 + (ex12 & 0xFFFF) + n1 - (sym == 1 ? back : 0u);
+        r[2] = base2 + (ex12 >> 16) + n2 - (sym == 2 ? back : 0u);
+        r[3] = base3 + (ex34 & 0xFFFF) + n3 - (sym == 3 ? back : 0u);
+        r[4] = base4 + (ex34 >> 16) + n4 - (sym == 4 ? back : 0u);
+        r[5] = base5 + ex5 + n5 - (sym == 5 ? back : 0u);
+      }
+      store_cum32(cum32, cum_stride, blk, r);
+    };
     if(!slow)
     {
       // Every event is a run shorter than 42: one byte each, in position order.  The bytes are
@@ -409,7 +501,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
         {
           const u64 blk = (off - a + opens) >> 6, p = tb + (u64)(long long)open_prev;
           block_start[blk] = p;
-          if(CUM) { store_block_cum(X, blk, p, cum, cum_stride); }
+          // the run that opens the block starts at a head of this tile (nothing of it lies behind p), or it is the run that ends at
+          // the tile's first head and began before the tile (its symbol is the one before the tile)
+          if(CUM) { store_cum_at(blk, p, (open_prev >= 0 ? (u32)open_prev : b0), ti.prev); }
         }
       }
       flush_chunk(lds, a, a + (u32)chunk_events, off - a);
@@ -450,7 +544,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
             idx += (u32)long_run_write_cb(lds, origin + idx, run_sym, len, prev1 - 1, origin, [&](u64 blk, u64 p)
             {
               block_start[blk] = p;
-              if(CUM) { store_block_cum(X, blk, p, cum, cum_stride); }
+              if(CUM) { store_cum_at(blk, p, b, run_sym); }
             });
           }
           else
@@ -458,7 +552,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
             if(((origin + idx) & (RLE_BLOCK - 1)) == 0)
             {
               block_start[(origin + idx) >> 6] = prev1 - 1;
-              if(CUM) { store_block_cum(X, (origin + idx) >> 6, prev1 - 1, cum, cum_stride); }
+              if(CUM) { store_cum_at((origin + idx) >> 6, prev1 - 1, b, run_sym); }
             }
             lds[idx++] = (u8)(run_sym + 6 * (len - 1));
           }
@@ -471,5 +565,6 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
     }
     u64 m = shfl_u64(incl, WAVE - 1);
     if(m > last) { last = m; }
+    if(CUM) { base1 += tot12 & 0xFFFF; base2 += tot12 >> 16; base3 += tot34 & 0xFFFF; base4 += tot34 >> 16; base5 += tot5; }
   }
 }
