@@ -87,6 +87,74 @@ __device__ inline u32 chunk_tiles(const uint4* recs, u64 nrecs, u64 first_tile, 
   return (u32)__shfl((int)last, WAVE - 1, WAVE);
 }
 
+// Maximum over the wave of a small value (DPP row shifts and broadcasts, like wave_incl_sum32); wave-uniform result.
+__device__ inline u32 wave_max32(u32 v)
+{
+#define BWTM_MAX_DPP(ctrl, rows) { const u32 t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xF, false); v = (t > v ? t : v); }
+  BWTM_MAX_DPP(0x111, 0xF) BWTM_MAX_DPP(0x112, 0xF) BWTM_MAX_DPP(0x114, 0xF) BWTM_MAX_DPP(0x118, 0xF) BWTM_MAX_DPP(0x142, 0xA) BWTM_MAX_DPP(0x143, 0xC)
+#undef BWTM_MAX_DPP
+  return (u32)__builtin_amdgcn_readlane((int)v, WAVE - 1);
+}
+
+// Position of the k-th (0-based) set bit of x; k < popcount(x).
+__device__ inline u32 select64(u64 x, u32 k)
+{
+  const u32 lo = (u32)x, clo = (u32)__builtin_popcount(lo);
+  const bool hi = (k >= clo);
+  u32 w = (hi ? (u32)(x >> 32) : lo), base = (hi ? 32u : 0u);
+  k -= (hi ? clo : 0u);
+#pragma unroll
+  for(u32 sft = 16; sft != 0; sft >>= 1)
+  {
+    const u32 low = w & ((1u << sft) - 1u), c = (u32)__builtin_popcount(low);
+    const bool up = (k >= c);
+    w = (up ? w >> sft : low); k -= (up ? c : 0u); base += (up ? sft : 0u);
+  }
+  return base;
+}
+
+// LDS of k_enc_emit: one staging area per wave (4096 + 15 bytes of a chunk at most, 16-byte phase of the destination) and a DUMP region that
+// absorbs the byte stores of the walk's idle trips: (address | ENC_DUMP) lies in [ENC_DUMP, ENC_DUMP + 4096 + 3] for every staging address.
+constexpr u32 ENC_STAGE_STRIDE = 4352;                               // 4 waves: [0, 17184)
+constexpr u32 ENC_DUMP = 0x7000;
+constexpr u32 ENC_LDS_BYTES = 0x8000 + 16;
+#ifndef BWTM_ENC_WALK_UNROLL
+#define BWTM_ENC_WALK_UNROLL 4
+#endif
+constexpr u32 ENC_WALK = BWTM_ENC_WALK_UNROLL;                       // events per trip of the walk (a power of two)
+
+// The one-byte events of one 32-bit half of a tile, in wave-uniform trips of ENC_WALK events (k_enc_emit's short-run path).  Every lane runs the
+// same number of trips -- the wave's maximum -- so the loop is scalar (no execution-mask bookkeeping, which was a third of the old loop's
+// instructions); a lane that has run out of events finds no bit (v_ffbl_b32 returns -1) and its byte goes to the dump region.
+//   hh: event bits of the half; q0..q2: planes of the half; prev: in-half position of the previous head (negative: before the half);
+//   sym: symbol of the run that is open at the start of the half; addr: LDS byte address of the half's first event
+__device__ inline void walk_half(u32 hh, u32 q0, u32 q1, u32 q2, int prev, u32 sym, u32 addr, u32 trips)
+{
+  typedef __attribute__((address_space(3))) u8 lds_u8;
+  for(u32 t = 0; t < trips; t += ENC_WALK)
+  {
+#pragma unroll
+    for(u32 j = 0; j < ENC_WALK; j++)
+    {
+      u32 bb, byte, b0, b1, b2;
+      asm("v_ffbl_b32 %0, %1" : "=v"(bb) : "v"(hh));                    // -1 when the half has no event left
+      const u32 len1 = bb + ~(u32)prev;                                 // length - 1 <= 40
+      asm("v_mad_u32_u24 %0, %1, 6, %2" : "=v"(byte) : "v"(len1), "v"(sym));     // sym + 6 (length - 1): Run::encodeBasic, support.h:231-234
+      const u32 a = (bb & ENC_DUMP) | addr;
+      ((lds_u8*)(uintptr_t)a)[j] = (u8)byte;
+#ifdef BWTM_SLACK_ENC_EMIT
+      { u32 slack = byte; valu_slack<BWTM_SLACK_ENC_EMIT>(slack); }
+#endif
+      b0 = __builtin_amdgcn_ubfe(q0, bb, 1u); b1 = __builtin_amdgcn_ubfe(q1, bb, 1u); b2 = __builtin_amdgcn_ubfe(q2, bb, 1u);
+      asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(sym) : "v"(b1), "v"(b0));
+      asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(sym) : "v"(b2), "v"(sym));
+      prev = (int)bb;
+      hh &= hh - 1;
+    }
+    addr += ENC_WALK;
+  }
+}
+
 // The three segment kernels cover the segments [seg_first, seg_end) and index `recs` and the per-segment arrays by GLOBAL
 // record / segment numbers: an output-range slice (one GPU's share of the result) passes the addresses of its local buffers
 // minus the offsets of its first record / segment.  `carry` = (last head before the first segment of the launch) + 1 as
@@ -338,12 +406,15 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_cum_expand(const u64* sup, co
 // host while the next range is written.  CUM: also the samples' cumulative counts at every block start, in the compact form cum32 (above);
 // whole-index launches only (`recs` is then the index's own record array).
 template<bool CUM>
-__global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 seg_first, u64 seg_end,
+__global__ void __launch_bounds__(BLOCK_THREADS, 4) k_enc_emit(const uint4* recs, u64 nrecs, u64 n, u64 ntiles, u64 seg_first, u64 seg_end,
   const u64* prevhead, u64 head_carry, const u64* seg_base, u8* out, u64* block_start, u32* cum32, u64 cum_stride)
 {
-  __shared__ __attribute__((aligned(16))) u8 stage[BLOCK_THREADS / WAVE][4096 + 32];
+  static_assert(BLOCK_THREADS / WAVE * ENC_STAGE_STRIDE <= ENC_DUMP && ENC_STAGE_STRIDE >= 4096 + 32, "staging areas below the dump region");
+  __shared__ __attribute__((aligned(16))) u8 lds_all[ENC_LDS_BYTES];   // the kernel's only LDS object: it starts at LDS address 0 (checked below)
   u64 seg = seg_first + (((u64)blockIdx.x * BLOCK_THREADS + threadIdx.x) >> 6);
   if(seg >= seg_end) { return; }
+  u8* const stage_lds = lds_all + (threadIdx.x >> 6) * ENC_STAGE_STRIDE;
+  const u32 stage_addr = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)stage_lds;      // LDS byte address of the wave's staging area
   u64 first = seg * SEG_TILES;
   u32 carry = (first == 0 ? 0u : symbol_at(recs, (first << 6) - 1));
   u64 last = prevhead[seg];
@@ -401,6 +472,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
       }
     };
     TileInfo ti;
+    // (Requesting the next chunk's planes here, while this one is worked on, is SLOWER: 4.78 -> 5.08 ms at config 2, round 5 -- the six
+    // registers push the kernel over 128 and the compiler spills lane constants that every chunk then reloads.)
     carry = chunk_tiles(recs, nrecs, ft, n, carry, ti);
     u64 T = ft + lane_id();
     if(T >= ntiles) { ti.H = 0; ti.E = 0; }
@@ -450,60 +523,39 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
     {
       // Every event is a run shorter than 42: one byte each, in position order.  The bytes are
       // staged in LDS at the same 16-byte phase as their destination and leave as 16-byte stores.
-      u8* lds = stage[threadIdx.x >> 6];
+      u8* lds = stage_lds;
       const u32 a = (u32)(off & 15);
-      u32 idx = a + (u32)(ev_incl - nev);
-      if(ti.H != 0)
+      const u32 idx0 = a + (u32)(ev_incl - nev);                          // staging index of the tile's first byte
       {
-        // Events of the tile in position order.  The run that ends at head b has the symbol found at the
-        // previous head and the length b - (previous head); only the first head needs the 64-bit state
-        // carried in from the tiles before.  The tile is walked as two 32-bit halves.
+        // The run that ends at head b has the symbol found at the previous head and the length b - (previous head).  The tile is
+        // walked as two 32-bit halves (walk_half): the run open at the start of the low half is the one that was open before the tile
+        // (symbol ti.prev, begun at the last head before the tile) -- unless the tile starts at position 0, a head without an event --
+        // and the run open at the start of the high half has the symbol at bit 31 and began at the last head of the low half, if any.
         const u64 tb = T << 6;
+        const u32 h_lo = (u32)ti.H, e_lo = (u32)ti.E, e_hi = (u32)(ti.E >> 32);
+        const bool at_zero = (tb == 0 && (h_lo & 1u) != 0);
+        const int prev_lo = (at_zero ? 0 : (int)(u32)(before - 1 - tb));  // in-tile position of the last head before the tile's first event (negative: before the tile)
+        const u32 sym_lo = (at_zero ? ((u32)(ti.p0 & 1) | ((u32)(ti.p1 & 1) << 1) | ((u32)(ti.p2 & 1) << 2)) : ti.prev);
+        const int prev_hi = (h_lo != 0 ? 31 - (int)__builtin_clz(h_lo) : prev_lo) - 32;
+        const u32 sym_hi = (u32)((ti.p0 >> 31) & 1) | ((u32)((ti.p1 >> 31) & 1) << 1) | ((u32)((ti.p2 >> 31) & 1) << 2);
+        const u32 n_lo = (u32)__builtin_popcount(e_lo), n_hi = nev - n_lo;
+        const u32 trips_lo = (wave_max32(n_lo) + (ENC_WALK - 1)) & ~(ENC_WALK - 1), trips_hi = (wave_max32(n_hi) + (ENC_WALK - 1)) & ~(ENC_WALK - 1);
+        walk_half(e_lo, (u32)ti.p0, (u32)ti.p1, (u32)ti.p2, prev_lo, sym_lo, stage_addr + idx0, trips_lo);
+        walk_half(e_hi, (u32)(ti.p0 >> 32), (u32)(ti.p1 >> 32), (u32)(ti.p2 >> 32), prev_hi, sym_hi, stage_addr + idx0 + n_lo, trips_hi);
+        // A tile emits at most 64 bytes, so at most one of them opens a 64-byte block: event number `kopen` of the tile, if it has that many.
+        // The run of that event starts at the head before it (found after the walk: tracking it inside cost two instructions per event).
         const u32 phase = (u32)((off - a) & (RLE_BLOCK - 1));            // byte (off - a + idx) opens a block iff ((phase + idx) & 63) == 0
-        // a tile emits at most 64 bytes, so at most one of them opens a block: its index is known before the walk
-        const u32 opens = idx + ((0u - (phase + idx)) & (u32)(RLE_BLOCK - 1));
-        const u32 b0 = (u32)__builtin_ctzll(ti.H);
-        u64 h = ti.H;
-        int prev_bit; u32 run_sym;
-        if(tb + b0 == 0) { h &= h - 1; prev_bit = 0; run_sym = (u32)(ti.p0 & 1) | ((u32)(ti.p1 & 1) << 1) | ((u32)(ti.p2 & 1) << 2); }   // position 0 is a head without an event
-        else { prev_bit = (int)b0 - (int)(u32)(tb + b0 + 1 - before); run_sym = event_symbol(ti, b0); }
-        // The loop body is kept free of branches and 64-bit arithmetic (it runs ~48 times per lane and the kernel is
-        // VALU-bound): the run that opens a block is remembered with a select and stored after the walk, the byte is a 24-bit mad.
-        constexpr int NO_OPEN = -0x40000000;
-        int open_prev = NO_OPEN;                                         // start (in-tile, may be negative) of the run that opens a block
-#pragma unroll
-        for(int half = 0; half < 2; half++)
+        const u32 kopen = (0u - (phase + idx0)) & (u32)(RLE_BLOCK - 1);
+        if(kopen < nev)
         {
-          u32 hh = (u32)(h >> (32 * half));
-          const u32 q0 = (u32)(ti.p0 >> (32 * half)), q1 = (u32)(ti.p1 >> (32 * half)), q2 = (u32)(ti.p2 >> (32 * half));
-          auto event = [&](u32 bb)
-          {
-            const int bit = (int)bb + 32 * half;
-            const u32 len1 = (u32)(bit - prev_bit - 1);                  // length - 1 <= 40
-            open_prev = (idx == opens ? prev_bit : open_prev);
-            u32 byte;                                                     // run_sym + 6 (length - 1): Run::encodeBasic, support.h:231-234
-            asm("v_mad_u32_u24 %0, %1, 6, %2" : "=v"(byte) : "v"(len1), "v"(run_sym));   // (the compiler picks the quarter-rate v_mad_u64_u32 here)
-            lds[idx++] = (u8)byte;
-#ifdef BWTM_SLACK_ENC_EMIT
-            { u32 slack = byte; valu_slack<BWTM_SLACK_ENC_EMIT>(slack); }
-#endif
-            run_sym = __builtin_amdgcn_ubfe(q0, bb, 1u) | (__builtin_amdgcn_ubfe(q1, bb, 1u) << 1) | (__builtin_amdgcn_ubfe(q2, bb, 1u) << 2);
-            prev_bit = bit;
-          };
-          // two events per trip of the (divergent) loop
-          while(hh)
-          {
-            event((u32)__builtin_ctz(hh)); hh &= hh - 1;
-            if(hh) { event((u32)__builtin_ctz(hh)); hh &= hh - 1; }
-          }
-        }
-        if(open_prev != NO_OPEN)
-        {
-          const u64 blk = (off - a + opens) >> 6, p = tb + (u64)(long long)open_prev;
+          const u32 ebit = select64(ti.E, kopen);
+          const u64 hb = ti.H & ((1ull << ebit) - 1);                     // heads before the event
+          const int open_prev = (hb != 0 ? 63 - (int)__builtin_clzll(hb) : prev_lo);
+          const u64 blk = (off - a + idx0 + kopen) >> 6, p = tb + (u64)(long long)open_prev;
           block_start[blk] = p;
           // the run that opens the block starts at a head of this tile (nothing of it lies behind p), or it is the run that ends at
           // the tile's first head and began before the tile (its symbol is the one before the tile)
-          if(CUM) { store_cum_at(blk, p, (open_prev >= 0 ? (u32)open_prev : b0), ti.prev); }
+          if(CUM) { store_cum_at(blk, p, (open_prev >= 0 ? (u32)open_prev : ebit), ti.prev); }
         }
       }
       flush_chunk(lds, a, a + (u32)chunk_events, off - a);
@@ -514,7 +566,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_emit(const uint4* recs, u
       // Some runs of >= 42 end in this chunk.  Their sizes depend on their byte offsets, so they are resolved
       // in order (a handful per chunk); every other event is one byte at (its event index + the extra bytes
       // of the long events before it), and all lanes write their tiles in parallel as above.
-      u8* lds = stage[threadIdx.x >> 6];
+      u8* lds = stage_lds;
       const u32 a = (u32)(off & 15);
       const u64 origin = off - a;                                      // stream offset of lds[0]
       const u32 ev_excl = (u32)(ev_incl - nev);

@@ -3,7 +3,7 @@
 # Usage: bash tools/isa_meta.sh [kernel-name-substring ...]      (the ISA text stays in /tmp/isa/bwtm_api.s)
 root=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p /tmp/isa
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only "${EXTRA[@]}" -o /tmp/isa/bwtm_api.s $root/bwt-merge_amd/csrc/bwtm_api.hip 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only $EXTRA -o /tmp/isa/bwtm_api.s $root/bwt-merge_amd/csrc/bwtm_api.hip 2>/dev/null
 python3 - "$@" <<'PY'
 import re, sys
 cur, meta = None, {}
