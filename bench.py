@@ -436,7 +436,8 @@ def measure(env, args):
 
 
 SEARCH_KERNEL_SOURCES = ("bwt-merge_amd/csrc/kernels/search_frontier.hip.h", "bwt-merge_amd/csrc/kernels/search_walk.hip.h",
-                         "bwt-merge_amd/csrc/kernels/common.hip.h", "bwt-merge_amd/csrc/bwtm_device.h")
+                         "bwt-merge_amd/csrc/kernels/common.hip.h", "bwt-merge_amd/csrc/bwtm_device.h",
+                         "bwt-merge_amd/csrc/api/search.hip.h")            # launch geometry and knobs of the search change its traffic too
 
 
 def search_code_hash():

@@ -74,7 +74,7 @@ namespace
 struct Tuning
 {
   long long search_algo = 0;      // 0 = by size (frontier search for large shards, per-chain walk for small ones), 1 = walk, 2 = frontier
-  long long frontier_unfused = 0; // 1 = generic scan + k_frontier_prep per step (the path of segment tables with > 8192 tiles)
+  long long frontier_unfused = 0; // 0 = scan + bookkeeping in one launch per step; 1 = generic scan + k_frontier_prep (the path of segment tables with > 8192 tiles); 2 = two launches (rounds 2 - 4)
   long long l1_cap = 0;           // tests: entries per level-1 region / emit capacity (0 = sized from the input): forces the exact fallbacks
   long long emit_path = 0;        // 0 = partitioned emit (default), 1 = atomicOr on the bitvector (the exact fallback, first version)
   long long round_emits = 1ll << 33;      // upper bound of emits partitioned per round of the walk (bounds the temporary regions)

@@ -26,6 +26,20 @@ struct bwtm_upload
 namespace
 {
 
+// The records [q_lo, q_hi) of the chunks [c0, c1) of the output (recs_out is indexed by the global record number): the counts at the
+// chunk starts first (k_interleave_base), then one workgroup per chunk.
+int interleave_chunks(const bwtm_index* a, const bwtm_index* b, bwtm_ra* ra, u64 c0, u64 c1, u64 q_lo, u64 q_hi, const u64* sup_out, uint4* recs_out)
+{
+  if(c1 <= c0) { return BWTM_OK; }
+  const u64 count = c1 - c0;
+  DevBuf base_rel; TRY(base_rel.alloc(5 * count * sizeof(u32)));
+  LAUNCH("interleave_base", k_interleave_base, div_up(count, BLOCK_THREADS), BLOCK_THREADS, a->view(), b->view(), ra->chunk_base.as<const u64>(), c0, c1,
+    sup_out, base_rel.as<u32>(), count);
+  LAUNCH("interleave", k_interleave, count, BLOCK_THREADS, a->view(), b->view(),
+    ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), c0, c1, q_lo, q_hi, base_rel.as<const u32>(), count, recs_out);
+  return BWTM_OK;                                                    // base_rel returns to the pool in stream order
+}
+
 int interleave_impl(const bwtm_index* a, const bwtm_index* b, bwtm_ra* ra, bwtm_index* x)
 {
   x->n = ra->n_out; x->m = a->m + b->m;                           // bwt.cpp:305-306
@@ -35,8 +49,7 @@ int interleave_impl(const bwtm_index* a, const bwtm_index* b, bwtm_ra* ra, bwtm_
   TRY(x->sup.alloc(x->nsup * SUP_STRIDE * sizeof(u64)));
   LAUNCH("interleave_sup", k_interleave_sup, div_up(x->nsup, BLOCK_THREADS), BLOCK_THREADS, a->view(), b->view(),
     ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), x->n, x->sup.as<u64>(), x->nsup, (const u64*)nullptr);
-  LAUNCH("interleave", k_interleave, ra->nchunks, BLOCK_THREADS, a->view(), b->view(),
-    ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), (u64)0, ra->nchunks, (u64)0, x->nrecs, x->sup.as<const u64>(), x->recs.as<uint4>());
+  TRY(interleave_chunks(a, b, ra, 0, ra->nchunks, 0, x->nrecs, x->sup.as<const u64>(), x->recs.as<uint4>()));
   return BWTM_OK;
 }
 

@@ -370,7 +370,7 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   } events;
   for(u32 k = 0; k < LOOK; k++) { HIP_TRY(hipEventCreateWithFlags(&events.ev[k], hipEventDisableTiming)); events.n = k + 1; }
   const u64 scan_tiles = div_up(nseg + 1, (u64)SCAN_TILE);
-  DevBuf scan_partial; TRY(scan_partial.alloc(scan_tiles * sizeof(u64)));
+  DevBuf scan_partial; TRY(scan_partial.alloc(scan_tiles * sizeof(u64), true));      // cleared: k_frontier_scan1's tagged words
   TRY(emit16.alloc((emit_cap + 16) * sizeof(unsigned short)));     // k_tile_build_frontier reads 16-byte chunks
   TRY(emit_base.alloc((EPOCH + 1) * sizeof(u64), true));
   TRY(bound.alloc(EPOCH * (ntiles + 1) * sizeof(u32)));
@@ -429,7 +429,14 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
     }
     if(scan_tiles <= FRONTIER_SCAN_TILES && g_tune.frontier_unfused == 0)
     {
-      // scan of the segment lengths + per-step bookkeeping in two launches (k_frontier_scan)
+      // scan of the segment lengths + per-step bookkeeping in one launch: the tiles exchange their totals through tagged words
+      LAUNCH("frontier_scan", k_frontier_scan1, scan_tiles, BLOCK_THREADS, seg_len[cur].as<const u64>(), scan_partial.as<unsigned long long>(), (u32)((t & 0x7FFFFFFFull) + 1), nseg,
+        seg_prefix.as<u64>(), first_seg.as<u32>(), emit_base.as<u64>(), in_epoch, host_ring + (t % LOOK));
+      size_in_ring = true;
+    }
+    else if(scan_tiles <= FRONTIER_SCAN_TILES && g_tune.frontier_unfused == 2)
+    {
+      // the same in two launches (k_scan_reduce + k_frontier_scan): rounds 2 - 4, kept for comparison
       if(scan_tiles > 1)
       {
         LAUNCH("scan_reduce", k_scan_reduce<0>, scan_tiles, BLOCK_THREADS, seg_len[cur].as<const u64>(), scan_partial.as<u64>(), nseg + 1, (u64)0, scan_tiles);

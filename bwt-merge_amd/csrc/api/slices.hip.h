@@ -214,9 +214,7 @@ extern "C" int bwtm_interleave_range(const bwtm_index* a, const bwtm_index* b, b
     if(rec_last > s->rec_halo)
     {
       const u64 c0 = s->rec_halo >> 6, c1 = div_up(rec_last, 64);
-      LAUNCH("interleave", k_interleave, c1 - c0, BLOCK_THREADS, a->view(), b->view(),
-        ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), c0, c1, s->rec_halo, rec_last, s->sup.as<const u64>(),
-        s->recs.as<uint4>() - 4 * s->rec_halo);
+      TRY(interleave_chunks(a, b, ra, c0, c1, s->rec_halo, rec_last, s->sup.as<const u64>(), s->recs.as<uint4>() - 4 * s->rec_halo));
     }
     return BWTM_OK;
   };

@@ -219,11 +219,29 @@ __device__ inline void window32(const u32 (*planes)[IL_WORDS], u64 first_word, u
   p2 = (u32)((((u64)planes[2][k + 1] << 32) | planes[2][k]) >> sh);
 }
 
+// Symbol counts at the start of every chunk of the launch, relative to the output's super table: rel[(c - 1) * stride + (chunk - chunk_first)]
+// = rank_A(a_off, c) + rank_B(b_off, c) - sup_out[super of the chunk][c].  One lane per chunk, two rank queries each -- 2.4 million of them at
+// config 2, 0.1 ms.  Until round 4 lane 0 of every k_interleave workgroup ran these queries itself: a chain of dependent loads in front of
+// the workgroup's second barrier, and ~300 instructions that the other 63 lanes of its wave executed masked off.
+__global__ void __launch_bounds__(BLOCK_THREADS) k_interleave_base(IndexView A, IndexView B, const u64* chunk_base, u64 chunk_first, u64 chunk_end,
+  const u64* sup_out, u32* rel, u64 stride)
+{
+  const u64 chunk = chunk_first + (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(chunk >= chunk_end) { return; }
+  const u64 b_chunk = chunk_base[chunk];
+  const u64 a_chunk = (chunk << (REC_SHIFT + 6)) - b_chunk;
+  u64 ra[6], rb[6];
+  index_ranks(A, (a_chunk > A.n ? A.n : a_chunk), ra);
+  index_ranks(B, (b_chunk > B.n ? B.n : b_chunk), rb);
+  const u64* sp = sup_out + ((chunk << 6) >> SUPER_REC_SHIFT) * SUP_STRIDE;
+#pragma unroll
+  for(u32 c = 1; c < 6; c++) { rel[(u64)(c - 1) * stride + (chunk - chunk_first)] = (u32)(ra[c] + rb[c] - sp[c]); }
+}
+
 __global__ void __launch_bounds__(BLOCK_THREADS) k_interleave(IndexView A, IndexView B, const u64* bits, const u64* chunk_base,
-  u64 chunk_first, u64 chunk_end, u64 q_lo, u64 q_hi, const u64* sup_out, uint4* recs_out)
+  u64 chunk_first, u64 chunk_end, u64 q_lo, u64 q_hi, const u32* base_rel, u64 base_stride, uint4* recs_out)
 {
   __shared__ u32 wave_tot[4][BLOCK_THREADS / WAVE];
-  __shared__ u64 base_rel[6];
   __shared__ u32 planes_a[3][IL_WORDS], planes_b[3][IL_WORDS];
   const u64 chunk = chunk_first + blockIdx.x;
   if(chunk >= chunk_end) { return; }
@@ -243,14 +261,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_interleave(IndexView A, Index
   const StagedLoad st = stage_issue(A, B, wa0, wb0, na_words, total_words);
   __builtin_amdgcn_sched_barrier(0);                              // both loads leave before the first LDS write
   stage_store(st, total_words, planes_a, planes_b);
-  if(t == 0)
-  {
-    u64 ra[6], rb[6];
-    index_ranks(A, (a_chunk > A.n ? A.n : a_chunk), ra);
-    index_ranks(B, (b_chunk > B.n ? B.n : b_chunk), rb);
-    const u64* sp = sup_out + ((chunk << 6) >> SUPER_REC_SHIFT) * SUP_STRIDE;
-    for(int c = 1; c < 6; c++) { base_rel[c] = ra[c] + rb[c] - sp[c]; }
-  }
+  // counts at the chunk start (k_interleave_base): workgroup-uniform addresses, i.e. scalar loads
+  const u32* br = base_rel + blockIdx.x;
+  const u32 br1 = br[0], br2 = br[base_stride], br3 = br[2 * base_stride], br4 = br[3 * base_stride], br5 = br[4 * base_stride];
   // cursors: B symbols before this word
   const u32 ones_incl = wave_incl_sum32(ones);
   if(lane == WAVE - 1) { wave_tot[0][wave] = ones_incl; }
@@ -285,14 +298,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_interleave(IndexView A, Index
   const u32 rec12 = (u32)__builtin_amdgcn_update_dpp(0, (int)before12, 0x00, 0xF, 0xF, false);
   const u32 rec34 = (u32)__builtin_amdgcn_update_dpp(0, (int)before34, 0x00, 0xF, 0xF, false);
   const u32 rec5 = (u32)__builtin_amdgcn_update_dpp(0, (int)before5, 0x00, 0xF, 0xF, false);
-  u32 rel[6]; u32 h[4];
-  rel[0] = 0;
-  rel[1] = (u32)(base_rel[1] + (rec12 & 0xFFFF)); rel[2] = (u32)(base_rel[2] + (rec12 >> 16));
-  rel[3] = (u32)(base_rel[3] + (rec34 & 0xFFFF)); rel[4] = (u32)(base_rel[4] + (rec34 >> 16));
-  rel[5] = (u32)(base_rel[5] + rec5);
-  pack_header(rel, h);
+  const u32 f1 = br1 + (rec12 & 0xFFFF), f2 = br2 + (rec12 >> 16), f3 = br3 + (rec34 & 0xFFFF), f4 = br4 + (rec34 >> 16), f5 = br5 + rec5;
+  // Word k of the 128-bit header (five 25-bit fields at bit 0, 25, 50, 75, 100: pack_header, bwtm_device.h) holds the top of field k + 1
+  // from bit 7 k of that field on and the bottom of field k + 2 at bit 25 - 7 k; lane k of the quad computes only that word.
   const u32 k = lane & 3;
-  const u32 hk = (k == 0 ? h[0] : (k == 1 ? h[1] : (k == 2 ? h[2] : h[3])));
+  const u32 fx = (k == 0 ? f1 : (k == 1 ? f2 : (k == 2 ? f3 : f4))), fy = (k == 0 ? f2 : (k == 1 ? f3 : (k == 2 ? f4 : f5)));
+  const u32 hk = (fx >> (7 * k)) | (fy << (25 - 7 * k));
   const u64 q = w >> 2;
   if(q >= q_lo && q < q_hi) { recs_out[w] = make_uint4(o0, o1, o2, hk); }
 }

@@ -425,6 +425,60 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_scan(const u64* seg_
   }
 }
 
+// The same in ONE launch (round 5): every block first publishes the total of its own tile -- (tag << 32) | total in ONE 8-byte word, stored
+// and polled at agent scope -- and then reads the words of all tiles before it, waiting for those that still carry the previous step's
+// tag.  All blocks of the launch are resident together (at most FRONTIER_SCAN_TILES tiles, one block each, are a fraction of the chip) and a block
+// publishes before it waits, so nothing can wait for a block that has not started.  `tag` changes with every step (never 0; the array is
+// cleared once per search) and every tile rewrites its word in every step, so a stale word is always the previous step's.  Totals fit 32 bits:
+// the frontier search is only used below 2^32 sequences per call.  Saves one launch and one kernel-to-kernel gap per LF step (~12 us of ~31).
+__global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_scan1(const u64* seg_len, unsigned long long* tile_total, u32 tag, u64 nseg, u64* seg_prefix, u32* first_seg,
+  u64* emit_base, u64 step, u64* host_n)
+{
+  __shared__ u64 lds[BLOCK_THREADS / WAVE];
+  const u64 n = nseg + 1;                                            // the entry after the last segment holds 0 and receives N_t
+  const u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+  u64 item[SCAN_ITEMS];
+  u64 acc = 0;
+#pragma unroll
+  for(int k = 0; k < SCAN_ITEMS; k++) { item[k] = seg_len[base + k < n ? base + k : n - 1]; }      // unconditional: see k_scan_reduce
+#pragma unroll
+  for(int k = 0; k < SCAN_ITEMS; k++) { if(base + k >= n) { item[k] = 0; } acc += item[k]; }
+  const u64 incl = wave_incl_sum(acc);
+  const u64 wave_total = shfl_u64(incl, WAVE - 1);
+  u64 excl = shfl_up_u64(incl, 1);
+  if(lane_id() == 0) { excl = 0; }
+  if(lane_id() == 0) { lds[threadIdx.x >> 6] = wave_total; }
+  __syncthreads();
+  u64 before_waves = 0, tile_sum = 0;
+  for(int k = 0; k < BLOCK_THREADS / WAVE; k++) { if(k < (int)(threadIdx.x >> 6)) { before_waves += lds[k]; } tile_sum += lds[k]; }
+  if(threadIdx.x == 0) { __hip_atomic_store(&tile_total[blockIdx.x], ((unsigned long long)tag << 32) | (unsigned long long)tile_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __syncthreads();                                                     // lds is reused below
+  u64 c = 0;
+  for(u64 k = threadIdx.x; k < blockIdx.x; k += BLOCK_THREADS)
+  {
+    unsigned long long w;
+    do { w = __hip_atomic_load(&tile_total[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while((u32)(w >> 32) != tag);
+    c += (u32)w;
+  }
+  const u64 carry = block_reduce<0>(c, lds);
+  u64 run = carry + before_waves + excl;
+  for(int k = 0; k < SCAN_ITEMS; k++)
+  {
+    const u64 idx = base + k;
+    if(idx < n)
+    {
+      seg_prefix[idx] = run;
+      if(idx < nseg)
+      {
+        const u64 b = (run + FR_BLOCK - 1) / FR_BLOCK;
+        if(b * FR_BLOCK < run + item[k]) { first_seg[b] = (u32)idx; }
+      }
+      else { emit_base[step + 1] = emit_base[step] + run; if(host_n) { *host_n = run; } }
+    }
+    run += item[k];
+  }
+}
+
 // Row t of the boundary table: bound[T] = logical index of the first element of step t whose bit
 // position lies in tile >= T (suffix minimum over the markers; N_t past the last element).
 // Two launches over (segment of BOUND_SEG tiles, step): the minimum of every segment, then every segment takes the minimum of

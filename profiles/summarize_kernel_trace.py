@@ -3,7 +3,7 @@
 restricted to the TIMED steps of the bench (the input tooling launches the same kernels).
 
 The timed region is recognised structurally: every merge step ends with the encoder
-(k_enc_emit) followed by the sample builder (k_block_cum); the last `steps` emits are
+(k_enc_emit) followed by the sample builder's last entry (k_block_cum until round 4, k_block_cum32 since round 5); the last `steps` emits are
 the timed steps -- not counting the `extra` untimed steps bench.py runs after them (since round 3: one step with every kernel
 bracketed by events, for the per-kernel table).  Usage: summarize_kernel_trace.py kernel_trace.csv steps [extra = 1] > summary.md
 """
@@ -29,9 +29,10 @@ def main():
         emits = emits[:-extra]
     first = emits[-(steps + 1)] if len(emits) > steps else -1
     # the step before the timed ones ends with its own k_block_cum
-    t_begin = next(r[1] for r in rows[first:] if r[2] == "k_block_cum") if first >= 0 else 0
+    closers = ("k_block_cum", "k_block_cum32")
+    t_begin = next(r[1] for r in rows[first:] if r[2] in closers) if first >= 0 else 0
     last_emit = emits[-1]
-    t_end = next(r[1] for r in rows[last_emit:] if r[2] == "k_block_cum")
+    t_end = next(r[1] for r in rows[last_emit:] if r[2] in closers)
     sel = [r for r in rows if r[0] >= t_begin and r[1] <= t_end]
     agg = defaultdict(list)
     for s, e, short, r in sel:

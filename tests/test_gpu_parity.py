@@ -302,7 +302,7 @@ def test_partitioned_emit_rounds_fallbacks_and_variants(gpu, oracle):
             ora = oracle.ra_from_runs(ranks, counts)
             A = gpu.Index.upload(a.data, a.sequences, a.bases)
             B = gpu.Index.upload(b.data, b.sequences, b.bases)
-            settings = [dict(search_algo=2), dict(search_algo=2, l1_cap=5000), dict(search_algo=2, frontier_unfused=1), dict(search_algo=2, frontier_epoch=9),
+            settings = [dict(search_algo=2), dict(search_algo=2, l1_cap=5000), dict(search_algo=2, frontier_unfused=1), dict(search_algo=2, frontier_unfused=2), dict(search_algo=2, frontier_epoch=9),
                         dict(search_algo=2, emit_budget=4096), dict(search_algo=0), dict(search_algo=1), dict(search_algo=1, round_emits=20000),
                         dict(search_algo=1, round_emits=3000), dict(emit_path=1), dict(search_algo=1, l1_cap=256),
                         # the node phase (fmi.cpp:304-322): never, for every level it can take (ratio 1: the whole search on trie nodes when
@@ -442,3 +442,37 @@ def test_sharded_search_with_caller_owned_buffers(gpu, oracle):
     m, _ = oracle.merge(a, b, threads=2)
     assert np.array_equal(M.data(), m.data)
     ra.free()
+
+
+def test_frontier_scan_forms_agree_on_a_multi_tile_segment_table(gpu):
+    """The per-step scan of the segment lengths has three forms (one launch with tagged tile totals: the default since round 5; two
+    launches; the generic scan).  Small collections have a one-tile segment table, where the tiles never wait for each other; here the
+    table has several tiles (6 x 10^5 sequences: 11 720 segments), and all forms must give the rank array of the per-chain walk."""
+    import torch
+    from bwt_merge_amd import synth
+    dev = torch.device("cuda", 0)
+    A = synth.build_index(gpu, 1001, 200_000, 40, leaf_reads=1 << 17, device=dev)
+    B = synth.build_index(gpu, 1002, 600_000, 25, leaf_reads=1 << 17, device=dev)
+    bits = {}
+    try:
+        for name, st in (("walk", dict(search_algo=1)), ("one_launch", dict(search_algo=2, frontier_unfused=0)), ("two_launches", dict(search_algo=2, frontier_unfused=2)),
+                         ("generic", dict(search_algo=2, frontier_unfused=1)), ("one_launch_no_nodes", dict(search_algo=2, frontier_unfused=0, range_ratio=0))):
+            gpu.tune("range_ratio", -1); gpu.tune("frontier_unfused", 0)
+            for k, v in st.items():
+                gpu.tune(k, v)
+            gpu.profile_enable(True); gpu.profile_reset()
+            ra = gpu.RankArray(A, B)
+            ra.search(A, B, 0, B.sequences - 1)
+            ra.finalize()
+            prof = gpu.profile_read(); gpu.profile_enable(False)
+            assert ra.values == B.bases, name
+            assert ("frontier_step" in prof) == (name != "walk"), (name, sorted(prof))
+            if name == "one_launch_no_nodes":
+                assert prof["frontier_scan"][1] == prof["frontier_step"][1], sorted(prof)     # one scan launch per step
+            bits[name] = ra.bits()
+            ra.free()
+    finally:
+        gpu.tune("search_algo", 2); gpu.tune("frontier_unfused", 0); gpu.tune("range_ratio", -1)
+    for name in bits:
+        assert np.array_equal(bits[name], bits["walk"]), name
+    A.free(); B.free()
