@@ -374,6 +374,40 @@ __global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64
       for(int w = 0; w < 16; w++)
       {
         const u32 word = row[w];
+#ifndef BWTM_BUILD_RECS_NO_WORD_PATH
+        // Round 5.  The per-byte `if(fill >= 32) flush()` below is taken by SOME lane of the wave at nearly every byte (a lane completes a word
+        // every ~24 bytes, 64 lanes), so the wave executed the flush body -- 3 LDS atomics + ~9 instructions -- ~0.9 times per byte on top of the
+        // 22 of the straight-line code.  When every lane's four bytes are runs of at most 8 (bytes < 48: all but a few words of a read-like
+        // stream), the word advances a lane by at most 32 positions, so a 64-bit accumulator per plane (lo = current word, hi = the next one)
+        // takes all four runs -- deposited as one pattern per plane, built at offset 0 and shifted into place once -- and ONE flush check per
+        // word suffices.  Wave-uniform test; any other word takes the per-byte path below.
+        const u32 over8 = (((word & 0x7F7F7F7Fu) + 0x50505050u) | word) & 0x80808080u;          // a byte >= 48
+        if(__ballot(cont || over8 != 0) == 0)
+        {
+#ifdef BWTM_SLACK_BUILD_RECS
+          { u32 slack = word; valu_slack<BWTM_SLACK_BUILD_RECS>(slack); }
+#endif
+          // the four runs as one pattern per plane relative to the lane's current position (at most 32 bits), shifted into place once
+          u32 pat0 = 0, pat1 = 0, pat2 = 0, adv = 0;
+#pragma unroll
+          for(int k = 0; k < 4; k++)
+          {
+            const u32 byte = (word >> (8 * k)) & 0xFF;
+            const u32 q = (byte * 171u) >> 10;                           // byte / 6, exact for byte < 256
+            const u32 sym = byte - 6 * q;
+            const u32 m = ((2u << q) - 1u) << adv;                       // length q + 1 <= 8 at offset adv <= 24
+            const u32 s0 = 0u - (sym & 1u), s1 = 0u - ((sym >> 1) & 1u), s2 = 0u - ((sym >> 2) & 1u);
+            pat0 |= s0 & m; pat1 |= s1 & m; pat2 |= s2 & m;
+            adv += q + 1;
+          }
+          const u64 w0 = (u64)pat0 << fill, w1 = (u64)pat1 << fill, w2 = (u64)pat2 << fill;      // fill < 32
+          lo0 |= (u32)w0; lo1 |= (u32)w1; lo2 |= (u32)w2;
+          hi0 |= (u32)(w0 >> 32); hi1 |= (u32)(w1 >> 32); hi2 |= (u32)(w2 >> 32);
+          fill += adv;
+          if(fill >= 32) { flush(); }
+          continue;
+        }
+#endif
         // bytes >= 186 (runs of 32 and more, heads of runs with a varint extension): high bit set and low 7 bits >= 0x3A
         const u32 big = ((word & 0x7F7F7F7Fu) + 0x46464646u) & word & 0x80808080u;
         if(!cont && big == 0)
