@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+T_START = time.time()
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8.0 TB/s spec
 PCIE_SPEC_GBS = 63.0                       # PCIe Gen5 x16 per direction
 SEARCH_BYTES_PER_BASE = 160                # one 64-byte block + 8 + 8 bytes on each side
@@ -74,6 +75,9 @@ def main():
                          "the line as `target`; auto = when this is the default single-GPU config-2 run and the device has the memory for it")
     ap.add_argument("--target-reads", type=int, default=500_000_000, help="reads per set of the target measurement (5e8 x 100 bp = 50.5 Gbase)")
     ap.add_argument("--target-steps", type=int, default=2)
+    ap.add_argument("--target-timeout", type=int, default=1500, help="seconds after which the target measurement's child process is stopped (the configured "
+                                                                     "workload's line is printed either way)")
+    ap.add_argument("--as-target", action="store_true", help=argparse.SUPPRESS)        # set by the parent for its target-size child: fewer repeats of every leg
     ap.add_argument("--keep-pool", action="store_true",
                     help="do not return the library's pooled memory to the driver after the inputs are built (under rocprofv3 --pmc memory released "
                          "with hipMemRelease does not come back: at 2 x 50 Gbase the merge then finds 118 GB less than it should)")
@@ -117,6 +121,7 @@ def main():
         pkg.tune(key, int(value))
 
     env = types.SimpleNamespace(pkg=pkg, synth=synth, np=np, torch=torch, dist=dist, dev=dev, rank=rank, world=world, sharded=sharded)
+    args.is_target = bool(args.as_target)
     out = measure(env, args)
 
     # ---------------------------------------------------------------- the north star's target size on ONE GPU
@@ -126,36 +131,55 @@ def main():
                      and not args.torch_leaves and not args.tune)
     want_target = (args.target == "on" or (args.target == "auto" and default_shape)) and world == 1 and not args.force_dist
     if want_target and rank == 0:
+        # The configured workload's line is final at this point: it goes to stderr (and to a side file) BEFORE the target measurement starts,
+        # so that no failure of that measurement -- which runs in a child process with its own timeout -- can lose it.
+        log("line before the target measurement: " + json.dumps(out))
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_line_before_target.json"), "w") as f:
+                f.write(json.dumps(out) + "\n")
+        except OSError:
+            pass
         free_b, total_b = torch.cuda.mem_get_info()
         need = 230e9 * (args.target_reads / 5e8)
         if total_b < need:
             out["target"] = {"skipped": "the device has %.0f GB of memory, the target size needs %.0f GB" % (total_b / 1e9, need / 1e9)}
         else:
-            out["target"] = target_record(env, args, out)
+            out["target"] = target_record(args, out)
     if rank == 0:
+        out["process_seconds"] = round(time.time() - T_START, 1)       # this process from its start to this line (the driver's clock sees launch + this)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def target_record(env, args, base):
+def target_record(args, base):
     """The target-size measurement as a record of the line: resident value, host to host (full + compact), verification, roofline of
-    the dominant kernel, and the ratio to the CPU baseline of the same run."""
-    import copy
-    t_args = copy.copy(args)
-    t_args.reads, t_args.reads_a = args.target_reads, 0
-    t_args.steps, t_args.warmup, t_args.host_steps = max(1, args.target_steps), 1, 1
-    t_args.no_cpu_baseline, t_args.is_target = True, True
+    the dominant kernel, and the ratio to the CPU baseline of the same run.  Measured by a CHILD process (this one has released its device
+    memory; it keeps only its HIP context): a hang, an abort or an out-of-memory kill there costs the record, not the line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--reads", str(args.target_reads), "--readlen", str(args.readlen), "--leaf-reads", str(args.leaf_reads),
+           "--steps", str(max(1, args.target_steps)), "--warmup", "1", "--host-steps", "1", "--verify-reads", str(args.verify_reads),
+           "--no-cpu-baseline", "--target", "off", "--as-target"]
+    if args.no_verify:
+        cmd.append("--no-verify")
+    if args.no_host:
+        cmd.append("--no-host")
     t0 = time.time()
     try:
-        full = measure(env, t_args)
-    except Exception as e:                                   # the configured workload's numbers must survive a failure here
-        log("target measurement failed: %r" % (e,))
+        run = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=args.target_timeout)         # stderr (the progress log) passes through
+        lines = [l for l in run.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+        if run.returncode != 0 or not lines:
+            return {"failed": "the child process ended with code %d and %d JSON lines" % (run.returncode, len(lines)), "seconds": round(time.time() - t0, 1)}
+        full = json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {"failed": "stopped after %d s (--target-timeout)" % args.target_timeout, "seconds": round(time.time() - t0, 1)}
+    except (OSError, ValueError) as e:
         return {"failed": repr(e), "seconds": round(time.time() - t0, 1)}
-    rec = {k: full[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "job_roofline", "kernel_ms_per_step",
-                                "host_to_host", "peak_device_bytes", "verified", "verification")}
-    rec["fits_in_driver_run"] = True
+    rec = {k: full.get(k) for k in ("value", "value_basis", "host_to_host_value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "job_roofline",
+                                    "kernel_ms_per_step", "host_to_host", "peak_device_bytes", "verified", "verification")}
+    rec["process"] = "child"
     rec["seconds"] = round(time.time() - t0, 1)
     cpu = base.get("cpu_baseline")
     if cpu and cpu.get("value"):
@@ -390,6 +414,8 @@ def measure(env, args):
     # ---------------------------------------------------------------- host to host (SURVEY 8(d)'s T), rank 0 at N == 1
     host = None
     dev_in.clear()                                   # the device copies of the inputs are not needed any more
+    from bwt_merge_amd import dist as bwtm_dist
+    bwtm_dist.release_buffers()                      # the cached bitvector of the sharded steps
     torch.cuda.empty_cache()
     if rank == 0 and not sharded and not args.no_host and nsets == 2:
         host = host_to_host(pkg, np, torch, dev, host_in, meta, args)
@@ -419,7 +445,7 @@ def measure(env, args):
              "mixed": "sigma=6, 100 / 150 bp mixed"}[args.workload]
     return {
         "metric": "merged Gbases/sec (input1+input2), bit-exact native BWT",
-        "value": round(value, 4), "unit": "Gbases/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 4), "value_basis": "hbm_resident", "host_to_host_value": (host or {}).get("value"), "unit": "Gbases/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(sec_per_step * 1e3, 2), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "%s Gbase synthetic %d bp read sets (%s)%s, native format, inputs resident in HBM" %

@@ -123,20 +123,6 @@ SYMBOLS = [
 ]
 
 
-# Every symbol include/bwtm_experimental.h declares: exported only by libbwtm_experimental.so (-DBWTM_EXPERIMENTAL), which the tests of
-# these features select with BWTM_LIB
-EXPERIMENTAL_SYMBOLS = [
-    ("bwtm_fslice_create", C.c_int, [vp, vp, vp, u64, C.c_int, C.POINTER(vp)]),
-    ("bwtm_fslice_free", None, [vp]),
-    ("bwtm_fslice_seed", C.c_int, [vp, u64, u64]),
-    ("bwtm_fslice_export", C.c_int, [vp, vp]),
-    ("bwtm_fslice_gather", C.c_int, [vp, vp, C.c_int, u64, u64]),
-    ("bwtm_fslice_advance", C.c_int, [vp]),
-    ("bwtm_fslice_finish", C.c_int, [vp]),
-]
-EXPERIMENTAL_LIB_PATH = os.path.join(HERE, "libbwtm_experimental.so")
-
-
 class BwtmError(RuntimeError):
     pass
 
@@ -163,29 +149,8 @@ def lib():
             f = getattr(L, name)       # AttributeError if the library does not export it
             f.restype = res
             f.argtypes = args
-        global _experimental
-        _experimental = hasattr(L, EXPERIMENTAL_SYMBOLS[0][0])
-        if _experimental:
-            for name, res, args in EXPERIMENTAL_SYMBOLS:
-                f = getattr(L, name)
-                f.restype = res
-                f.argtypes = args
         _lib = L
     return _lib
-
-
-_experimental = False
-
-
-def experimental():
-    """True when the loaded library is the experimental build (include/bwtm_experimental.h)."""
-    lib()
-    return _experimental
-
-
-def need_experimental(what):
-    if not experimental():
-        raise BwtmError("%s is not part of libbwtm.so: load the experimental build (BWTM_LIB=%s)" % (what, EXPERIMENTAL_LIB_PATH))
 
 
 def check(rc):
@@ -736,46 +701,6 @@ class Slice:
         out = np.zeros(count, dtype=np.uint8)
         check(lib().bwtm_slice_extract(self.h, first, count, out.ctypes.data_as(p_u8)))
         return out
-
-
-class FSliceView(C.Structure):
-    _fields_ = [("lo", vp), ("hi", vp), ("prefix", vp), ("phys", vp), ("blocks", u64), ("totals", u64 * 5)]
-
-
-class FSlice:
-    """One GPU's state of the sliced frontier search (bwtm_fslice; include/bwtm.h)."""
-
-    def __init__(self, a, b, ra, capacity, parts):
-        need_experimental("the sliced frontier search")
-        out = vp()
-        check(lib().bwtm_fslice_create(a.h, b.h, ra.h, capacity, parts, C.byref(out)))
-        self.h = out
-
-    def free(self):
-        if self.h:
-            lib().bwtm_fslice_free(self.h)
-            self.h = None
-
-    def __del__(self):
-        try:
-            self.free()
-        except Exception:
-            pass
-
-    def seed(self, seq_first, count):
-        check(lib().bwtm_fslice_seed(self.h, seq_first, count))
-
-    def export(self, view):
-        check(lib().bwtm_fslice_export(self.h, C.byref(view)))
-
-    def gather(self, views, parts, first, last):
-        check(lib().bwtm_fslice_gather(self.h, C.byref(views), parts, first, last))
-
-    def advance(self):
-        check(lib().bwtm_fslice_advance(self.h))
-
-    def finish(self):
-        check(lib().bwtm_fslice_finish(self.h))
 
 
 def merged_records(a, b):

@@ -270,9 +270,9 @@ void profile_collect()
 // (the test-suite runs once with small values so that every buffer of every test goes through map / unmap).
 // 1-GiB chunks since round 4: at 2 x 50 Gbase a merge remaps ~300 GB of blocks (inputs' records -> result records -> native result ...), and
 // with 128-MiB chunks the map / unmap calls took 45 ms per merge with the GPU idle (a 76.5 GB block: 14.5 ms); with 1-GiB chunks 7 ms
-// (2.5 ms), 1202 -> 1149 ms per merge.  Blocks between 128 MiB and 1 GiB round up to a whole chunk (a few GB in total at config 2).
+// (2.5 ms), 1202 -> 1149 ms per merge.  Blocks between VMM_MIN and 1 GiB round up to a whole chunk.
 u64 VMM_CHUNK = 1024ull << 20;
-u64 VMM_MIN = 128ull << 20;
+u64 VMM_MIN = 512ull << 20;        // (128 MiB until round 5: a 130-MiB block then took a whole 1-GiB chunk; blocks below half a chunk now come from hipMalloc and are reused by size)
 
 u64 pool_round(u64 n)
 {

@@ -211,7 +211,8 @@ extern "C" int bwtm_interleave_range(const bwtm_index* a, const bwtm_index* b, b
     TRY(s->sup.alloc(s->nsup * SUP_STRIDE * sizeof(u64)));
     LAUNCH("interleave_sup", k_interleave_sup, div_up(s->nsup, BLOCK_THREADS), BLOCK_THREADS, a->view(), b->view(),
       ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), s->n, s->sup.as<u64>(), s->nsup, (ra->ranged ? ra->super_boff.as<const u64>() : (const u64*)nullptr));
-    if(rec_last > s->rec_halo)
+    // an empty range (more GPUs than output chunks) interleaves nothing: its halo chunk was not installed by bwtm_ra_finalize_range either
+    if(rec_first < rec_last)
     {
       const u64 c0 = s->rec_halo >> 6, c1 = div_up(rec_last, 64);
       TRY(interleave_chunks(a, b, ra, c0, c1, s->rec_halo, rec_last, s->sup.as<const u64>(), s->recs.as<uint4>() - 4 * s->rec_halo));

@@ -63,7 +63,7 @@ def exchange_bitvector_ranges(words, shard_words, rank, world, dist, torch):
     behind the bitvector) -> afterwards words[rank * shard_words : (rank + 1) * shard_words] holds the sum (= or) over all ranks and
     the rest of `words` is unspecified.  Every rank sends and receives (world - 1) / world of ONE bitvector: half of an all-reduce."""
     assert words.numel() == world * shard_words
-    if dist is None or world == 1:
+    if dist is None:                                   # no process group at all; with one the collective runs on a single rank too (--force-dist)
         return words
     mine = torch.empty(shard_words, dtype=words.dtype, device=words.device)
     dist.reduce_scatter_tensor(mine, words, op=dist.ReduceOp.SUM)
@@ -168,51 +168,27 @@ def upload_sharded(pkg, host_array, sequences, bases, rank, world, dist, torch, 
     return ix, length
 
 
-def slice_range(total, part, parts):
-    """Contiguous share `part` of `total` frontier elements: [first, last)."""
-    per = (total + parts - 1) // parts
-    return min(total, part * per), min(total, (part + 1) * per)
+_bitvector_cache = {}
 
 
-def search_sliced(pkg, indexes, ras, sequences, enter=None):
-    """The sliced frontier search driven from ONE host thread over `parts` GPUs (or contexts of one GPU): indexes[g] = (A, B) as
-    GPU g holds them, ras[g] = its rank array; enter(g) makes GPU g's context current for the calling thread (None: one context).
-    Every GPU ends up with the bits of the elements it advanced; combine the rank arrays as after bwtm_search().  Returns the
-    number of LF steps.  (A host thread or process per GPU would run the same loop with barriers where this one switches GPUs.)"""
-    parts = len(indexes)
-    cap = (sequences + parts - 1) // parts + 1
-    views = (pkg.FSliceView * parts)()
-    fs = []
-    for g in range(parts):
-        if enter:
-            enter(g)
-        f = pkg.FSlice(indexes[g][0], indexes[g][1], ras[g], cap, parts)
-        first, last = shard_range(sequences, g, parts)
-        f.seed(first, (last - first + 1) if first <= last else 0)
-        f.export(views[g])
-        fs.append(f)
-    steps = 0
-    while True:
-        total = sum(int(views[h].totals[c]) for h in range(parts) for c in range(5))
-        if total == 0:
-            break
-        for g in range(parts):                              # every GPU pulls its slice of the frontier from all GPUs' outputs ...
-            if enter:
-                enter(g)
-            first, last = slice_range(total, g, parts)
-            fs[g].gather(views, parts, first, last)
-        for g in range(parts):                              # ... and only then overwrites its own outputs
-            if enter:
-                enter(g)
-            fs[g].advance()
-            fs[g].export(views[g])
-        steps += 1
-    for g in range(parts):
-        if enter:
-            enter(g)
-        fs[g].finish()
-        fs[g].free()
-    return steps
+def bitvector_buffer(words, torch, device):
+    """The caller-owned bitvector of a sharded merge, zeroed: ONE tensor per device and size, kept across merges (a fresh torch.zeros per
+    merge went through the caching allocator's search and, the first time, a device allocation of up to 12.6 GB inside the timed merge)."""
+    key = (str(device), int(words))
+    buf = _bitvector_cache.get(key)
+    if buf is None:
+        _bitvector_cache.clear()                       # one size at a time: a chain's merges grow
+        buf = torch.empty(int(words), dtype=torch.int64, device=device)
+        _bitvector_cache[key] = buf
+    buf.zero_()
+    if str(device).startswith("cuda"):
+        torch.cuda.synchronize()                       # the library's streams do not order themselves behind torch's
+    return buf
+
+
+def release_buffers():
+    """Drops the cached bitvector (bench.py calls it before measurements that need the memory)."""
+    _bitvector_cache.clear()
 
 
 def merge_sharded(pkg, A, B, rank, world, dist, torch, device):
@@ -223,8 +199,7 @@ def merge_sharded(pkg, A, B, rank, world, dist, torch, device):
     bounds = [pkg.slice_bounds_equal(nrecs, world, g) for g in range(world)]
     rec_first, rec_last, shard_bytes = bounds[rank]
     assert world * shard_bytes >= pkg.ra_buffer_bytes(A, B)            # equal shares for the collective: zero words behind the bitvector
-    buf = torch.zeros(world * shard_bytes // 8, dtype=torch.int64, device=device)
-    torch.cuda.synchronize()
+    buf = bitvector_buffer(world * shard_bytes // 8, torch, device)
     ra = pkg.RankArray(A, B, buf.data_ptr(), buf.numel() * 8)
     first, last = shard_range(B.sequences, rank, world)
     if first <= last:
@@ -241,5 +216,4 @@ def merge_sharded(pkg, A, B, rank, world, dist, torch, device):
     S.total_nbytes = total_bytes
     pkg.synchronize()
     ra.free()
-    del buf
     return S

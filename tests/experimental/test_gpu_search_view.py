@@ -9,7 +9,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def gpu(bwtm):
     bwtm.init(0)
-    assert bwtm.experimental(), "these tests need BWTM_LIB=libbwtm_experimental.so"
+    from bwt_merge_amd import experimental
+    assert experimental.loaded(), "these tests need BWTM_LIB=libbwtm_experimental.so"
     bwtm.tune("search_algo", 2)
     yield bwtm
     bwtm.tune("search_algo", 0)

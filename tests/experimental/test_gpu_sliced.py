@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def gpu(bwtm):
     bwtm.init(0)
-    assert bwtm.experimental(), "these tests need BWTM_LIB=libbwtm_experimental.so"
+    from bwt_merge_amd import experimental
+    assert experimental.loaded(), "these tests need BWTM_LIB=libbwtm_experimental.so"
     yield bwtm
     bwtm.make_default_current()
     bwtm.trim()
@@ -24,7 +25,7 @@ def oracle_ra(oracle, a, b):
 @pytest.mark.parametrize("parts,contexts", [(1, False), (2, False), (3, True), (5, True), (8, False)])
 def test_sliced_search_equals_oracle(gpu, oracle, parts, contexts):
     """Reads of mixed lengths (slices shrink and become empty at different steps), more parts than some steps have elements."""
-    from bwt_merge_amd.dist import search_sliced
+    from bwt_merge_amd.experimental import search_sliced
     rng = np.random.default_rng(7)
     ta = oracle.generate_reads(9100, 2200, 90)
     tb = np.concatenate([oracle.generate_reads(9200 + k, 300, int(n)) for k, n in enumerate([1, 17, 60, 100, 139, 33])])
@@ -68,7 +69,7 @@ def test_sliced_search_equals_oracle(gpu, oracle, parts, contexts):
 
 def test_sliced_search_wide_coordinates_and_epochs(gpu, oracle):
     """Coordinates beyond 2^32 (the high bytes travel through the gather) and epochs of a few steps in every slice."""
-    from bwt_merge_amd.dist import search_sliced
+    from bwt_merge_amd.experimental import search_sliced
     small_a = oracle.FMI.from_text(oracle.generate_reads(9301, 600, 60)); small_b = oracle.FMI.from_text(oracle.generate_reads(9302, 500, 70))
     a = oracle.FMI.from_runs(small_a.symbols.astype(np.uint64), np.full(small_a.symbols.size, 120000, dtype=np.uint64))
     assert a.bases > (1 << 32)

@@ -29,9 +29,25 @@ def test_every_declared_function_is_exported_and_bound(bwtm):
 
 def test_experimental_header_matches_the_experimental_library(bwtm):
     bwtm.build(experimental=True)
+    from bwt_merge_amd import experimental
     names = declared("bwtm_experimental.h")
-    assert names == sorted(n for n, _, _ in bwtm.capi.EXPERIMENTAL_SYMBOLS)
-    exp = ctypes.CDLL(bwtm.EXPERIMENTAL_LIB_PATH)
+    assert names == sorted(n for n, _, _ in experimental.EXPERIMENTAL_SYMBOLS)
+    exp = ctypes.CDLL(experimental.EXPERIMENTAL_LIB_PATH)
     product = ctypes.CDLL(os.path.join(ROOT, "bwt-merge_amd", "libbwtm.so"))
     for n in names:
         assert hasattr(exp, n) and not hasattr(product, n), n
+
+
+def test_product_package_exposes_no_experimental_names(bwtm):
+    """The binding follows the split of the C side: nothing of include/bwtm_experimental.h is reachable through the product package or
+    its modules (capi, dist); the experimental module refuses to bind against the product library."""
+    import pytest
+    from bwt_merge_amd import capi, dist, experimental
+    for mod in (bwtm, capi, dist):
+        for name in ("FSlice", "FSliceView", "search_sliced", "slice_range", "EXPERIMENTAL_SYMBOLS", "EXPERIMENTAL_LIB_PATH", "need_experimental"):
+            assert not hasattr(mod, name), (mod.__name__, name)
+    assert not any(n.startswith("bwtm_fslice") for n, _, _ in capi.SYMBOLS)
+    if not os.environ.get("BWTM_LIB"):                                          # the product library is what this process binds
+        assert experimental.loaded() is False
+        with pytest.raises(bwtm.BwtmError):
+            experimental._bind()

@@ -260,12 +260,14 @@ def test_fold_offsets_binding_matches_host_logic(bwtm):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# The sliced frontier search (bwt-merge_amd/dist.py: search_sliced, include/bwtm_experimental.h: bwtm_fslice_*) as a plain CPU model: every part
+# The sliced frontier search (bwt-merge_amd/experimental.py: search_sliced, include/bwtm_experimental.h: bwtm_fslice_*) as a plain CPU model: every part
 # advances a contiguous slice of the sorted frontier and the next frontier is read in the order (class, part, position inside the
 # part's output).  The claim the GPU code rests on: that order IS the suffix order, so the union of the parts' emits is the rank array.
 
-def test_sliced_frontier_model_on_cpu(oracle):
-    from bwt_merge_amd.dist import shard_range, slice_range
+def test_sliced_frontier_model_on_cpu(oracle, bwtm):
+    bwtm.build(experimental=True)                                # bwt_merge_amd.experimental imports only next to libbwtm_experimental.so
+    from bwt_merge_amd.dist import shard_range
+    from bwt_merge_amd.experimental import slice_range
     ta = oracle.generate_reads(1001, 50, 30)
     tb = np.concatenate([oracle.generate_reads(1002 + k, 12, n) for k, n in enumerate([1, 7, 19, 40, 33])])
     a, b = oracle.FMI.from_text(ta), oracle.FMI.from_text(tb)

@@ -41,7 +41,8 @@ def test_bench_target_record_and_traffic_check(bwtm):
     d = run_bench([sys.executable, "bench.py", "--reads", "3000000", "--steps", "2", "--warmup", "1", "--cpu-sample-reads", "20000", "--no-config1",
                    "--target", "on", "--target-reads", "4500000", "--target-steps", "1"])
     t = d["target"]
-    assert d["verified"] is True and t["verified"] is True and t["fits_in_driver_run"] is True
+    assert d["verified"] is True and t["verified"] is True and t["process"] == "child" and 0 < t["seconds"] <= d["process_seconds"]
+    assert d["value_basis"] == "hbm_resident" and d["host_to_host_value"] == d["host_to_host"]["value"] and t["host_to_host_value"] == t["host_to_host"]["value"]
     assert t["config"]["reads_per_set"] == 4500000 and d["config"]["reads_per_set"] == 3000000
     assert t["value"] > 0 and t["host_to_host"]["value"] > 0 and t["host_to_host"]["compact_samples"]["value"] > 0
     assert t["vs_cpu_baseline"]["resident"] > 30 and t["vs_cpu_baseline"]["cpu_cores"] == d["cpu_baseline"]["cores"]
