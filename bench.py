@@ -847,15 +847,36 @@ def cpu_baseline(pkg, synth, torch, np, dev, args):
     candidates = sorted(set(t for t in (16, 32, 64, cores) if t <= cores)) or [cores]
     a_s, b_s = sample(n_sweep)
     bases_s = a_s.bases + b_s.bases
+    def accounting(tm, search_seconds):
+        """Where the threads of the search phase were (oracle/bwtm_oracle.cpp, SearchStats): shares of threads x search wall time."""
+        th = max(1.0, tm["threads"])
+        total = th * max(search_seconds, 1e-9)
+        busy = {k: tm[k] for k in ("dfs", "sort_encode", "merge_thread", "lock_wait", "merge_global", "write")}
+        shares = {k: round(v / total, 4) for k, v in busy.items()}
+        shares["flush_one_thread"] = round(tm["flush"] * th / total, 4)          # every other thread is idle during the flush
+        shares["idle_after_last_block"] = round(max(0.0, th * (search_seconds - tm["flush"]) - tm["threads_wall"]) / total, 4)
+        return {"threads": int(th), "sequence_blocks": int(tm["sequence_blocks"]), "shares_of_thread_seconds": shares,
+                "flush_seconds": round(tm["flush"], 3)}
+
     sweep = []
     for th in candidates:
         t1 = time.perf_counter()
-        _, secs = orc.merge(a_s.clone(), b_s.clone(), threads=th)
+        _, secs, tm = orc.merge_timed(a_s.clone(), b_s.clone(), threads=th)
         dt = time.perf_counter() - t1
-        sweep.append({"threads": th, "seconds": round(dt, 3), "search_seconds": round(secs[0], 3), "value": round(bases_s / 1e9 / dt, 6)})
-        log("cpu baseline sweep, %d threads: %.2f s (%.4f Gbases/s) on 2 x %d reads" % (th, dt, sweep[-1]["value"], n_sweep))
-    del a_s, b_s
+        sweep.append({"threads": th, "seconds": round(dt, 3), "search_seconds": round(secs[0], 3), "value": round(bases_s / 1e9 / dt, 6),
+                      "accounting": accounting(tm, secs[0])})
+        log("cpu baseline sweep, %d threads: %.2f s (%.4f Gbases/s) on 2 x %d reads; %s" % (th, dt, sweep[-1]["value"], n_sweep, sweep[-1]["accounting"]["shares_of_thread_seconds"]))
     best = max(sweep, key=lambda s: s["value"])["threads"]
+    # the reference's default is 4 sequence blocks per thread (fmi.h:52); more blocks = smaller thread buffers and more two-way merges
+    blocks_sweep = []
+    for per_thread in (16, 64):
+        t1 = time.perf_counter()
+        _, secs, tm = orc.merge_timed(a_s.clone(), b_s.clone(), threads=best, sequence_blocks=per_thread * best)
+        dt = time.perf_counter() - t1
+        blocks_sweep.append({"threads": best, "sequence_blocks": per_thread * best, "seconds": round(dt, 3), "search_seconds": round(secs[0], 3),
+                             "value": round(bases_s / 1e9 / dt, 6), "accounting": accounting(tm, secs[0])})
+        log("cpu baseline, %d threads x %d blocks per thread: %.2f s (%.4f Gbases/s)" % (best, per_thread, dt, blocks_sweep[-1]["value"]))
+    del a_s, b_s
 
     # (2) the reported value: the best thread count on the large sample
     n = args.cpu_sample_reads or (1 << 22 if cores >= 16 else 1 << 18)
@@ -869,26 +890,37 @@ def cpu_baseline(pkg, synth, torch, np, dev, args):
     log("cpu baseline sample: 2 x %d reads prepared (%.1f s since the start of the baseline); running the oracle on %d threads" % (n, time.time() - t0, best))
     t1 = time.perf_counter()
     merged = a.bases + b.bases
-    m, secs = orc.merge(a, b, threads=best)
+    n_b_large = b.bases
+    m, secs, tm_large = orc.merge_timed(a, b, threads=best)
     dt = time.perf_counter() - t1
     ok = bool(np.array_equal(gpu_bytes, m.data))
     del m, gpu_bytes
     log("cpu baseline: %.2f s (search %.2f s, interleave %.2f s), parity with GPU on the sample: %s" % (dt, secs[0], secs[1], ok))
     # (3) BASELINE config 1 (two sets of 10^5 reads) on ONE thread: the reference's `bwt_merge -t 1` plumbing case
     one = None
+    efficiency = None
     if not args.no_config1:
         n1 = min(100000, args.reads)
         fm1 = sample(n1)
         bases1 = fm1[0].bases + fm1[1].bases
+        n_b_one = fm1[1].bases
         t1 = time.perf_counter()
         _, secs1 = orc.merge(fm1[0], fm1[1], threads=1)
         dt1 = time.perf_counter() - t1
-        one = {"value": round(bases1 / 1e9 / dt1, 6), "unit": "Gbases/s", "cores": 1, "seconds": round(dt1, 3),
+        # search phase only: rank-array values per second and thread on the large sample / the same on one thread
+        if secs1[0] > 0 and secs[0] > 0:
+            efficiency = round((n_b_large / secs[0]) / (best * (n_b_one / secs1[0])), 4)
+        one = {"value": round(bases1 / 1e9 / dt1, 6), "unit": "Gbases/s", "cores": 1, "seconds": round(dt1, 3), "search_seconds": round(secs1[0], 3),
                "sample": "BASELINE config 1: two sets of %d synthetic reads (%.3g Gbase merged), oracle merge with 1 thread (bwt_merge -t 1), "
                          "timer around the merging constructor as in bwt_merge.cpp:290-297" % (n1, bases1 / 1e9)}
         log("cpu baseline, config 1 on one thread: %.2f s (%.4f Gbases/s)" % (dt1, one["value"]))
     return {"value": round(merged / 1e9 / dt, 6), "unit": "Gbases/s", "cores": best, "cores_available": cores, "cpu_model": cpu_model(),
-            "thread_sweep": {"sample": "two sets of %d reads (%.3g Gbase merged)" % (n_sweep, bases_s / 1e9), "runs": sweep, "best_threads": best},
+            "thread_sweep": {"sample": "two sets of %d reads (%.3g Gbase merged)" % (n_sweep, bases_s / 1e9), "runs": sweep, "best_threads": best,
+                             "blocks_per_thread_sweep": blocks_sweep},
+            "search_parallel_efficiency": efficiency, "search_accounting": accounting(tm_large, secs[0]),
+            "search_accounting_note": "shares of (threads x search wall time) by what a thread was doing; the reference's thread / merge-buffer hierarchy "
+                                      "(fmi.cpp:139-257) is restated as it is: the two-way merges of ever larger buffers by single threads and the final flush "
+                                      "bound the search phase once the trie walk is spread over many threads",
             "config1_one_thread": one, "kind": "port",
             "sample": "two sets of %d synthetic reads of the same workload (%.3g Gbase merged), oracle merge with %d threads (the best of the sweep %s), "
                       "reference default buffers" % (n, merged / 1e9, best, candidates),

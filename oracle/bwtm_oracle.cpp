@@ -174,15 +174,22 @@ struct BWT
   std::vector<u8> data;                  // BlockArray
   std::vector<u64> block_end;            // block_boundaries: last sequence position of each block
   std::vector<u64> cum[SIGMA];           // samples[c]: cum[c][k] = #c in blocks [0, k)
+  std::vector<u64> rank_hint;            // rank_hint[j] = block_rank(64 j): what makes block_rank O(1), as sd_vector's rank_1 is (see block_rank)
 
   u64 size() const { return bases; }
   u64 bytes() const { return data.size(); }
   u64 blocks() const { return block_end.size(); }
 
-  // block_rank(i): number of block-end marks in [0, i)   (sd_vector rank_1)
+  // block_rank(i): number of block-end marks in [0, i)   (sd_vector rank_1).
+  // Round 5: answered from a table of the ranks at every 64th position plus a short forward scan (a full block written by Run::write
+  // encodes at least 64 positions, so the scan takes a step or two), the way SDSL's Elias-Fano rank answers in constant time.  Rounds 1 - 4
+  // ran a binary search over all block ends here -- ~20 dependent cache misses per rank query that the reference does not pay, i.e. a
+  // port slower than what it restates.  Same values.
   u64 block_rank(u64 i) const
   {
-    return (u64)(std::lower_bound(block_end.begin(), block_end.end(), i) - block_end.begin());
+    u64 k = rank_hint[std::min(i >> 6, (u64)rank_hint.size() - 1)];
+    while(k < block_end.size() && block_end[k] < i) { k++; }
+    return k;
   }
   // block_select(k): position of the k-th mark, 1-based   (sd_vector select_1)
   u64 block_select(u64 k) const { return block_end[k - 1]; }
@@ -208,12 +215,25 @@ struct BWT
         for(u64 c = 0; c < SIGMA; c++) { cum[c].push_back(cumulative[c]); }
       }
     }
+    build_hint(seq_pos);
+  }
+
+  void build_hint(u64 positions)
+  {
+    rank_hint.assign((positions >> 6) + 2, 0);
+    u64 k = 0;
+    for(u64 j = 0; j < rank_hint.size(); j++)
+    {
+      while(k < block_end.size() && block_end[k] < (j << 6)) { k++; }
+      rank_hint[j] = k;
+    }
   }
 
   // bwt.cpp:514-521
   void destroy()
   {
     block_end.clear(); block_end.shrink_to_fit();
+    rank_hint.clear(); rank_hint.shrink_to_fit();
     for(u64 c = 0; c < SIGMA; c++) { cum[c].clear(); cum[c].shrink_to_fit(); }
   }
 
@@ -498,6 +518,9 @@ static void rlarray_merge(RLArray& out, RLArray& a, RLArray& b)
   RLIterator ai(a), bi(b);
   u64 prev = 0;
   RunBuffer rb;
+  // the merged array is at most as long as both inputs together plus the re-coded first delta of one of them: no regrowth while it
+  // is written (the reference writes into a BlockArray, which never copies; a std::vector grown by doubling copied every byte ~twice)
+  result.data.reserve(a.bytes() + b.bytes() + 16);
   while(!ai.end() || !bi.end())
   {
     range_t temp;
@@ -603,25 +626,50 @@ struct MergeBuffer
   }
 };
 
-static void merge_ra(MergeBuffer& mb, RLArray& thread_buffer, std::vector<range_t>& run_buffer, bool force)
+struct SearchStats
 {
+  std::atomic<u64> single{0}, shortr{0}, longr{0};
+  // Where the threads of the search phase spend their time (nanoseconds, summed over threads):
+  //   dfs            inside buildRA's loop over trie nodes, without the calls below
+  //   sort_encode    RLArray(run_buffer): sort + coalesce + encode (fmi.cpp:224)
+  //   merge_thread   the two-way merge of that array into the thread buffer (fmi.cpp:225)
+  //   lock_wait      waiting for buffer_lock (fmi.cpp:240)
+  //   merge_global   two-way merges with global merge buffers taken over from others (fmi.cpp:252)
+  //   write          MergeBuffer::write (the reference's temp file; an in-memory array here)
+  //   flush          MergeBuffer::flush after the threads have joined (one thread, wall clock)
+  //   threads_wall   sum over threads of (finish - start): dfs + ... + write + idle at the end is the difference to threads x wall
+  std::atomic<u64> t_dfs{0}, t_sort_encode{0}, t_merge_thread{0}, t_lock_wait{0}, t_merge_global{0}, t_write{0}, t_flush{0}, t_threads_wall{0};
+};
+
+static inline u64 now_ns() { return (u64)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static void merge_ra(MergeBuffer& mb, RLArray& thread_buffer, std::vector<range_t>& run_buffer, bool force, SearchStats* stats = nullptr)
+{
+  u64 t0 = (stats ? now_ns() : 0), t1 = 0;
+#define ORC_LAP(field) if(stats) { t1 = now_ns(); stats->field += t1 - t0; t0 = t1; }
   RLArray temp;                                                   // fmi.cpp:224-226
   rlarray_from_records(temp, run_buffer); run_buffer.clear();
+  ORC_LAP(t_sort_encode)
   rlarray_merge(thread_buffer, thread_buffer, temp);
+  ORC_LAP(t_merge_thread)
   if(!force && thread_buffer.bytes() < mb.parameters.thread_buffer_size) { return; }
 
   for(u64 i = 0; i < mb.merge_buffers.size(); i++)                // fmi.cpp:236-254
   {
     bool done = false;
     {
-      std::lock_guard<std::mutex> lock(mb.buffer_lock);
+      std::unique_lock<std::mutex> lock(mb.buffer_lock);
+      ORC_LAP(t_lock_wait)
       if(mb.merge_buffers[i].empty()) { thread_buffer.swap(mb.merge_buffers[i]); done = true; }
       else { temp.swap(mb.merge_buffers[i]); }
     }
     if(done) { return; }
     rlarray_merge(thread_buffer, thread_buffer, temp);
+    ORC_LAP(t_merge_global)
   }
   mb.write(thread_buffer);                                        // fmi.cpp:256
+  ORC_LAP(t_write)
+#undef ORC_LAP
 }
 
 //------------------------------------------------------------------------------
@@ -633,15 +681,26 @@ struct MergePosition
   MergePosition(u64 a, range_t b) : a_pos(a), b_range(b) {}
 };
 
-struct SearchStats { std::atomic<u64> single{0}, shortr{0}, longr{0}; };
 
 static void build_ra(std::atomic<u64>& tail, const std::vector<range_t>& blocks,
   const FMI& a, const FMI& b, MergeBuffer& mb, SearchStats* stats)
 {
+  const u64 t_start = (stats ? now_ns() : 0);
+  u64 in_merge = 0;                                               // nanoseconds this thread spent inside merge_ra
+  auto timed_merge = [&](RLArray& tb, std::vector<range_t>& rbuf, bool force)
+  {
+    const u64 t0 = (stats ? now_ns() : 0);
+    merge_ra(mb, tb, rbuf, force, stats);
+    if(stats) { in_merge += now_ns() - t0; }
+  };
   while(true)
   {
     u64 block = tail++;                                           // utils.cpp:204-209
-    if(block >= blocks.size()) { return; }
+    if(block >= blocks.size())
+    {
+      if(stats) { const u64 wall = now_ns() - t_start; stats->t_threads_wall += wall; stats->t_dfs += wall - in_merge; }
+      return;
+    }
     range_t sequence_range = blocks[block];
 
     RLArray thread_buffer;
@@ -656,7 +715,7 @@ static void build_ra(std::atomic<u64>& tail, const std::vector<range_t>& blocks,
     {
       MergePosition curr = positions.top(); positions.pop();
       run_buffer.push_back(range_t(curr.a_pos, range_length(curr.b_range)));   // fmi.cpp:290
-      if(run_buffer.size() >= mb.parameters.run_buffer_size) { merge_ra(mb, thread_buffer, run_buffer, false); }
+      if(run_buffer.size() >= mb.parameters.run_buffer_size) { timed_merge(thread_buffer, run_buffer, false); }
 
       if(range_length(curr.b_range) == 1)                         // fmi.cpp:296-303
       {
@@ -686,7 +745,7 @@ static void build_ra(std::atomic<u64>& tail, const std::vector<range_t>& blocks,
         }
       }
     }
-    merge_ra(mb, thread_buffer, run_buffer, true);                // fmi.cpp:325
+    timed_merge(thread_buffer, run_buffer, true);                 // fmi.cpp:325
     if(stats) { stats->single += n_single; stats->shortr += n_short; stats->longr += n_long; }
   }
 }
@@ -704,7 +763,9 @@ static void search(const FMI& a, const FMI& b, const MergeParameters& p, MergeBu
     threads.emplace_back(build_ra, std::ref(tail), std::cref(blocks), std::cref(a), std::cref(b), std::ref(mb), stats);
   }
   for(auto& t : threads) { t.join(); }
+  const u64 t0 = (stats ? now_ns() : 0);
   mb.flush();
+  if(stats) { stats->t_flush += now_ns() - t0; }
 }
 
 //------------------------------------------------------------------------------
@@ -1153,6 +1214,21 @@ void* orc_merge(void* ha, void* hb, const OrcParams* params, double* seconds)
   FMI* a = (FMI*)ha; FMI* b = (FMI*)hb;
   FMI* out = new FMI();
   merge(*a, *b, to_params(params), *out, nullptr, seconds);
+  return out;
+}
+
+// The same with the time accounting of the search phase: timing[0..7] = dfs, sort_encode, merge_thread, lock_wait, merge_global, write, flush,
+// threads_wall in seconds (summed over threads except flush), timing[8] = threads used, timing[9] = sequence blocks.
+void* orc_merge_timed(void* ha, void* hb, const OrcParams* params, double* seconds, double* timing)
+{
+  FMI* a = (FMI*)ha; FMI* b = (FMI*)hb;
+  FMI* out = new FMI();
+  SearchStats st;
+  MergeParameters p = to_params(params);
+  merge(*a, *b, p, *out, &st, seconds);
+  const std::atomic<u64>* src[8] = {&st.t_dfs, &st.t_sort_encode, &st.t_merge_thread, &st.t_lock_wait, &st.t_merge_global, &st.t_write, &st.t_flush, &st.t_threads_wall};
+  for(int k = 0; k < 8; k++) { timing[k] = (double)src[k]->load() * 1e-9; }
+  timing[8] = (double)std::min(p.threads, p.sequence_blocks); timing[9] = (double)p.sequence_blocks;
   return out;
 }
 

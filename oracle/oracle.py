@@ -74,6 +74,7 @@ def lib():
         sig("orc_find", None, C.c_void_p, p_u8, u64, p_u64, p_u64)
         sig("orc_search", u64, C.c_void_p, C.c_void_p, C.POINTER(OrcParams), p_u64, p_u64, u64, p_u64)
         sig("orc_merge", C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(OrcParams), C.POINTER(C.c_double))
+        sig("orc_merge_timed", C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(OrcParams), C.POINTER(C.c_double), C.POINTER(C.c_double))
         sig("orc_interleave_symbols", None, p_u8, u64, p_u8, u64, p_u64, p_u8)
         _lib = L
     return _lib
@@ -289,6 +290,19 @@ def merge(a, b, **kw):
     p = _params(**kw)
     h = lib().orc_merge(a.h, b.h, C.byref(p), secs)
     return FMI(h), (secs[0], secs[1])
+
+
+TIMING_FIELDS = ("dfs", "sort_encode", "merge_thread", "lock_wait", "merge_global", "write", "flush", "threads_wall", "threads", "sequence_blocks")
+
+
+def merge_timed(a, b, **kw):
+    """merge() with the time accounting of the search phase: returns (merged FMI, (search_s, interleave_s), {field: seconds summed over
+    threads (flush: one thread's wall clock), threads, sequence_blocks})."""
+    secs = (C.c_double * 2)()
+    timing = (C.c_double * len(TIMING_FIELDS))()
+    p = _params(**kw)
+    h = lib().orc_merge_timed(a.h, b.h, C.byref(p), secs, timing)
+    return FMI(h), (secs[0], secs[1]), {k: timing[i] for i, k in enumerate(TIMING_FIELDS)}
 
 
 def interleave_symbols(a, b, ra):
