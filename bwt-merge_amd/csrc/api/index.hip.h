@@ -23,7 +23,8 @@ struct bwtm_index
   const void* borrowed = nullptr;     // caller-owned native bytes (bwtm_index_from_device_borrowed) instead of `data`
   const u8* native_bytes() const { return borrowed ? (const u8*)borrowed : data.as<const u8>(); }
   DevBuf block_start;                 // nblocks + 1 u64
-  DevBuf gcum; u64 ngroups = 0;       // 6 x (ngroups + 1) u64: cumulative symbol counts at the starts of the 62-block groups
+  DevBuf gcum; u64 ngroups = 0;       // 7 x (ngroups + 1) u64: cumulative symbol counts (rows 0..5) and positions (row 6) at the starts of the 62-block groups
+  DevBuf blen;                        // nblocks u64: positions per block, between the first decode pass and the transcode
   DevBuf cum32;                       // 5 x (nblocks + 1) u32: cumulative counts of 1..5 at the block starts, relative to the super block of the
                                       // start (kernels/encoder.hip.h); written by the encoder when it fits the budget, else answered by the records
   DevBuf flags;                       // k_block_len's verdict on the stream (read by upload_validate)
@@ -97,12 +98,13 @@ int upload_prepare(bwtm_index* x)
   const u64 gstride = x->ngroups + 1;
   x->cum32.release();
   TRY(x->block_start.alloc((x->nblocks + 1) * sizeof(u64)));
-  TRY(x->gcum.alloc(6 * gstride * sizeof(u64)));
+  TRY(x->blen.alloc(std::max<u64>(1, x->nblocks) * sizeof(u64)));
+  TRY(x->gcum.alloc(7 * gstride * sizeof(u64)));
   TRY(x->flags.alloc(sizeof(u32), true));
-  // the kernel fills columns [0, nblocks) / [0, ngroups); the extra column of each exclusive scan is zeroed here
-  HIP_TRY(hipMemsetAsync(x->block_start.as<u64>() + x->nblocks, 0, sizeof(u64), CTX.stream));
+  // the kernel fills the columns [0, ngroups); the extra column of each exclusive scan is zeroed here
   // (plain 1-D calls: the 2-D memset / memcpy entry points of the runtime reject the pool's mapped blocks)
-  for(u64 c = 0; c < 6; c++) { HIP_TRY(hipMemsetAsync(x->gcum.as<u64>() + c * gstride + x->ngroups, 0, sizeof(u64), CTX.stream)); }
+  for(u64 c = 0; c < 7; c++) { HIP_TRY(hipMemsetAsync(x->gcum.as<u64>() + c * gstride + x->ngroups, 0, sizeof(u64), CTX.stream)); }
+  if(x->nblocks == 0) { HIP_TRY(hipMemsetAsync(x->block_start.p, 0, sizeof(u64), CTX.stream)); }       // the empty stream: no group writes the entry behind the last block
   return BWTM_OK;
 }
 
@@ -141,7 +143,7 @@ int upload_decode(bwtm_index* x, const UploadEvents* events)
     const u64 g1 = std::min(x->ngroups, g0 + groups_per_chunk);
     if(events) { HIP_TRY(hipStreamWaitEvent(CTX.stream, events->ev[chunk], 0)); }
     LAUNCH("block_len", k_block_len, div_up(g1 - g0, BLOCK_THREADS / WAVE), BLOCK_THREADS,
-      x->native_bytes(), x->nbytes, x->nblocks, g0, g1, x->block_start.as<u64>(), x->gcum.as<u64>(), gstride, x->flags.as<u32>());
+      x->native_bytes(), x->nbytes, x->nblocks, g0, g1, x->blen.as<u64>(), x->gcum.as<u64>(), gstride, x->flags.as<u32>());
   }
   return BWTM_OK;
 }
@@ -162,8 +164,7 @@ int upload_queue(bwtm_index* x, const u8* host_src)
 int upload_scan(bwtm_index* x, u32 slot)
 {
   const u64 gstride = x->ngroups + 1;
-  TRY(device_scan<0>(x->block_start.as<u64>(), x->block_start.as<u64>(), x->nblocks + 1));
-  TRY(device_scan_multi<0>(x->gcum.as<u64>(), x->gcum.as<u64>(), gstride, 6, gstride));
+  TRY(device_scan_multi<0>(x->gcum.as<u64>(), x->gcum.as<u64>(), gstride, 7, gstride));      // six symbol counts + the positions, per group
   for(u32 c = 0; c < 6; c++) { TRY(fetch_u64(x->gcum.as<u64>() + c * gstride + x->ngroups, slot + c)); }
   CTX.host_scratch[slot + 6] = 0;                         // the copy below fills the low 32 bits
   HIP_TRY(hipMemcpyAsync(CTX.host_scratch + slot + 6, x->flags.p, sizeof(u32), hipMemcpyDeviceToHost, CTX.stream));
@@ -204,19 +205,20 @@ int transcode(bwtm_index* x)
   TRY(x->sup.alloc(x->nsup * SUP_STRIDE * sizeof(u64)));
   const u64 gstride = x->ngroups + 1;
   LAUNCH("build_sup", k_build_sup, div_up(x->nsup * WAVE, BLOCK_THREADS), BLOCK_THREADS,   // one wave per super
-    x->native_bytes(), x->nbytes, x->block_start.as<const u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, x->n,
+    x->native_bytes(), x->nbytes, x->blen.as<const u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, x->n,
     x->sup.as<u64>(), x->nsup);
   // one wave per group; LDS window sized to the positions a group covers on average (iid reads: ~5300)
   const u64 per_group = x->n / x->ngroups;
   const bool long_runs = (x->nblocks > 0 && x->n / x->nblocks > 400);        // > ~6 positions per byte: cooperative fill of long runs pays
 #define BUILD_RECS(W, WAVES, FILL) LAUNCH("build_recs", (k_build_recs<W, WAVES, FILL>), div_up(x->ngroups, WAVES), WAVES * WAVE, \
-    x->native_bytes(), x->nbytes, x->block_start.as<const u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, x->n, \
+    x->native_bytes(), x->nbytes, x->blen.as<const u64>(), x->block_start.as<u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, x->n, \
     x->sup.as<const u64>(), x->recs.as<uint4>(), x->nrecs)
   if(per_group <= 6500) { BUILD_RECS(8192, 4, false); }
   else if(per_group <= 14000) { BUILD_RECS(16384, 4, false); }
   else if(!long_runs) { BUILD_RECS(32768, 2, false); }
   else { BUILD_RECS(32768, 2, true); }
 #undef BUILD_RECS
+  x->blen.release();                                             // (stream ordered) the block starts are in block_start now
   return BWTM_OK;
 }
 
@@ -624,7 +626,7 @@ extern "C" int bwtm_index_drop_native(bwtm_index* x)
   if(!x) { return fail(BWTM_EINVAL, "null index"); }
   ENTER(x->ctx);
   if(x->borrowed) { HIP_TRY(hipStreamSynchronize(CTX.stream)); x->borrowed = nullptr; }
-  x->data.release(); x->cum32.release(); x->gcum.release(); x->block_start.release();
+  x->data.release(); x->cum32.release(); x->gcum.release(); x->block_start.release(); x->blen.release();
   x->has_native = false; x->nbytes = 0; x->nblocks = 0;
   return BWTM_OK;
 }

@@ -31,6 +31,20 @@ inline void gpuCheck(int rc, const char* where)
   }
 }
 
+// The library's pool takes the addresses of its large blocks from reserved ranges that are consumed and never reused (DESIGN.md section 2;
+// INTEGRATION.md "How many merges a process can run").  When they are used up -- after the order of two hundred merges of 2 x 50 Gbase in one
+// process -- large blocks come from hipMalloc, which is correct but can stall for seconds: said ONCE on stderr, at the merge that notices it.
+inline void warnIfPoolExhausted(const char* where)
+{
+  static bool warned = false;
+  bwtm_pool_info info;
+  if(warned || bwtm_pool_stats(&info) != BWTM_OK || !info.address_space_exhausted) { return; }
+  warned = true;
+  std::cerr << where << ": the device memory pool has used up its address ranges (" << info.address_bytes_reserved << " bytes reserved, "
+            << info.hipmalloc_fallbacks << " large blocks served by hipMalloc so far): further merges of this process stay correct but may be slow; "
+            << "restart the process to get the mapped pool back" << std::endl;
+}
+
 class BWT;
 
 // Rank array of inserting b into a: a handle on the device bitvector (replaces the temp-file

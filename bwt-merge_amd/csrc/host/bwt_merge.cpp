@@ -85,8 +85,15 @@ static void merge(FMI& index, FMI& increment, const MergeParameters& parameters,
   double start = readTimer();
   if(devices.size() > 1)
   {
-    FMI temp; mergeMultiGPU(index, increment, devices, temp, nullptr, sliced_search);      // one host thread per GPU, result assembled on the host
+    FMI temp; MultiGPUTimes times;
+    mergeMultiGPU(index, increment, devices, temp, &times, sliced_search);      // one host thread per GPU, result assembled on the host
     index.swap(temp);
+#ifdef VERBOSE_STATUS_INFO
+    // the phases of the sharded merge as GPU 0's thread saw them (stderr, like the reference's status lines): what a SCALE session reads
+    std::cerr << "mergeMultiGPU(): " << devices.size() << " GPUs" << (sliced_search ? " (sliced search)" : "") << ": upload " << times.upload << " s, search " << times.search
+              << " s, exchange " << times.exchange << " s, interleave + encode " << times.interleave_encode << " s, download " << times.download
+              << " s, total " << times.total << " s; exchanged " << times.exchange_bytes << " bytes per GPU; host bytes to GPU 0 " << times.host_bytes_gpu0 << std::endl;
+#endif
   }
   else
   {

@@ -250,6 +250,7 @@ inline FMI::FMI(FMI& a, FMI& b, MergeParameters parameters)
 #endif
   }
   this->alpha = merged;
+  warnIfPoolExhausted("FMI::FMI()");
 }
 
 //------------------------------------------------------------------------------

@@ -108,9 +108,53 @@ private:
 };
 #endif
 
+#ifdef BWTM_WITH_RCCL
+// RCCL communicators and one collective stream per device, created once per device list and kept for the process: a chain of merges
+// (bwt_merge in1 in2 in3 in4 out) pays ncclCommInitAll -- hundreds of milliseconds on eight GPUs -- and the stream creation once,
+// not per merge (until round 4 every merge created and destroyed both).  Thread g of a merge uses comm(g) / stream(g) only.
+class CollectiveCache
+{
+public:
+  static CollectiveCache& instance() { static CollectiveCache c; return c; }
+  struct Set { std::vector<ncclComm_t> comms; std::vector<hipStream_t> streams; };
+  // The set for `devices` (distinct, more than one); nullptr and a message on stderr when RCCL or a stream cannot be set up.
+  const Set* get(const std::vector<int>& devices)
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = sets.find(devices);
+    if(it != sets.end()) { return &it->second; }
+    Set set;
+    set.comms.assign(devices.size(), nullptr); set.streams.assign(devices.size(), nullptr);
+    if(ncclCommInitAll(set.comms.data(), (int)devices.size(), devices.data()) != ncclSuccess) { std::cerr << "mergeMultiGPU(): ncclCommInitAll failed" << std::endl; return nullptr; }
+    for(size_t g = 0; g < devices.size(); g++)
+    {
+      if(hipSetDevice(devices[g]) != hipSuccess || hipStreamCreateWithFlags(&set.streams[g], hipStreamNonBlocking) != hipSuccess)
+      {
+        std::cerr << "mergeMultiGPU(): cannot create the collective stream of GPU " << devices[g] << std::endl; return nullptr;
+      }
+    }
+    return &sets.emplace(devices, std::move(set)).first->second;
+  }
+  void releaseAll()
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    for(auto& kv : sets)
+    {
+      for(hipStream_t st : kv.second.streams) { if(st) { (void)hipStreamDestroy(st); } }
+      for(ncclComm_t c : kv.second.comms) { if(c) { ncclCommDestroy(c); } }
+    }
+    sets.clear();
+  }
+private:
+  std::mutex mu;
+  std::map<std::vector<int>, Set> sets;
+};
+#endif
+
 struct MultiGPUTimes
 {
   uint64_t host_bytes_gpu0 = 0;          // native bytes GPU 0 received from the host (sharded upload: 1 / G of both inputs)
+  uint64_t exchange_bytes = 0;           // bytes of bitvector every GPU sends and receives in the reduce-scatter: (G - 1) / G of one bitvector
   double upload = 0, search = 0, exchange = 0, interleave_encode = 0, download = 0, total = 0;   // seconds, thread 0's view
 };
 
@@ -140,9 +184,12 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
 
 #ifdef BWTM_WITH_RCCL
   std::vector<ncclComm_t> comms(G, nullptr);
+  std::vector<hipStream_t> coll_streams(G, nullptr);
   if(distinct && G > 1)
   {
-    if(ncclCommInitAll(comms.data(), (int)G, devices.data()) != ncclSuccess) { std::cerr << "mergeMultiGPU(): ncclCommInitAll failed" << std::endl; std::exit(EXIT_FAILURE); }
+    const CollectiveCache::Set* set = CollectiveCache::instance().get(devices);       // created by the first merge on these devices, reused afterwards
+    if(!set) { std::exit(EXIT_FAILURE); }
+    comms = set->comms; coll_streams = set->streams;
   }
 #else
   if(distinct && G > 1) { std::cerr << "mergeMultiGPU(): built without RCCL, cannot combine rank arrays across devices" << std::endl; std::exit(EXIT_FAILURE); }
@@ -192,7 +239,7 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
   // One input, sharded over the links: staging[g] = this GPU's full-size device buffer (hipMalloc: peers and RCCL may touch it).
   std::vector<void*> staging_a(G, nullptr), staging_b(G, nullptr);
   std::vector<uint64_t> host_bytes_per_gpu(G, 0);
-  auto uploadSharded = [&](const BlockArray& data, size_type sequences, size_type bases, const uint64_t* C, size_type g, std::vector<void*>& staging, int slot, ncclComm_t comm) -> bwtm_index*
+  auto uploadSharded = [&](const BlockArray& data, size_type sequences, size_type bases, const uint64_t* C, size_type g, std::vector<void*>& staging, int slot, ncclComm_t comm, hipStream_t stream) -> bwtm_index*
   {
     const uint64_t nbytes = data.size();
     const uint64_t chunk = ((nbytes + G - 1) / G + 255) / 256 * 256;          // equal parts (the collective wants them), 256-byte aligned
@@ -208,10 +255,8 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
     barrier.wait();                                                         // every part is on its device
     if(comm)
     {
-      hipStream_t stream = nullptr;
-      check(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
       if(ncclAllGather((char*)staging[g] + g * chunk, staging[g], chunk, ncclUint8, comm, stream) != ncclSuccess) { std::cerr << "mergeMultiGPU(): ncclAllGather failed" << std::endl; std::exit(EXIT_FAILURE); }
-      check(hipStreamSynchronize(stream), "all-gather"); (void)hipStreamDestroy(stream);
+      check(hipStreamSynchronize(stream), "all-gather");
       check(hipMemset((char*)staging[g] + nbytes, 0, chunk * G + 16 - nbytes), "hipMemset");    // the padding of the last part travelled too
     }
     else
@@ -244,8 +289,8 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
       // Sharded upload: this GPU's PCIe link carries only 1 / G of each input's native bytes; the other parts arrive from the
       // peers (all-gather over xGMI, or device-to-device copies between contexts of one GPU); every GPU then decodes and
       // transcodes its complete device copy (BWT::load, ~9 ms per 5 Gbase input).
-      A = uploadSharded(adata, a.sequences(), a.size(), ca.data(), g, staging_a, 0, (distinct ? comms[g] : nullptr));
-      B = uploadSharded(bdata, b.sequences(), b.size(), cb.data(), g, staging_b, 0, (distinct ? comms[g] : nullptr));      // the inputs are staged one after the other: one cached block serves both
+      A = uploadSharded(adata, a.sequences(), a.size(), ca.data(), g, staging_a, 0, (distinct ? comms[g] : nullptr), (distinct ? coll_streams[g] : nullptr));
+      B = uploadSharded(bdata, b.sequences(), b.size(), cb.data(), g, staging_b, 0, (distinct ? comms[g] : nullptr), (distinct ? coll_streams[g] : nullptr));      // the inputs are staged one after the other: one cached block serves both
     }
     else
 #endif
@@ -315,13 +360,13 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
       if(distinct)
       {
 #ifdef BWTM_WITH_RCCL
-        hipStream_t stream = nullptr;
-        if(hipSetDevice(devices[g]) != hipSuccess || hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { std::cerr << "mergeMultiGPU(): no stream" << std::endl; std::exit(EXIT_FAILURE); }
+        hipStream_t stream = coll_streams[g];
+        if(hipSetDevice(devices[g]) != hipSuccess) { std::cerr << "mergeMultiGPU(): hipSetDevice failed" << std::endl; std::exit(EXIT_FAILURE); }
         if(ncclReduceScatter(bits[g], (char*)bits[g] + g * shard_bytes, shard_bytes / sizeof(uint64_t), ncclUint64, ncclSum, comms[g], stream) != ncclSuccess)
         {
           std::cerr << "mergeMultiGPU(): ncclReduceScatter failed" << std::endl; std::exit(EXIT_FAILURE);
         }
-        (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream);
+        if(hipStreamSynchronize(stream) != hipSuccess) { std::cerr << "mergeMultiGPU(): the reduce-scatter failed" << std::endl; std::exit(EXIT_FAILURE); }
 #endif
       }
       else
@@ -348,7 +393,7 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
     // The small exchange: set bits of every range, local offsets of the supers that start in it, its last chunk of bits.
     gpuCheck(bwtm_ra_range_counts(ra, rec_first, rec_last, &range_ones[g], super_local.data() + g * nsup, tails.data() + g * 128), "mergeMultiGPU()");
     barrier.wait();
-    if(g == 0) { local.exchange = readTimer() - t_x; }
+    if(g == 0) { local.exchange = readTimer() - t_x; local.exchange_bytes = (G > 1 ? (G - 1) * shard_bytes : 0); }
 
     // This thread's range of the output.
     double t_i = readTimer();
@@ -416,6 +461,7 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
     bwtm_slice_free(slice);
     barrier.wait();
     if(g == 0) { local.download = readTimer() - t_d; }
+    if(g == 0) { warnIfPoolExhausted("mergeMultiGPU()"); }
     gpuCheck(bwtm_context_make_current(nullptr), "mergeMultiGPU()");
     bwtm_context_destroy(ctx);
   };
@@ -424,9 +470,6 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
   for(size_type g = 1; g < G; g++) { threads.emplace_back(worker, g); }
   worker(0);
   for(std::thread& t : threads) { t.join(); }
-#ifdef BWTM_WITH_RCCL
-  for(ncclComm_t c : comms) { if(c) { ncclCommDestroy(c); } }
-#endif
 
   out.header.sequences = a.sequences() + b.sequences();
   out.header.bases = a.size() + b.size();

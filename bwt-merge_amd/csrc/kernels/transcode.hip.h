@@ -10,8 +10,10 @@
 // The stream is cut into GROUPs of 62 consecutive 64-byte blocks; one wave owns one group and one
 // lane decodes one block, so the byte stream is read exactly once per kernel with coalesced loads.
 //
-//   k_block_len   : positions per block (-> exclusive scan = block_start, the set bits of
-//                   block_boundaries, bwt.cpp:496) and symbol counts per group (-> exclusive scan)
+//   k_block_len   : positions per block, and per group of 62 blocks its positions and symbol counts (-> exclusive scans over the
+//                   GROUPS: 1 / 62 of the blocks; the block starts -- the set bits of block_boundaries, bwt.cpp:496 -- are written by
+//                   k_build_recs, whose waves add a scan of their own 64 block lengths to the group's start.  Until round 4 the lengths
+//                   of ALL blocks were scanned: three passes over 8 bytes per block, 0.7 ms per merge at config 2)
 //   k_build_sup   : absolute counts at the super boundaries
 //   k_build_recs  : the records
 //   k_block_cum   : cumulative symbol counts at the block starts (samples[c], bwt.cpp:489-511),
@@ -119,7 +121,7 @@ __device__ inline void for_each_run(const u32* row, u32 valid, FS&& on_short, FL
   }
 }
 
-// blen[b] = positions encoded by block b; gcount[c * gstride + g] = occurrences of c in group g.
+// blen[b] = positions encoded by block b; gcount[c * gstride + g] = occurrences of c in group g (c = 0..5), gcount[6 * gstride + g] = positions of group g.
 // flags bit 0: a block other than the last one encodes fewer than 64 positions.
 // The launch covers the groups [group_first, group_end): the pipelined upload runs one launch per H2D chunk.
 // One-byte runs (the common case) are counted through a 256-entry LDS table: entry of byte v < 246 = (v / 6 + 1) << (10 (v % 6)),
@@ -206,6 +208,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_block_len(const u8* data, u64
   {
     gcount[0 * gstride + g] = t0; gcount[1 * gstride + g] = t1; gcount[2 * gstride + g] = t2;
     gcount[3 * gstride + g] = t3; gcount[4 * gstride + g] = t4; gcount[5 * gstride + g] = t5;
+    gcount[6 * gstride + g] = t0 + t1 + t2 + t3 + t4 + t5;
   }
 }
 
@@ -216,21 +219,34 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_block_end(const u64* block_st
   if(b < count) { block_end[b] = block_start[first + b + 1] - 1; }
 }
 
-// Largest b in [0, nblocks) with block_start[b] <= p (p < n).
-__device__ inline u64 find_block(const u64* block_start, u64 nblocks, u64 p)
+// Largest g in [0, ngroups) with gpos[g] <= p (p < n; gpos = exclusive scan of the groups' positions, gpos[ngroups] = n).
+__device__ inline u64 find_group(const u64* gpos, u64 ngroups, u64 p)
 {
-  u64 lo = 0, hi = nblocks;           // invariant: block_start[lo] <= p < block_start[hi]
+  u64 lo = 0, hi = ngroups;           // invariant: gpos[lo] <= p < gpos[hi]
   while(hi - lo > 1)
   {
     u64 mid = (lo + hi) >> 1;
-    if(block_start[mid] <= p) { lo = mid; } else { hi = mid; }
+    if(gpos[mid] <= p) { lo = mid; } else { hi = mid; }
   }
   return lo;
 }
 
+// Start position of the lane's block of the 64 blocks from `first` on (the group's 62 and the two lookahead blocks): the group's start + an
+// exclusive wave scan of the block lengths (the 32-bit DPP scan unless some block of the wave holds 2^25 positions or more).  len_out = the lane's own length.
+__device__ inline u64 group_block_start(const u64* blen, u64 nblocks, u64 first, u64 group_start, u64& len_out)
+{
+  const u64 b = first + lane_id();
+  const u64 len = (b < nblocks ? blen[b] : 0);
+  len_out = len;
+  u64 incl;
+  if(__ballot((len >> 25) != 0) == 0) { incl = (u64)wave_incl_sum32((u32)len); }
+  else { incl = wave_incl_sum(len); }
+  return group_start + incl - len;
+}
+
 // Super table from the native stream: one wave per super.  The counts at position p are the counts at
 // the start of p's group plus the runs of the group's blocks before p (one lane per block).
-__global__ void __launch_bounds__(BLOCK_THREADS) k_build_sup(const u8* data, u64 nbytes, const u64* block_start,
+__global__ void __launch_bounds__(BLOCK_THREADS) k_build_sup(const u8* data, u64 nbytes, const u64* blen,
   const u64* gcum, u64 gstride, u64 nblocks, u64 ngroups, u64 n, u64* sup, u64 nsup)
 {
   const u32 lane = lane_id();
@@ -241,12 +257,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_build_sup(const u8* data, u64
   u64 c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
   if(p < n)
   {
-    const u64 b = find_block(block_start, nblocks, p);   // wave-uniform
-    g = b / GROUP;
+    const u64* gpos = gcum + 6 * gstride;
+    g = find_group(gpos, ngroups, p);               // wave-uniform
+    u64 len;
+    const u64 start = group_block_start(blen, nblocks, g * GROUP, gpos[g], len);
     const u64 blk = g * GROUP + lane;
-    if(lane < (u32)GROUP && blk <= b)
+    if(lane < (u32)GROUP && blk < nblocks && start <= p)
     {
-      u64 pos = block_start[blk], rle = blk * RLE_BLOCK;
+      u64 pos = start, rle = blk * RLE_BLOCK;
       const u64 end = (nbytes - rle >= RLE_BLOCK ? rle + RLE_BLOCK : nbytes);
       while(rle < end && pos < p)
       {
@@ -284,7 +302,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_build_sup(const u8* data, u64
 constexpr u32 BR_FILLS = 256;
 
 template<u32 BR_WINDOW, int WAVES, bool FILL>
-__global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64 nbytes, const u64* block_start,
+__global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64 nbytes, const u64* blen, u64* block_start,
   const u64* gcum, u64 gstride, u64 nblocks, u64 ngroups, u64 n, const u64* sup, uint4* recs, u64 nrecs)
 {
   constexpr u32 PW = BR_WINDOW / 32;                             // words per plane
@@ -298,15 +316,21 @@ __global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64
   const u64 first = g * GROUP;
   const bool last_group = (g + 1 == ngroups);
   const u32 nb = (nblocks > first ? (nblocks - first > (u64)STAGE_ROWS ? (u32)STAGE_ROWS : (u32)(nblocks - first)) : 0u);
-  const u64 S = (nb > 0 ? block_start[first] : 0);
+  const u64* gpos = gcum + 6 * gstride;                          // start position of every group (gpos[ngroups] = n)
+  const u64 S = gpos[g];
+  // the starts of the wave's 64 blocks: written out for the group's own 62 (block_start: the set bits of block_boundaries, bwt.cpp:496, plus one)
+  u64 blen_own;
+  const u64 bstart_all = group_block_start(blen, nblocks, first, S, blen_own);
+  if(lane < (u32)GROUP && first + lane < nblocks) { block_start[first + lane] = bstart_all; }
+  if(last_group && lane == 0) { block_start[nblocks] = gpos[ngroups]; }
   const u64 q_lo = (S + REC_POS - 1) >> REC_SHIFT;
-  const u64 q_hi = (last_group ? nrecs : (block_start[first + GROUP] + REC_POS - 1) >> REC_SHIFT);
+  const u64 q_hi = (last_group ? nrecs : (gpos[g + 1] + REC_POS - 1) >> REC_SHIFT);
   if(q_lo >= q_hi) { return; }                                  // wave-uniform: no record starts in this group
   u32* rows = stage[wave];
   if(nb > 0) { stage_blocks(data, nbytes, first, nb, rows); }
   const bool have = (lane < nb);
   const u64 b = first + lane;
-  const u64 bstart = (have ? block_start[b] : 0), bend = (have ? block_start[b + 1] : 0);
+  const u64 bstart = (have ? bstart_all : 0), bend = (have ? bstart_all + blen_own : 0);
   const u32 valid = (have ? (nbytes - b * RLE_BLOCK >= RLE_BLOCK ? (u32)RLE_BLOCK : (u32)(nbytes - b * RLE_BLOCK)) : 0u);
   u64 a1 = gcum[1 * gstride + g], a2 = gcum[2 * gstride + g], a3 = gcum[3 * gstride + g],
       a4 = gcum[4 * gstride + g], a5 = gcum[5 * gstride + g];   // counts before the first record of the window

@@ -93,6 +93,25 @@ def test_cli_chained_merge_with_verification(bwtm, oracle, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_says_once_when_the_pool_runs_out_of_addresses(bwtm, oracle, tmp_path):
+    """A process that has used up the pool's address ranges (here: a 96-MiB limit and every buffer on the mapped path) keeps merging
+    correctly from hipMalloc blocks, and the facade says so ONCE on stderr (how many merges a process can run)."""
+    build_host()
+    sets = [oracle.generate_reads(4200 + k, 6000, 100) for k in range(4)]
+    names = []
+    for k, t in enumerate(sets):
+        names.append(str(tmp_path / ("in%d.plain" % k)))
+        write_plain(names[-1], oracle.FMI.from_text(t))
+    env = dict(os.environ, BWTM_POOL_VMM_CHUNK="2097152", BWTM_POOL_VMM_MIN="65536", BWTM_POOL_VA_SEGMENT="33554432", BWTM_POOL_VA_LIMIT="100663296")
+    out = subprocess.run([os.path.join(HOST, "bwt_merge"), "-i", "plain_default", "-o", "plain_default"] + names + [str(tmp_path / "out.plain")],
+                         capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stderr.count("has used up its address ranges") == 1, out.stderr[-2000:]
+    direct = oracle.FMI.from_text(np.concatenate(sets))
+    assert np.array_equal(np.fromfile(tmp_path / "out.plain", dtype=np.uint8), CHARS[direct.symbols])
+
+
+@pytest.mark.gpu
 def test_cli_one_thread_per_gpu(bwtm, oracle, tmp_path):
     """bwt_merge -g 0,0,0: three host threads, each with its own context (here on the same GPU), shard the search and
     produce one output slice each; the file equals the single-GPU result, also for a chained merge."""
