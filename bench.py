@@ -818,6 +818,26 @@ def host_chain(pkg, np, torch, host_in, meta, args, chain_tail):
     return out
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use per scheduling period (cgroup v2 cpu.max or v1 cfs quota); None = unlimited or unknown.
+    The GPU boxes of this pool show 256 logical CPUs to sched_getaffinity and give 16 (profiles/r05_cpu_quota_probe.txt): threads beyond
+    the quota only take turns."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = float(f.read())
+        return None if quota <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -836,6 +856,8 @@ def cpu_baseline(pkg, synth, torch, np, dev, args):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    quota = cpu_quota()
+    usable = max(1, min(cores, int(quota + 0.5))) if quota else cores     # threads beyond the container's CPU quota only take turns
 
     def sample(n):
         return [orc.FMI.from_symbols(synth.leaf_symbols(args.workload, seed, 0, n, args.readlen, n, dev).cpu().numpy()) for seed in (1001, 1002)]
@@ -844,7 +866,7 @@ def cpu_baseline(pkg, synth, torch, np, dev, args):
     # (profiles/r01g_cpu_baseline_threads.log), so "all cores" is not the best the CPU path can do
     t0 = time.time()
     n_sweep = min(1 << 19, args.reads)
-    candidates = sorted(set(t for t in (16, 32, 64, cores) if t <= cores)) or [cores]
+    candidates = sorted(set(t for t in (max(1, usable // 2), usable, 2 * usable, 4 * usable) if t <= cores)) or [cores]
     a_s, b_s = sample(n_sweep)
     bases_s = a_s.bases + b_s.bases
     def accounting(tm, search_seconds):
@@ -879,7 +901,7 @@ def cpu_baseline(pkg, synth, torch, np, dev, args):
     del a_s, b_s
 
     # (2) the reported value: the best thread count on the large sample
-    n = args.cpu_sample_reads or (1 << 22 if cores >= 16 else 1 << 18)
+    n = args.cpu_sample_reads or (1 << 22 if usable >= 16 else 1 << 18)
     n = min(n, args.reads)
     a, b = sample(n)
     A = pkg.Index.upload(a.data, a.sequences, a.bases)
@@ -909,15 +931,22 @@ def cpu_baseline(pkg, synth, torch, np, dev, args):
         dt1 = time.perf_counter() - t1
         # search phase only: rank-array values per second and thread on the large sample / the same on one thread
         if secs1[0] > 0 and secs[0] > 0:
-            efficiency = round((n_b_large / secs[0]) / (best * (n_b_one / secs1[0])), 4)
+            efficiency = round((n_b_large / secs[0]) / (min(best, usable) * (n_b_one / secs1[0])), 4)     # per CPU the container really gives
         one = {"value": round(bases1 / 1e9 / dt1, 6), "unit": "Gbases/s", "cores": 1, "seconds": round(dt1, 3), "search_seconds": round(secs1[0], 3),
                "sample": "BASELINE config 1: two sets of %d synthetic reads (%.3g Gbase merged), oracle merge with 1 thread (bwt_merge -t 1), "
                          "timer around the merging constructor as in bwt_merge.cpp:290-297" % (n1, bases1 / 1e9)}
         log("cpu baseline, config 1 on one thread: %.2f s (%.4f Gbases/s)" % (dt1, one["value"]))
-    return {"value": round(merged / 1e9 / dt, 6), "unit": "Gbases/s", "cores": best, "cores_available": cores, "cpu_model": cpu_model(),
+    return {"value": round(merged / 1e9 / dt, 6), "unit": "Gbases/s", "cores": best, "cores_available": cores, "cpu_quota": quota,
+            "cores_note": "threads of the reported run = the best of the sweep; the container shows %d logical CPUs%s" %
+                          (cores, (" but its cgroup quota is %.1f CPUs' worth of time: more threads than that only take turns, which is why the sweep "
+                                   "stops scaling there (profiles/r05_cpu_quota_probe.txt, r05_cpu_baseline_study.txt)" % quota) if quota else ""),
+            "cpu_model": cpu_model(),
             "thread_sweep": {"sample": "two sets of %d reads (%.3g Gbase merged)" % (n_sweep, bases_s / 1e9), "runs": sweep, "best_threads": best,
                              "blocks_per_thread_sweep": blocks_sweep},
-            "search_parallel_efficiency": efficiency, "search_accounting": accounting(tm_large, secs[0]),
+            "search_parallel_efficiency": efficiency,
+            "search_parallel_efficiency_basis": "rank-array values per second of the search phase on the large sample / (min(threads, CPU quota) x the same on one "
+                                                "thread, config 1)",
+            "search_accounting": accounting(tm_large, secs[0]),
             "search_accounting_note": "shares of (threads x search wall time) by what a thread was doing; the reference's thread / merge-buffer hierarchy "
                                       "(fmi.cpp:139-257) is restated as it is: the two-way merges of ever larger buffers by single threads and the final flush "
                                       "bound the search phase once the trie walk is spread over many threads",
