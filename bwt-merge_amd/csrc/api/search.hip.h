@@ -362,7 +362,8 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
   // The host learns the frontier size with a delay of LOOK steps and never drains the stream for it: the size of step t travels
   // to page-locked memory behind step t's scan, and the host waits for it only before it queues step t + LOOK.  The frontier only
   // shrinks, so a stale size is a valid upper bound; the price is LOOK dead steps at the end (an empty step costs ~20 us).
-  const u32 LOOK = (count >= (1ull << 20) ? 8 : 32);
+  // (4 steps of lead when a step takes a millisecond: every step of lead is one dead launch pair, ~50 us, after the last chain has ended)
+  const u32 LOOK = (count >= (1ull << 24) ? 4 : (count >= (1ull << 20) ? 8 : 32));
   struct Events
   {
     hipEvent_t ev[32]; u32 n = 0;

@@ -1,0 +1,36 @@
+#!/bin/bash
+# What a SCALE session on a multi-GPU node runs to decide between the two multi-GPU searches: the C++ tool on the
+# same two inputs with 1, 2, 4, 8 GPUs, once with sequence blocks (product: bwt_merge -g ...) and once with the sliced frontier search
+# (experimental build: bwt_merge_experimental -g ... -S).  Every run prints the phases of mergeMultiGPU() on stderr (upload / search /
+# exchange / interleave + encode / download, exchanged bytes per GPU); this script collects those lines.
+# Usage: bash tools/scale_cli.sh <reads per set> [max gpus]        (inputs are built with bwt_ingest from synthetic reads; needs >= 2 GPUs)
+set -e
+reads=${1:-50000000}; maxg=${2:-8}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; H=$R/bwt-merge_amd/csrc/host; W=${TMPDIR:-/tmp}/scale_cli; mkdir -p $W $R/gpurun_out
+make -C $H -s; make -C $H -s experimental
+python3 - $reads $W <<'PY'
+import sys, os
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+import numpy as np, torch, _pkg
+pkg = _pkg.load(); pkg.init(0)
+from bwt_merge_amd import synth
+n, w = int(sys.argv[1]), sys.argv[2]
+for k, seed in enumerate((1001, 1002)):
+    ix = synth.build_index(pkg, seed, n, 100, device=torch.device("cuda", 0)); ix.encode()
+    data = ix.data(); be, cum = ix.samples()
+    np.save(os.path.join(w, "in%d.npy" % k), data)
+    open(os.path.join(w, "in%d.meta" % k), "w").write("%d %d\n" % (ix.sequences, ix.bases))
+    ix.free()
+PY
+echo "inputs in $W (native byte streams as .npy + header fields): convert with bwt_convert or load through the facade" > $R/gpurun_out/scale_cli.txt
+ngpu=$(python3 -c "import torch; print(torch.cuda.device_count())")
+for g in 1 2 4 8; do
+  if [ $g -gt $maxg ] || [ $g -gt $ngpu ]; then break; fi
+  list=$(seq -s, 0 $((g-1)))
+  for mode in blocks sliced; do
+    exe=$H/bwt_merge; extra=""
+    if [ $mode = sliced ]; then if [ $g -lt 2 ]; then continue; fi; exe=$H/bwt_merge_experimental; extra="-S"; fi
+    echo "== $g GPU(s), $mode" | tee -a $R/gpurun_out/scale_cli.txt
+    $exe -g $list $extra -i native $W/in0.native $W/in1.native $W/out_$g_$mode.native 2>&1 | grep -E "mergeMultiGPU|BWTs merged|Total time" | tee -a $R/gpurun_out/scale_cli.txt || true
+  done
+done
