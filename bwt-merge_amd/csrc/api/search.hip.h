@@ -428,14 +428,17 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
       alive_bound = CTX.host_scratch[64 + (u32)(t % LOOK)];
       if(alive_bound == 0) { break; }
     }
-    if(scan_tiles <= FRONTIER_SCAN_TILES && g_tune.frontier_unfused == 0)
+    // One launch when every tile's workgroup is resident at the same time whatever the order of dispatch (1024 workgroups of 256 threads:
+    // four per CU, the kernel allows seven): a tile that waits for another can then never wait for one that has not started.  Larger tables
+    // (above 5 x 10^7 sequences per call: the target size has 4769 tiles) take the two-launch form, 4 us more per step of 10 ms.
+    if(scan_tiles <= FRONTIER_SCAN1_TILES && g_tune.frontier_unfused == 0)
     {
       // scan of the segment lengths + per-step bookkeeping in one launch: the tiles exchange their totals through tagged words
       LAUNCH("frontier_scan", k_frontier_scan1, scan_tiles, BLOCK_THREADS, seg_len[cur].as<const u64>(), scan_partial.as<unsigned long long>(), (u32)((t & 0x7FFFFFFFull) + 1), nseg,
         seg_prefix.as<u64>(), first_seg.as<u32>(), emit_base.as<u64>(), in_epoch, host_ring + (t % LOOK));
       size_in_ring = true;
     }
-    else if(scan_tiles <= FRONTIER_SCAN_TILES && g_tune.frontier_unfused == 2)
+    else if(scan_tiles <= FRONTIER_SCAN_TILES && g_tune.frontier_unfused != 1)
     {
       // the same in two launches (k_scan_reduce + k_frontier_scan): rounds 2 - 4, kept for comparison
       if(scan_tiles > 1)

@@ -457,6 +457,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 4) k_enc_emit(const uint4* recs
   if(seg >= seg_end) { return; }
   u8* const stage_lds = lds_all + (threadIdx.x >> 6) * ENC_STAGE_STRIDE;
   const u32 stage_addr = (u32)(uintptr_t)(__attribute__((address_space(3))) u8*)stage_lds;      // LDS byte address of the wave's staging area
+  if(stage_addr != (threadIdx.x >> 6) * ENC_STAGE_STRIDE) { __builtin_trap(); }                  // the dump-region trick needs lds_all at LDS address 0
   u64 first = seg * SEG_TILES;
   u32 carry = (first == 0 ? 0u : symbol_at(recs, (first << 6) - 1));
   u64 last = prevhead[seg];

@@ -382,6 +382,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_prep(const u64* seg_
 // sums the totals before its tile itself, scans its tile, and publishes seg_prefix, first_seg and emit_base --
 // two launches per step instead of four.
 constexpr u64 FRONTIER_SCAN_TILES = 8192;
+constexpr u64 FRONTIER_SCAN1_TILES = 1024;      // the one-launch form (k_frontier_scan1) below: all its workgroups must be co-resident
 
 // host_n (may be null): page-locked host memory the frontier's size N_t is written to directly -- a separate 8-byte copy command between
 // this kernel and the step kernel cost ~14 us of idle device per LF step (profiles/r03_config2_summary.md, gap table).
@@ -427,8 +428,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_scan(const u64* seg_
 
 // The same in ONE launch (round 5): every block first publishes the total of its own tile -- (tag << 32) | total in ONE 8-byte word, stored
 // and polled at agent scope -- and then reads the words of all tiles before it, waiting for those that still carry the previous step's
-// tag.  All blocks of the launch are resident together (at most FRONTIER_SCAN_TILES tiles, one block each, are a fraction of the chip) and a block
-// publishes before it waits, so nothing can wait for a block that has not started.  `tag` changes with every step (never 0; the array is
+// tag.  All blocks of the launch are resident together (at most FRONTIER_SCAN1_TILES tiles, one block each: four workgroups per CU where seven
+// fit) and a block publishes before it waits, so nothing can wait for a block that has not started -- in whatever order blocks are dispatched.  `tag` changes with every step (never 0; the array is
 // cleared once per search) and every tile rewrites its word in every step, so a stale word is always the previous step's.  Totals fit 32 bits:
 // the frontier search is only used below 2^32 sequences per call.  Saves one launch and one kernel-to-kernel gap per LF step (~12 us of ~31).
 __global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_scan1(const u64* seg_len, unsigned long long* tile_total, u32 tag, u64 nseg, u64* seg_prefix, u32* first_seg,

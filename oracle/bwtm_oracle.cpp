@@ -174,22 +174,24 @@ struct BWT
   std::vector<u8> data;                  // BlockArray
   std::vector<u64> block_end;            // block_boundaries: last sequence position of each block
   std::vector<u64> cum[SIGMA];           // samples[c]: cum[c][k] = #c in blocks [0, k)
-  std::vector<u64> rank_hint;            // rank_hint[j] = block_rank(64 j): what makes block_rank O(1), as sd_vector's rank_1 is (see block_rank)
+  std::vector<u64> rank_hint;            // rank_hint[j] = block_rank(j << hint_shift): what makes block_rank O(1), as sd_vector's rank_1 is (see block_rank)
+  u64 hint_shift = 6;                    // cells of 64 positions for ordinary streams; wider when runs are huge (a table of at most ~4 cells per block)
 
   u64 size() const { return bases; }
   u64 bytes() const { return data.size(); }
   u64 blocks() const { return block_end.size(); }
 
   // block_rank(i): number of block-end marks in [0, i)   (sd_vector rank_1).
-  // Round 5: answered from a table of the ranks at every 64th position plus a short forward scan (a full block written by Run::write
-  // encodes at least 64 positions, so the scan takes a step or two), the way SDSL's Elias-Fano rank answers in constant time.  Rounds 1 - 4
-  // ran a binary search over all block ends here -- ~20 dependent cache misses per rank query that the reference does not pay, i.e. a
-  // port slower than what it restates.  Same values.
+  // Round 5: answered from a table of the ranks at every 2^hint_shift-th position (64 for ordinary streams: a full block written by
+  // Run::write encodes at least 64 positions, so a cell holds a block end or two) plus a search inside the cell, the way SDSL's Elias-Fano
+  // rank answers in constant time.  Rounds 1 - 4 ran a binary search over ALL block ends here -- ~20 dependent cache misses per rank query
+  // that the reference does not pay, i.e. a port slower than what it restates.  Same values.
   u64 block_rank(u64 i) const
   {
-    u64 k = rank_hint[std::min(i >> 6, (u64)rank_hint.size() - 1)];
-    while(k < block_end.size() && block_end[k] < i) { k++; }
-    return k;
+    const u64 cell = std::min(i >> hint_shift, (u64)rank_hint.size() - 2);
+    const u64 lo = rank_hint[cell], hi = rank_hint[cell + 1];            // the answer lies in [lo, hi] when i is inside the cell; a few entries
+    if(hi - lo <= 8) { u64 k = lo; while(k < block_end.size() && block_end[k] < i) { k++; } return k; }
+    return (u64)(std::lower_bound(block_end.begin() + lo, block_end.end(), i) - block_end.begin());
   }
   // block_select(k): position of the k-th mark, 1-based   (sd_vector select_1)
   u64 block_select(u64 k) const { return block_end[k - 1]; }
@@ -220,11 +222,13 @@ struct BWT
 
   void build_hint(u64 positions)
   {
-    rank_hint.assign((positions >> 6) + 2, 0);
+    hint_shift = 6;
+    while((positions >> hint_shift) > 4 * (u64)block_end.size() + 1024) { hint_shift++; }     // streams of huge runs: not one cell per 64 positions
+    rank_hint.assign((positions >> hint_shift) + 3, 0);
     u64 k = 0;
     for(u64 j = 0; j < rank_hint.size(); j++)
     {
-      while(k < block_end.size() && block_end[k] < (j << 6)) { k++; }
+      while(k < block_end.size() && block_end[k] < (j << hint_shift)) { k++; }
       rank_hint[j] = k;
     }
   }
