@@ -394,20 +394,25 @@ __global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64
       };
       const u32* row = rows + lane * STAGE_WORDS;
       u32 rsym = 0, rshift = 0; u64 rlen = 0; bool cont = false;
+      int w = 0;
 #pragma unroll 1
-      for(int w = 0; w < 16; w++)
+      while(w < 16)
       {
-        const u32 word = row[w];
 #ifndef BWTM_BUILD_RECS_NO_WORD_PATH
         // Round 5.  The per-byte `if(fill >= 32) flush()` below is taken by SOME lane of the wave at nearly every byte (a lane completes a word
         // every ~24 bytes, 64 lanes), so the wave executed the flush body -- 3 LDS atomics + ~9 instructions -- ~0.9 times per byte on top of the
         // 22 of the straight-line code.  When every lane's four bytes are runs of at most 8 (bytes < 48: all but a few words of a read-like
         // stream), the word advances a lane by at most 32 positions, so a 64-bit accumulator per plane (lo = current word, hi = the next one)
         // takes all four runs -- deposited as one pattern per plane, built at offset 0 and shifted into place once -- and ONE flush check per
-        // word suffices.  Wave-uniform test; any other word takes the per-byte path below.
-        const u32 over8 = (((word & 0x7F7F7F7Fu) + 0x50505050u) | word) & 0x80808080u;          // a byte >= 48
-        if(__ballot(cont || over8 != 0) == 0)
+        // word suffices.  Wave-uniform test; any other word takes the per-byte path below.  The words of the word path run in a loop
+        // of their own: as one of two branches of a common loop body the compiler shuffled the ~20 loop-carried registers between the two
+        // branches' allocations at the end of every iteration (22 v_mov per word, a fifth of the path's instructions).
+#pragma unroll 1
+        for(; w < 16; w++)
         {
+          const u32 word = row[w];
+          const u32 over8 = (((word & 0x7F7F7F7Fu) + 0x50505050u) | word) & 0x80808080u;          // a byte >= 48
+          if(__ballot(cont || over8 != 0) != 0) { break; }
 #ifdef BWTM_SLACK_BUILD_RECS
           { u32 slack = word; valu_slack<BWTM_SLACK_BUILD_RECS>(slack); }
 #endif
@@ -429,9 +434,11 @@ __global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64
           hi0 |= (u32)(w0 >> 32); hi1 |= (u32)(w1 >> 32); hi2 |= (u32)(w2 >> 32);
           fill += adv;
           if(fill >= 32) { flush(); }
-          continue;
         }
+        if(w >= 16) { break; }
 #endif
+        const u32 word = row[w];
+        w++;
         // bytes >= 186 (runs of 32 and more, heads of runs with a varint extension): high bit set and low 7 bits >= 0x3A
         const u32 big = ((word & 0x7F7F7F7Fu) + 0x46464646u) & word & 0x80808080u;
         if(!cont && big == 0)
