@@ -260,6 +260,8 @@ def measure(env, args):
     def load_inputs():
         return load_input(0), load_input(1)
 
+    shard_times = {}                                 # phases of the sharded merges of this rank (N > 1 or --force-dist)
+
     # ---------------------------------------------------------------- one step
     def step(keep=False):
         A, B = load_inputs()
@@ -269,7 +271,7 @@ def measure(env, args):
                 B = load_input(k)
             M = pkg.merge_consume(A, B)          # "merges a and b, destroying them": their records are released after the interleave
         else:
-            M = merge_sharded(pkg, A, B, rank, world, dist, torch, dev)      # this rank's slice of the result
+            M = merge_sharded(pkg, A, B, rank, world, dist, torch, dev, times=shard_times)      # this rank's slice of the result
             A.free(); B.free()
         pkg.synchronize()
         if keep:
@@ -280,6 +282,7 @@ def measure(env, args):
     for _ in range(args.warmup):
         step()
     pkg.device_bytes_peak(reset=True)
+    shard_times.clear()
     # Inside the timed region only the dominant kernel's launches are bracketed by HIP events (two event records per launch cost
     # microseconds each on the stream, and a search is ~330 launches); the per-kernel table comes from one more, untimed step.
     pkg.profile_only(None if args.profile_all else "frontier_step,lf_walk")
@@ -293,6 +296,11 @@ def measure(env, args):
     barrier()
     elapsed = time.perf_counter() - t0
     prof = pkg.profile_read()
+    shard_phases = None
+    if sharded and shard_times.get("merges"):
+        # rank 0's view, per merge of the timed region; the maximum over ranks of the whole step is `ms_per_step`
+        shard_phases = {k: round(shard_times[k] / shard_times["merges"], 2) for k in ("ms_search", "ms_exchange", "ms_interleave_encode")}
+        shard_phases["exchange_bytes_per_gpu"] = int(shard_times["exchange_bytes_per_gpu"])
     prof_all, prof_all_steps = prof, max(1, args.steps)
     if not args.profile_all:
         if last is not None and (n_a + n_b) > 4e10:
@@ -458,6 +466,7 @@ def measure(env, args):
                    "bases": [mt["bases"] for mt in meta], "native_bytes": [mt["nbytes"] for mt in meta] + [out_bytes],
                    "parallelism": "sequence blocks of input2 sharded over %d GPU(s)%s" %
                    (world, ", RCCL reduce-scatter of the rank-array bitvector by output range, result sharded by output range" if sharded else "")},
+        "sharded_phases_rank0": shard_phases,
         "roofline": roofline, "job_roofline": job, "kernel_ms_per_step": kernel_ms,
         "host_to_host": host, "peak_device_bytes": peak_device,
         "cpu_baseline": cpu, "verified": verified, "verification": checks,

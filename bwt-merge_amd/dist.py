@@ -191,10 +191,14 @@ def release_buffers():
     _bitvector_cache.clear()
 
 
-def merge_sharded(pkg, A, B, rank, world, dist, torch, device):
+def merge_sharded(pkg, A, B, rank, world, dist, torch, device, times=None):
     """FMI::FMI(a, b) on `world` GPUs, as this rank sees it: search of its block of b's sequences, reduce-scatter of the rank-array
     bitvector by output range (RCCL over xGMI) + one small all-reduce, then interleave + encode of its own range of the output.
-    Returns the encoded pkg.Slice (total_nbytes = size of the whole merged stream)."""
+    Returns the encoded pkg.Slice (total_nbytes = size of the whole merged stream).  times (a dict, optional) receives this rank's phases
+    in milliseconds (search / exchange = reduce-scatter + the small all-reduce / interleave_encode incl. the carries) and the bytes of
+    bitvector this rank sends and receives in the reduce-scatter."""
+    import time as _time
+    t0 = _time.perf_counter()
     nrecs = pkg.merged_records(A, B)
     bounds = [pkg.slice_bounds_equal(nrecs, world, g) for g in range(world)]
     rec_first, rec_last, shard_bytes = bounds[rank]
@@ -205,10 +209,12 @@ def merge_sharded(pkg, A, B, rank, world, dist, torch, device):
     if first <= last:
         ra.search(A, B, first, last)
     pkg.synchronize()
+    t1 = _time.perf_counter()
     exchange_bitvector_ranges(buf, shard_bytes // 8, rank, world, dist, torch)
     torch.cuda.synchronize()
     ones, local, tail = ra.range_counts(rec_first, rec_last)
     before, total, super_boff, halo = combine_range_counts(ones, local, tail, [(b[0], b[1]) for b in bounds], rank, world, dist, torch, device)
+    t2 = _time.perf_counter()
     ra.finalize_range(rec_first, rec_last, before, total, super_boff, halo)
     S = pkg.Slice(A, B, ra, rec_first, rec_last)
     _, offset, total_bytes = exchange_encoder_carries(S.lasthead(), S.size_table, rank, world, dist, torch, device)
@@ -216,4 +222,10 @@ def merge_sharded(pkg, A, B, rank, world, dist, torch, device):
     S.total_nbytes = total_bytes
     pkg.synchronize()
     ra.free()
+    if times is not None:
+        t3 = _time.perf_counter()
+        for k, v in (("ms_search", t1 - t0), ("ms_exchange", t2 - t1), ("ms_interleave_encode", t3 - t2)):
+            times[k] = times.get(k, 0.0) + v * 1e3
+        times["merges"] = times.get("merges", 0) + 1
+        times["exchange_bytes_per_gpu"] = (world - 1) * shard_bytes      # sent and received by every rank: (N - 1) / N of one bitvector
     return S

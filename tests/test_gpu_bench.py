@@ -80,6 +80,8 @@ def test_bench_distributed_path_on_one_rank(bwtm):
                    "--master-port", "29517", "bench.py", "--gpus", "1", "--force-dist", "--reads", "200000", "--steps", "2", "--warmup", "1",
                    "--no-cpu-baseline"])
     assert d["value"] > 0 and d["config"]["native_bytes"][2] > 0 and d["verified"] is True and d["rccl_ranks"] == 1
+    ph = d["sharded_phases_rank0"]                                  # what a SCALE line carries: phases of the sharded merge and the exchanged bytes
+    assert ph["ms_search"] > 0 and ph["ms_exchange"] > 0 and ph["ms_interleave_encode"] > 0 and ph["exchange_bytes_per_gpu"] == 0
     h = d["host_to_host"]                     # the N-GPU host-to-host leg (sharded upload + all-gather, slice download) on its one rank
     assert h["value"] > 0 and h["bytes"]["h2d_this_rank"] == h["bytes"]["h2d_all_inputs"] and h["bytes"]["d2h_all_ranks"] == d["config"]["native_bytes"][2]
 
