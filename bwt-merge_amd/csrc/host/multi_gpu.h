@@ -4,8 +4,9 @@
   that own a GPU each).
 
     1. every thread uploads 1 / G of each input's native bytes to its GPU and receives the other parts from its peers
-       (all-gather over xGMI: the PCIe links carry every byte once instead of G times), then decodes and transcodes the
-       complete copy (the indexes are replicated: every LF chain touches arbitrary positions of both);
+       (all-gather over xGMI: the PCIe links carry every byte once instead of G times; in up to eight rounds, the H2D copy of round
+       j + 1 under the all-gather of round j), then decodes and transcodes the complete copy (the indexes are replicated: every LF
+       chain touches arbitrary positions of both);
     2. thread g searches block g of b's sequences (getBounds, utils.cpp:169-187) into its own bitvector;
     3. ONE bulk exchange: reduce-scatter (sum == or, the bits are disjoint) of the bitvectors by equal OUTPUT RANGES -- RCCL over
        xGMI, called directly (ncclReduceScatter in place on the buffer bwtm_ra_device_buffer() exposes): every GPU receives only the
@@ -31,6 +32,7 @@
 #define BWTM_HOST_MULTI_GPU_H
 
 #include <condition_variable>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <set>
@@ -241,30 +243,63 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
   std::vector<uint64_t> host_bytes_per_gpu(G, 0);
   auto uploadSharded = [&](const BlockArray& data, size_type sequences, size_type bases, const uint64_t* C, size_type g, std::vector<void*>& staging, int slot, ncclComm_t comm, hipStream_t stream) -> bwtm_index*
   {
+    // The stream is cut into K x G pieces of `sub` bytes; piece (j, h) = bytes [(j G + h) sub, (j G + h + 1) sub) is uploaded by GPU h in round j.
+    // The pieces of one round are contiguous, so round j's all-gather is ONE in-place ncclAllGather over [j G sub, (j + 1) G sub) -- and
+    // while it runs over xGMI, this GPU's piece of round j + 1 crosses PCIe (round 5: until then the whole 1 / G part was copied with one
+    // synchronous hipMemcpy and the all-gather started only after every GPU had finished; small inputs still take one round).
     const uint64_t nbytes = data.size();
-    const uint64_t chunk = ((nbytes + G - 1) / G + 255) / 256 * 256;          // equal parts (the collective wants them), 256-byte aligned
-    const uint64_t off = std::min<uint64_t>(g * chunk, nbytes), len = std::min<uint64_t>(chunk, nbytes - off);
+    uint64_t K = std::max<uint64_t>(1, std::min<uint64_t>(8, nbytes / (G * (64ull << 20))));
+    if(const char* v = std::getenv("BWTM_SHARDED_UPLOAD_ROUNDS")) { const long r = std::atol(v); if(r >= 1 && r <= 64) { K = (uint64_t)r; } }   // tests: several rounds on small inputs
+    const uint64_t sub = ((nbytes + G * K - 1) / (G * K) + 255) / 256 * 256;  // equal pieces (the collective wants them), 256-byte aligned
+    const uint64_t staged = sub * G * K + 16;
     auto check = [&](hipError_t e, const char* what) { if(e != hipSuccess) { std::cerr << "mergeMultiGPU(): " << what << ": " << hipGetErrorString(e) << std::endl; std::exit(EXIT_FAILURE); } };
     check(hipSetDevice(devices[g]), "hipSetDevice");
     // contexts of one GPU share the device: every thread needs its own block there, so only distinct devices use the cache
-    if(distinct) { staging[g] = DeviceBuffers::instance().get(devices[g], slot, chunk * G + 16); if(!staging[g]) { check(hipErrorOutOfMemory, "staging buffer"); } }
-    else { check(hipMalloc(&staging[g], chunk * G + 16), "hipMalloc of the staging buffer"); }
-    check(hipMemset((char*)staging[g] + nbytes, 0, chunk * G + 16 - nbytes), "hipMemset");      // readable zeros behind the stream
-    if(len > 0) { check(hipMemcpy((char*)staging[g] + off, data.data() + off, len, hipMemcpyHostToDevice), "H2D copy of this GPU's part"); }
-    host_bytes_per_gpu[g] += len;
-    barrier.wait();                                                         // every part is on its device
+    if(distinct) { staging[g] = DeviceBuffers::instance().get(devices[g], slot, staged); if(!staging[g]) { check(hipErrorOutOfMemory, "staging buffer"); } }
+    else { check(hipMalloc(&staging[g], staged), "hipMalloc of the staging buffer"); }
+    check(hipMemset((char*)staging[g] + nbytes, 0, staged - nbytes), "hipMemset");               // readable zeros behind the stream
+    auto piece = [&](uint64_t j, uint64_t h, uint64_t& off, uint64_t& len)
+    {
+      off = std::min<uint64_t>((j * G + h) * sub, nbytes); len = std::min<uint64_t>(sub, nbytes - off);
+    };
     if(comm)
     {
-      if(ncclAllGather((char*)staging[g] + g * chunk, staging[g], chunk, ncclUint8, comm, stream) != ncclSuccess) { std::cerr << "mergeMultiGPU(): ncclAllGather failed" << std::endl; std::exit(EXIT_FAILURE); }
-      check(hipStreamSynchronize(stream), "all-gather");
-      check(hipMemset((char*)staging[g] + nbytes, 0, chunk * G + 16 - nbytes), "hipMemset");    // the padding of the last part travelled too
+      hipStream_t copy = nullptr; hipEvent_t arrived = nullptr;
+      check(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking), "hipStreamCreate");
+      check(hipEventCreateWithFlags(&arrived, hipEventDisableTiming), "hipEventCreate");
+      check(hipDeviceSynchronize(), "hipDeviceSynchronize");                                     // the memset above ran on the null stream
+      barrier.wait();                                                                           // every GPU's buffer is ready to receive
+      for(uint64_t j = 0; j < K; j++)
+      {
+        uint64_t off, len; piece(j, g, off, len);
+        if(len > 0) { check(hipMemcpyAsync((char*)staging[g] + off, data.data() + off, len, hipMemcpyHostToDevice, copy), "H2D copy of this GPU's piece"); host_bytes_per_gpu[g] += len; }
+        check(hipEventRecord(arrived, copy), "hipEventRecord");
+        check(hipStreamWaitEvent(stream, arrived, 0), "hipStreamWaitEvent");                     // round j's collective waits for round j's piece only
+        if(ncclAllGather((char*)staging[g] + (j * G + g) * sub, (char*)staging[g] + j * G * sub, sub, ncclUint8, comm, stream) != ncclSuccess)
+        {
+          std::cerr << "mergeMultiGPU(): ncclAllGather failed" << std::endl; std::exit(EXIT_FAILURE);
+        }
+      }
+      check(hipStreamSynchronize(stream), "all-gather"); check(hipStreamSynchronize(copy), "H2D copies");
+      (void)hipEventDestroy(arrived); (void)hipStreamDestroy(copy);
+      check(hipMemset((char*)staging[g] + nbytes, 0, staged - nbytes), "hipMemset");             // the padding of the last pieces travelled too
+      check(hipDeviceSynchronize(), "hipDeviceSynchronize");
     }
     else
     {
-      for(size_type h = 0; h < G; h++)
+      for(uint64_t j = 0; j < K; j++)
       {
-        const uint64_t o = std::min<uint64_t>(h * chunk, nbytes), l = std::min<uint64_t>(chunk, nbytes - o);
-        if(h != g && l > 0) { check(hipMemcpy((char*)staging[g] + o, (const char*)staging[h] + o, l, hipMemcpyDeviceToDevice), "device-to-device copy of a peer's part"); }
+        uint64_t off, len; piece(j, g, off, len);
+        if(len > 0) { check(hipMemcpy((char*)staging[g] + off, data.data() + off, len, hipMemcpyHostToDevice), "H2D copy of this GPU's piece"); host_bytes_per_gpu[g] += len; }
+      }
+      barrier.wait();                                                                           // every piece is on its device
+      for(uint64_t j = 0; j < K; j++)
+      {
+        for(size_type h = 0; h < G; h++)
+        {
+          uint64_t off, len; piece(j, h, off, len);
+          if(h != g && len > 0) { check(hipMemcpy((char*)staging[g] + off, (const char*)staging[h] + off, len, hipMemcpyDeviceToDevice), "device-to-device copy of a peer's piece"); }
+        }
       }
     }
     barrier.wait();                                                         // nobody reads a peer's buffer any more
