@@ -48,7 +48,10 @@ def test_bench_target_record_and_traffic_check(bwtm):
     assert t["vs_cpu_baseline"]["resident"] > 30 and t["vs_cpu_baseline"]["cpu_cores"] == d["cpu_baseline"]["cores"]
     assert d["cpu_baseline"]["thread_sweep"]["best_threads"] == d["cpu_baseline"]["cores"] and len(d["cpu_baseline"]["thread_sweep"]["runs"]) >= 1
     for r in (d["roofline"], t["roofline"]):
-        assert r["traffic"] is None and "no PMC passes for" in r["traffic_profile_check"] and "design floor" in r["frac_basis"] and 0 < r["frac"] <= 1
+        # (the basis is the design floor of k_frontier_step -- or the algorithmic bytes when the whole search ran on trie nodes or as a walk,
+        # as it does under BWTM_TUNE=range_ratio=1 at this size)
+        assert r["traffic"] is None and "no PMC passes for" in r["traffic_profile_check"] and 0 <= r["frac"] <= 1
+        assert "design floor" in r["frac_basis"] or "algorithmic bytes" in r["frac_basis"]
 
 
 def test_stored_traffic_entries_describe_this_code(bwtm):
