@@ -57,6 +57,16 @@ struct IndexView
 #endif
 };
 
+// Streaming stores: data that is written once and not read again by the kernel that writes it (the next frontier's coordinates, emits, records
+// of a transcode / interleave, encoded bytes) goes past the L2 with the non-temporal hint, which leaves the cache to the lines that ARE re-used
+// (the records neighbouring elements share).  Round 5: -2.8 % on k_frontier_step from its two stores alone (profiles/r05_nt_stores_ab.txt).
+typedef unsigned int bwtm_v4u __attribute__((ext_vector_type(4)));
+__device__ inline void nt_store(uint4* p, const uint4& v) { __builtin_nontemporal_store(bwtm_v4u{v.x, v.y, v.z, v.w}, (bwtm_v4u*)p); }
+__device__ inline void nt_store(uint2* p, const uint2& v) { __builtin_nontemporal_store((unsigned long long)v.x | ((unsigned long long)v.y << 32), (unsigned long long*)p); }
+__device__ inline void nt_store(unsigned short* p, unsigned short v) { __builtin_nontemporal_store(v, p); }
+__device__ inline void nt_store(u64* p, u64 v) { __builtin_nontemporal_store(v, p); }
+__device__ inline void nt_store(u32* p, u32 v) { __builtin_nontemporal_store(v, p); }
+
 #include "kernels/common.hip.h"
 #include "kernels/transcode.hip.h"
 #include "kernels/queries.hip.h"

@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(FR_BLOCK, (VIEW ? 6 : 8)) k_frontier_step(Inde
       if(active)
       {
         u64 slot = f.emit_base[f.step] + g;
-        if(slot < f.emit_cap) { f.emit16[slot] = (unsigned short)(p & TILE_MASK); }
+        if(slot < f.emit_cap) { nt_store(&f.emit16[slot], (unsigned short)(p & TILE_MASK)); }
         else { sink_fallback(f.bits32, p); }                      // exact fallback; k_tile_build_frontier skips these slots
         if(lane != 0 && my_tile != prev_tile) { atomicMin(&f.bound_row[my_tile], (u32)g); }
       }
@@ -344,8 +344,10 @@ __global__ void __launch_bounds__(FR_BLOCK, (VIEW ? 6 : 8)) k_frontier_step(Inde
   if(active && c != 0)
   {
     u64 dst = g0 + class_base + before_waves + my_rank;
-    f.lo_next[dst] = make_uint2((u32)ni, (u32)nr);
-    if(HI) { f.hi_next[dst] = (unsigned short)(((ni >> 32) & 0xFF) | (((nr >> 32) & 0xFF) << 8)); }
+    // streaming stores (nt_store): the next frontier and the emits are not read again by this launch; past the L2 they leave it to the records
+    // (-2 to -3 ms of 92 per merge at config 2, profiles/r05_nt_stores_ab.txt; non-temporal LOADS of the coordinates on top: no change)
+    nt_store(&f.lo_next[dst], make_uint2((u32)ni, (u32)nr));
+    if(HI) { nt_store(&f.hi_next[dst], (unsigned short)(((ni >> 32) & 0xFF) | (((nr >> 32) & 0xFF) << 8))); }
   }
   if(wave == 0)
   {
