@@ -24,6 +24,7 @@ struct bwtm_fslice
     if(ctx) { ctx->live_handles--; }
     for(void* p : exported) { if(p) { (void)hipFree(p); } }
     if(host_pieces) { (void)hipHostFree(host_pieces); }
+    if(host_below) { (void)hipHostFree(host_below); }
   }
   bwtm_fslice(const bwtm_fslice&) = delete; bwtm_fslice& operator=(const bwtm_fslice&) = delete;
   const bwtm_index* a = nullptr; const bwtm_index* b = nullptr; bwtm_ra* ra = nullptr;
@@ -38,6 +39,8 @@ struct bwtm_fslice
   SlicePiece* host_pieces = nullptr; u32 max_pieces = 0;
   u64 n_in = 0;
   DevBuf emit16, emit_base, bound; u64 emit_cap = 0, EPOCH = 1, in_epoch = 0, epoch_used = 0;
+  // fixed cuts (bwtm_fslice_set_cuts): the cuts on the device, the counts below them of the last outputs (device and page-locked host)
+  DevBuf cuts, below; u64* host_below = nullptr; u32 ncuts = 0;
 };
 
 namespace
@@ -47,6 +50,12 @@ int fslice_scan_outputs(bwtm_fslice* fs)
 {
   TRY(device_scan<0>(fs->seg_len_out.as<u64>(), fs->out_prefix, fs->nseg + 1));
   for(u32 c = 0; c <= 5; c++) { TRY(fetch_u64(fs->out_prefix + (u64)c * fs->nbl, 96 + c)); }        // class boundaries -> totals (bwtm_fslice_export)
+  if(fs->ncuts > 0)
+  {
+    LAUNCH("cut_counts", k_cut_counts, 1, BLOCK_THREADS, (const uint2*)fs->lo_out, (const unsigned short*)fs->hi_out, (const u64*)fs->out_prefix, (const u64*)fs->seg_phys_out,
+      fs->nbl, fs->cuts.as<const u64>(), fs->ncuts, fs->below.as<u64>());
+    HIP_TRY(hipMemcpyAsync(fs->host_below, fs->below.p, 5ull * fs->ncuts * sizeof(u64), hipMemcpyDeviceToHost, CTX.stream));
+  }
   return BWTM_OK;
 }
 
@@ -136,6 +145,11 @@ extern "C" int bwtm_fslice_export(bwtm_fslice* fs, bwtm_fslice_view* view)
   HIP_TRY(hipStreamSynchronize(CTX.stream));
   for(u32 c = 0; c < 5; c++) { fs->totals[c] = CTX.host_scratch[96 + c + 1] - CTX.host_scratch[96 + c]; view->totals[c] = fs->totals[c]; }
   view->lo = fs->lo_out; view->hi = fs->hi_out; view->prefix = fs->out_prefix; view->phys = fs->seg_phys_out; view->blocks = fs->nbl;
+  for(u32 c = 0; c < 5; c++)
+  {
+    for(u32 k = 0; k <= BWTM_X_MAX_PARTS; k++) { view->below[c][k] = (k < fs->ncuts ? fs->host_below[c * fs->ncuts + k] : fs->totals[c]); }
+    if(fs->ncuts > 0) { view->below[c][0] = 0; view->below[c][fs->ncuts - 1] = fs->totals[c]; }      // R_0 = 0, R_parts = everything
+  }
   return BWTM_OK;
 }
 
@@ -219,4 +233,102 @@ extern "C" int bwtm_fslice_finish(bwtm_fslice* fs)
   fs->in_epoch = 0; fs->epoch_used = 0;
   HIP_TRY(hipStreamSynchronize(CTX.stream));
   return BWTM_OK;
+}
+
+extern "C" int bwtm_x_device_scan(const uint64_t* in, uint64_t* out, uint64_t n, uint64_t narrays, int op)
+{
+  if(!in || !out || n == 0 || narrays == 0 || (op != 0 && op != 1)) { return fail(BWTM_EINVAL, "bwtm_x_device_scan: bad argument"); }
+  ENTER(nullptr);
+  DevBuf buf; TRY(buf.alloc(n * narrays * sizeof(u64)));
+  HIP_TRY(hipMemcpyAsync(buf.p, in, n * narrays * sizeof(u64), hipMemcpyHostToDevice, CTX.stream));
+  if(op == 0) { TRY(device_scan_multi<0>(buf.as<u64>(), buf.as<u64>(), n, narrays, n)); }
+  else { TRY(device_scan_multi<1>(buf.as<u64>(), buf.as<u64>(), n, narrays, n)); }
+  HIP_TRY(hipMemcpyAsync(out, buf.p, n * narrays * sizeof(u64), hipMemcpyDeviceToHost, CTX.stream));
+  HIP_TRY(hipStreamSynchronize(CTX.stream));
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_fslice_set_cuts(bwtm_fslice* fs, const uint64_t* r_cuts, int parts)
+{
+  if(!fs || !r_cuts || parts < 1 || parts > BWTM_X_MAX_PARTS) { return fail(BWTM_EINVAL, "bwtm_fslice_set_cuts: bad argument (at most %d parts)", BWTM_X_MAX_PARTS); }
+  for(int k = 0; k < parts; k++) { if(r_cuts[k] > r_cuts[k + 1] && k + 1 < parts) { return fail(BWTM_EINVAL, "bwtm_fslice_set_cuts: cuts must not decrease"); } }
+  if(r_cuts[0] != 0) { return fail(BWTM_EINVAL, "bwtm_fslice_set_cuts: the first cut is 0"); }
+  ENTER(fs->ctx);
+  if((u32)(5 * parts) > fs->max_pieces) { return fail(BWTM_EINVAL, "bwtm_fslice_set_cuts: more parts than the slice was created for"); }
+  fs->ncuts = (u32)parts + 1;
+  TRY(fs->cuts.alloc(fs->ncuts * sizeof(u64))); TRY(fs->below.alloc(5ull * fs->ncuts * sizeof(u64), true));
+  if(!fs->host_below) { HIP_TRY(hipHostMalloc((void**)&fs->host_below, 5ull * (BWTM_X_MAX_PARTS + 1) * sizeof(u64), hipHostMallocDefault)); }
+  std::memset(fs->host_below, 0, 5ull * (BWTM_X_MAX_PARTS + 1) * sizeof(u64));
+  u64 host_cuts[BWTM_X_MAX_PARTS + 1];
+  for(int k = 0; k <= parts; k++) { host_cuts[k] = (k == parts ? ~0ull : r_cuts[k]); }
+  HIP_TRY(hipMemcpyAsync(fs->cuts.p, host_cuts, fs->ncuts * sizeof(u64), hipMemcpyHostToDevice, CTX.stream));
+  HIP_TRY(hipStreamSynchronize(CTX.stream));                       // host_cuts lives on this stack
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_fslice_gather_cut(bwtm_fslice* fs, const bwtm_fslice_view* views, int parts, int part)
+{
+  if(!fs || !views || parts < 1 || part < 0 || part >= parts) { return fail(BWTM_EINVAL, "bwtm_fslice_gather_cut: bad argument"); }
+  ENTER(fs->ctx);
+  if(fs->ncuts != (u32)parts + 1) { return fail(BWTM_EINVAL, "bwtm_fslice_gather_cut: bwtm_fslice_set_cuts was not called for %d parts", parts); }
+  // The global order of the frontier is (class, GPU, block) and it is sorted by position: this GPU's elements are, in every (class, GPU)
+  // piece, the range between the piece's counts below this GPU's two cuts.
+  u32 np = 0; u64 n_in = 0;
+  for(u32 c = 0; c < 5; c++)
+  {
+    for(int h = 0; h < parts; h++)
+    {
+      const u64 lo_x = views[h].below[c][part], hi_x = views[h].below[c][part + 1];
+      if(lo_x > hi_x || hi_x > views[h].totals[c]) { return fail(BWTM_EINVAL, "bwtm_fslice_gather_cut: counts of GPU %d, class %u are not monotone", h, c); }
+      if(lo_x < hi_x)
+      {
+        SlicePiece pc;
+        pc.lo = (const uint2*)views[h].lo; pc.hi = (const unsigned short*)views[h].hi;
+        pc.prefix = (const u64*)views[h].prefix; pc.phys = (const u64*)views[h].phys;
+        pc.seg_first = (u64)c * views[h].blocks; pc.seg_count = views[h].blocks;
+        pc.src_first = lo_x; pc.count = hi_x - lo_x; pc.dst_first = n_in;
+        fs->host_pieces[np++] = pc;
+        n_in += hi_x - lo_x;
+      }
+    }
+  }
+  if(n_in > fs->cap) { return fail(BWTM_EINVAL, "bwtm_fslice_gather_cut: %llu elements fall into this GPU's range, capacity %llu", (unsigned long long)n_in, (unsigned long long)fs->cap); }
+  fs->n_in = n_in;
+  if(n_in == 0) { return BWTM_OK; }
+  HIP_TRY(hipMemcpyAsync(fs->pieces.p, fs->host_pieces, (u64)np * sizeof(SlicePiece), hipMemcpyHostToDevice, CTX.stream));
+  LAUNCH("frontier_gather", k_frontier_gather, div_up(fs->n_in, BLOCK_THREADS), BLOCK_THREADS, fs->pieces.as<const SlicePiece>(), np, fs->n_in,
+    fs->lo_in.as<uint2>(), fs->hi_in.as<unsigned short>());
+  HIP_TRY(hipStreamSynchronize(CTX.stream));                       // the peers may overwrite their outputs once every GPU has returned from here
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_x_index_window(const bwtm_index* whole, uint64_t pos_first, uint64_t pos_last, bwtm_index** out)
+{
+  if(!whole || !out || pos_first > pos_last) { return fail(BWTM_EINVAL, "bwtm_x_index_window: bad argument"); }
+  ENTER(whole->ctx);
+  WHOLE_INDEX(whole, "bwtm_x_index_window");
+  if(whole->nrecs == 0 || !whole->recs.p) { return fail(BWTM_EINVAL, "bwtm_x_index_window: the index holds no records"); }
+  const u64 q0 = std::min<u64>(pos_first >> REC_SHIFT, whole->nrecs - 1), q1 = std::min<u64>(pos_last >> REC_SHIFT, whole->nrecs - 1);
+  bwtm_index* w = new bwtm_index();
+  auto body = [&]() -> int
+  {
+    w->n = whole->n; w->m = whole->m; w->nrecs = whole->nrecs; w->nsup = whole->nsup;
+    for(int c = 0; c < 8; c++) { w->C[c] = whole->C[c]; }
+    w->windowed = true; w->win_first = q0; w->win_count = q1 - q0 + 1;
+    TRY(w->recs.alloc(w->win_count * 64));
+    HIP_TRY(hipMemcpyAsync(w->recs.p, (const char*)whole->recs.p + (q0 << 6), w->win_count * 64, hipMemcpyDeviceToDevice, CTX.stream));
+    TRY(w->sup.alloc(whole->nsup * SUP_STRIDE * sizeof(u64)));
+    HIP_TRY(hipMemcpyAsync(w->sup.p, whole->sup.p, whole->nsup * SUP_STRIDE * sizeof(u64), hipMemcpyDeviceToDevice, CTX.stream));
+    return BWTM_OK;
+  };
+  int rc = body();
+  if(rc != BWTM_OK) { delete w; return rc; }
+  *out = w;
+  return BWTM_OK;
+}
+
+extern "C" uint64_t bwtm_x_index_record_bytes(const bwtm_index* x)
+{
+  if(!x) { return 0; }
+  return (x->windowed ? x->win_count : x->nrecs) * 64;
 }

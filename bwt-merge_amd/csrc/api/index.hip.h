@@ -32,6 +32,11 @@ struct bwtm_index
   mutable DevBuf sview, vsup;         // the search view (built on demand by the frontier search, dropped with the records)
   mutable u64 nview = 0;
   mutable bool view_ready = false;    // set after both kernels that fill the view were queued
+  // A WINDOW of another index's records (bwtm_x_index_window; the partitioned search): `recs` holds the records
+  // [win_first, win_first + win_count) only, and view() hands the kernels a base pointer shifted back by win_first records, so that
+  // absolute record numbers address it unchanged.  Positions outside the window must never be queried: only bwtm_fslice_* take such a handle.
+  u64 win_first = 0, win_count = 0;
+  bool windowed = false;
 #endif
 
   IndexView view() const
@@ -42,10 +47,18 @@ struct bwtm_index
     for(int c = 0; c < 8; c++) { v.C[c] = C[c]; }
 #ifdef BWTM_EXPERIMENTAL
     v.view = (view_ready ? sview.as<const uint4>() : nullptr); v.vsup = (view_ready ? vsup.as<const u64>() : nullptr); v.nview = (view_ready ? nview : 0);
+    if(windowed) { v.recs = (const uint4*)((const char*)recs.p - (win_first << 6)); }        // 64 bytes per record
 #endif
     return v;
   }
 };
+
+// Entry points that query arbitrary positions refuse a window of an index (experimental build; nothing in the product build).
+#ifdef BWTM_EXPERIMENTAL
+#define WHOLE_INDEX(x, who) if((x)->windowed) { return fail(BWTM_EINVAL, who ": a window of an index (bwtm_x_index_window) only serves bwtm_fslice_*"); }
+#else
+#define WHOLE_INDEX(x, who)
+#endif
 
 namespace
 {
@@ -634,6 +647,7 @@ extern "C" int bwtm_index_drop_native(bwtm_index* x)
 extern "C" int bwtm_index_encode(bwtm_index* x)
 {
   if(!x) { return fail(BWTM_EINVAL, "null index"); }
+  WHOLE_INDEX(x, "bwtm_index_encode");
   ENTER(x->ctx);
   return encode_blocking(x);
 }
@@ -691,6 +705,7 @@ extern "C" int bwtm_index_download_samples_compact(bwtm_index* x, int width, voi
 extern "C" int bwtm_rank_batch(const bwtm_index* x, const uint64_t* positions, const uint8_t* comps, uint64_t count, uint64_t* out_ranks)
 {
   if(!x || !positions || !comps || !out_ranks) { return fail(BWTM_EINVAL, "bwtm_rank_batch: null argument"); }
+  WHOLE_INDEX(x, "bwtm_rank_batch");
   ENTER(x->ctx);
   if(count == 0) { return BWTM_OK; }
   DevBuf dp, dc, dr;
@@ -706,6 +721,7 @@ extern "C" int bwtm_rank_batch(const bwtm_index* x, const uint64_t* positions, c
 extern "C" int bwtm_inverse_select_batch(const bwtm_index* x, const uint64_t* positions, uint64_t count, uint64_t* out_ranks, uint8_t* out_comps)
 {
   if(!x || !positions || !out_ranks || !out_comps) { return fail(BWTM_EINVAL, "bwtm_inverse_select_batch: null argument"); }
+  WHOLE_INDEX(x, "bwtm_inverse_select_batch");
   ENTER(x->ctx);
   if(count == 0) { return BWTM_OK; }
   DevBuf dp, dc, dr;
@@ -721,6 +737,7 @@ extern "C" int bwtm_inverse_select_batch(const bwtm_index* x, const uint64_t* po
 extern "C" int bwtm_find_batch(const bwtm_index* x, const uint8_t* patterns, const uint64_t* offsets, uint64_t count, uint64_t* out_sp, uint64_t* out_ep)
 {
   if(!x || !offsets || !out_sp || !out_ep) { return fail(BWTM_EINVAL, "bwtm_find_batch: null argument"); }
+  WHOLE_INDEX(x, "bwtm_find_batch");
   ENTER(x->ctx);
   if(count == 0) { return BWTM_OK; }
   u64 total = offsets[count];
@@ -739,6 +756,7 @@ extern "C" int bwtm_find_batch(const bwtm_index* x, const uint8_t* patterns, con
 extern "C" int bwtm_extract(const bwtm_index* x, uint64_t first, uint64_t count, uint8_t* out)
 {
   if(!x || !out) { return fail(BWTM_EINVAL, "bwtm_extract: null argument"); }
+  WHOLE_INDEX(x, "bwtm_extract");
   ENTER(x->ctx);
   if(first + count > x->n) { return fail(BWTM_EINVAL, "bwtm_extract: range past the end"); }   // bwt.h:137
   if(count == 0) { return BWTM_OK; }

@@ -55,6 +55,7 @@ int interleave_impl(const bwtm_index* a, const bwtm_index* b, bwtm_ra* ra, bwtm_
 
 int check_interleave_args(const bwtm_index* a, const bwtm_index* b, const bwtm_ra* ra, bool allow_ranged = false)
 {
+  WHOLE_INDEX(a, "bwtm_interleave"); WHOLE_INDEX(b, "bwtm_interleave");
   if(!ra->finalized) { return fail(BWTM_EINVAL, "bwtm_interleave: rank array not finalized"); }
   if(ra->ranged && !allow_ranged) { return fail(BWTM_EINVAL, "bwtm_interleave: the rank array was finalized for an output range (bwtm_interleave_range takes it)"); }
   if(ra->na != a->n || ra->nb != b->n) { return fail(BWTM_EINVAL, "bwtm_interleave: rank array was created for other inputs"); }
@@ -286,6 +287,7 @@ extern "C" int bwtm_merge(const bwtm_index* a, const bwtm_index* b, bwtm_index**
 {
   if(!a || !b || !out) { return fail(BWTM_EINVAL, "bwtm_merge: null argument"); }
   if(a->ctx != b->ctx) { return fail(BWTM_EINVAL, "bwtm_merge: the two indexes live in different contexts"); }
+  WHOLE_INDEX(a, "bwtm_merge"); WHOLE_INDEX(b, "bwtm_merge");
   ENTER(a->ctx);
   bwtm_index* aa = const_cast<bwtm_index*>(a); bwtm_index* bb = const_cast<bwtm_index*>(b);
   bwtm_index* x = nullptr;

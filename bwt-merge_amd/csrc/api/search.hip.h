@@ -568,6 +568,7 @@ extern "C" int bwtm_search(const bwtm_index* a, const bwtm_index* b, uint64_t se
   if(!a || !b || !ra) { return fail(BWTM_EINVAL, "bwtm_search: null argument"); }
   if(a->ctx != ra->ctx || b->ctx != ra->ctx) { return fail(BWTM_EINVAL, "bwtm_search: handles of different contexts"); }
   ENTER(ra->ctx);
+  WHOLE_INDEX(a, "bwtm_search"); WHOLE_INDEX(b, "bwtm_search");
   if(ra->na != a->n || ra->nb != b->n) { return fail(BWTM_EINVAL, "bwtm_search: rank array was created for other inputs"); }
   if(ra->finalized) { return fail(BWTM_EINVAL, "bwtm_search: rank array already finalized"); }
   if(b->m == 0 || seq_first > seq_last) { return BWTM_OK; }       // empty range (utils.h:80-83)

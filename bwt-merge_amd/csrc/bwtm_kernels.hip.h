@@ -78,6 +78,9 @@ __device__ inline void nt_store(u32* p, u32 v) { __builtin_nontemporal_store(v, 
 #include "kernels/search_view.hip.h"
 #endif
 #include "kernels/search_frontier.hip.h"
+#ifdef BWTM_EXPERIMENTAL
+#include "kernels/search_partition.hip.h"
+#endif
 #include "kernels/search_range.hip.h"
 #include "kernels/interleave.hip.h"
 #include "kernels/encoder.hip.h"

@@ -5,6 +5,9 @@ process that has loaded THAT library as its bwtm library (BWTM_LIB=<path of libb
 (bwt_merge_amd, capi.py, dist.py) exposes none of these names -- tests/test_c_abi.py checks both directions.
 
   FSlice, FSliceView, search_sliced   the frontier search in position slices, one per GPU
+  partition_cuts, index_window, search_partitioned   the same search over PARTITIONED records: fixed cuts, every GPU holds one window of
+                                      each index and the elements travel
+  device_scan                         test hook of the library's device scan
   (the two-plane search view has no entry point of its own: it is the `search_view` knob of the experimental build)
 """
 import ctypes as C
@@ -25,6 +28,11 @@ EXPERIMENTAL_SYMBOLS = [
     ("bwtm_fslice_gather", C.c_int, [vp, vp, C.c_int, u64, u64]),
     ("bwtm_fslice_advance", C.c_int, [vp]),
     ("bwtm_fslice_finish", C.c_int, [vp]),
+    ("bwtm_x_device_scan", C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), u64, u64, C.c_int]),
+    ("bwtm_x_index_window", C.c_int, [vp, u64, u64, C.POINTER(vp)]),
+    ("bwtm_x_index_record_bytes", u64, [vp]),
+    ("bwtm_fslice_set_cuts", C.c_int, [vp, C.POINTER(u64), C.c_int]),
+    ("bwtm_fslice_gather_cut", C.c_int, [vp, vp, C.c_int, C.c_int]),
 ]
 EXPERIMENTAL_LIB_PATH = os.path.join(HERE, "libbwtm_experimental.so")
 if not os.path.exists(EXPERIMENTAL_LIB_PATH):
@@ -53,8 +61,11 @@ def _bind():
         _bound = True
 
 
+MAX_PARTS = 16                  # BWTM_X_MAX_PARTS
+
+
 class FSliceView(C.Structure):
-    _fields_ = [("lo", vp), ("hi", vp), ("prefix", vp), ("phys", vp), ("blocks", u64), ("totals", u64 * 5)]
+    _fields_ = [("lo", vp), ("hi", vp), ("prefix", vp), ("phys", vp), ("blocks", u64), ("totals", u64 * 5), ("below", (u64 * (MAX_PARTS + 1)) * 5)]
 
 
 class FSlice:
@@ -86,6 +97,13 @@ class FSlice:
     def gather(self, views, parts, first, last):
         check(lib().bwtm_fslice_gather(self.h, C.byref(views), parts, first, last))
 
+    def set_cuts(self, r_cuts):
+        arr = (u64 * len(r_cuts))(*[int(x) for x in r_cuts])
+        check(lib().bwtm_fslice_set_cuts(self.h, arr, len(r_cuts) - 1))
+
+    def gather_cut(self, views, parts, part):
+        check(lib().bwtm_fslice_gather_cut(self.h, C.byref(views), parts, part))
+
     def advance(self):
         check(lib().bwtm_fslice_advance(self.h))
 
@@ -97,6 +115,16 @@ def slice_range(total, part, parts):
     """Contiguous share `part` of `total` frontier elements: [first, last)."""
     per = (total + parts - 1) // parts
     return min(total, part * per), min(total, (part + 1) * per)
+
+
+def device_scan(values, narrays=1, op=0):
+    """Exclusive scan (op 0 = sum, 1 = max) of `narrays` equally long u64 arrays laid end to end, by the library's device scan."""
+    import numpy as np
+    _bind()
+    v = np.ascontiguousarray(values, dtype=np.uint64)
+    out = np.empty_like(v)
+    check(lib().bwtm_x_device_scan(v.ctypes.data_as(C.POINTER(C.c_uint64)), out.ctypes.data_as(C.POINTER(C.c_uint64)), v.size // narrays, narrays, op))
+    return out
 
 
 def search_sliced(pkg, indexes, ras, sequences, enter=None):
@@ -140,3 +168,87 @@ def search_sliced(pkg, indexes, ras, sequences, enter=None):
     return steps
 
 
+
+
+def index_window(index, pos_first, pos_last):
+    """The records of the positions [pos_first, pos_last] of `index` as a handle of their own (bwtm_x_index_window): only for FSlice / RankArray."""
+    _bind()
+    out = vp()
+    check(lib().bwtm_x_index_window(index.h, int(pos_first), int(pos_last), C.byref(out)))
+    return capi.Index(out)
+
+
+def index_record_bytes(index):
+    _bind()
+    return int(lib().bwtm_x_index_record_bytes(index.h))
+
+
+def partition_cuts(a, b, parts, k=4):
+    """Cuts of the merged order at k-mer boundaries that balance the POSITIONS (a's + b's) of the parts: returns (I, R), two lists of
+    parts + 1 ranks with I[0] = R[0] = 0, I[parts] = a.bases, R[parts] = b.bases.  (I[g], R[g]) = the number of a's / b's suffixes below the
+    g-th chosen k-mer w: sp(c w) = C[c] + rank_c(sp(w)), the insertion point of backward search, also for k-mers that do not occur."""
+    import numpy as np
+
+    def insertion_points(x):
+        C_of = [int(x.find([[c]])[0][0]) for c in range(1, 6)]
+        sp = np.zeros(1, dtype=np.uint64)                           # the empty string
+        for _ in range(k):
+            nxt = []
+            for c in range(1, 6):                                    # c w for every w, c-major: lexicographic order is kept
+                r = x.rank(sp, np.full(sp.size, c, dtype=np.uint8))
+                nxt.append(np.uint64(C_of[c - 1]) + r)
+            sp = np.concatenate(nxt)
+        return sp
+
+    spa, spb = insertion_points(a), insertion_points(b)
+    na, nb = int(a.bases), int(b.bases)
+    both = spa.astype(np.float64) + spb.astype(np.float64)
+    I, R = [0], [0]
+    for g in range(1, parts):
+        j = int(np.argmin(np.abs(both - g * (na + nb) / parts)))
+        I.append(max(I[-1], int(spa[j]))); R.append(max(R[-1], int(spb[j])))
+    I.append(na); R.append(nb)
+    return I, R
+
+
+def search_partitioned(pkg, windows, ras, sequences, r_cuts, enter=None):
+    """The frontier search over partitioned records, driven from ONE host thread: windows[g] = (window of A, window of B) as GPU g holds
+    them (index_window over the cuts of partition_cuts), ras[g] = its rank array, r_cuts = the B ranks of the cuts.  Every GPU advances the
+    elements whose coordinates fall into its windows and ends up with the bits of its own output range.  Returns (LF steps, the largest
+    number of elements any GPU held in a step, elements advanced per GPU)."""
+    parts = len(windows)
+    cap = sequences + 1                                             # the first steps sit on few GPUs: all roots lie below the first k-mer
+    views = (FSliceView * parts)()
+    fs = []
+    for g in range(parts):
+        if enter:
+            enter(g)
+        f = FSlice(windows[g][0], windows[g][1], ras[g], cap, parts)
+        f.set_cuts(r_cuts)
+        first, last = min(int(r_cuts[g]), sequences), min(int(r_cuts[g + 1]), sequences)
+        f.seed(first, last - first)
+        f.export(views[g])
+        fs.append(f)
+    steps, largest, work = 0, 0, [0] * parts
+    while True:
+        total = sum(int(views[h].totals[c]) for h in range(parts) for c in range(5))
+        if total == 0:
+            break
+        for g in range(parts):                              # every GPU pulls the elements of its position range from all GPUs' outputs ...
+            if enter:
+                enter(g)
+            fs[g].gather_cut(views, parts, g)
+            held = sum(int(views[h].below[c][g + 1]) - int(views[h].below[c][g]) for h in range(parts) for c in range(5))
+            largest = max(largest, held); work[g] += held
+        for g in range(parts):                              # ... and only then overwrites its own outputs
+            if enter:
+                enter(g)
+            fs[g].advance()
+            fs[g].export(views[g])
+        steps += 1
+    for g in range(parts):
+        if enter:
+            enter(g)
+        fs[g].finish()
+        fs[g].free()
+    return steps, largest, work

@@ -28,6 +28,7 @@ extern "C" {
    completes the GPU's bits in its rank array, and the rank arrays are combined as for bwtm_search() (all-reduce / bwtm_ra_or_from).
    A view holds raw device pointers into the exporting GPU's memory (hipMalloc): contexts of one device can always read them,
    other devices need peer access. */
+#define BWTM_X_MAX_PARTS 16
 typedef struct bwtm_fslice bwtm_fslice;
 typedef struct
 {
@@ -35,6 +36,7 @@ typedef struct
   const void* prefix; const void* phys;      /* its segment tables: 5 * blocks + 1 entries each */
   uint64_t blocks;
   uint64_t totals[5];                        /* elements per class (the symbols 1..5; the seed holds its sequences in class 0) */
+  uint64_t below[5][BWTM_X_MAX_PARTS + 1];   /* after bwtm_fslice_set_cuts(): elements of class c whose B coordinate lies below cut k */
 } bwtm_fslice_view;
 /* `capacity` = the largest slice this GPU will be given (ceil(sequences / parts) + 1 is enough: the frontier only shrinks). */
 int bwtm_fslice_create(const bwtm_index* a, const bwtm_index* b, bwtm_ra* ra, uint64_t capacity, int parts, bwtm_fslice** out);
@@ -45,6 +47,31 @@ int bwtm_fslice_export(bwtm_fslice* fs, bwtm_fslice_view* view);                
 int bwtm_fslice_gather(bwtm_fslice* fs, const bwtm_fslice_view* views, int parts, uint64_t first, uint64_t last);   /* synchronizes */
 int bwtm_fslice_advance(bwtm_fslice* fs);
 int bwtm_fslice_finish(bwtm_fslice* fs);
+
+/* PARTITIONED RECORDS (the search half, a functional prototype).  The sliced search above cuts the frontier into
+   equal shares, so a GPU's slice wanders over the whole of A and B and every GPU must hold all records.  With FIXED cuts every GPU keeps
+   one window of each index and the frontier's elements travel to the GPU that owns their positions:
+     - a cut is a pair (I_k, R_k) = (suffixes of a below w_k, suffixes of b below w_k) for some string w_k (k-mers: ranks by backward
+       search, e.g. bwtm_rank_batch); I_0 = R_0 = 0; both ranks are monotone along the merged order, so an element with R_g <= r < R_g+1
+       has I_g <= i <= I_g+1;
+     - GPU g holds bwtm_x_index_window(a, I_g, I_g+1) and bwtm_x_index_window(b, R_g, R_g+1): the records of those positions only,
+       addressed by absolute record numbers (1 / parts of the records per GPU; the super tables are whole, they are small);
+     - bwtm_fslice_set_cuts(fs, R_0 .. R_parts) makes every export count, per class, its output elements below every cut
+       (bwtm_fslice_view.below), and bwtm_fslice_gather_cut(fs, views, parts, g) pulls exactly GPU g's elements from all peers;
+     - the roots of the sequences (b coordinate = sequence number) are seeded on the GPU that owns them: bwtm_fslice_seed with the
+       sequences [R_g, R_g+1) that exist.
+   The loop is the sliced search's with bwtm_fslice_gather_cut in place of bwtm_fslice_gather.  Every GPU sets the bits of its own
+   output range [I_g + R_g, I_g+1 + R_g+1) only: no bitvector exchange is needed afterwards (the prototype keeps whole-length bitvectors).
+   A window handle is only valid as an argument of bwtm_fslice_create / bwtm_ra_create; every other entry point refuses it. */
+int bwtm_x_index_window(const bwtm_index* whole, uint64_t pos_first, uint64_t pos_last, bwtm_index** out);
+uint64_t bwtm_x_index_record_bytes(const bwtm_index* index);       /* bytes of records the handle holds (a window: its share) */
+int bwtm_fslice_set_cuts(bwtm_fslice* fs, const uint64_t* r_cuts, int parts);      /* r_cuts[0 .. parts]: R_0 = 0 <= R_1 <= ... ; R_parts is ignored (= everything) */
+int bwtm_fslice_gather_cut(bwtm_fslice* fs, const bwtm_fslice_view* views, int parts, int part);   /* synchronizes */
+
+/* Test hook of the library's device scan (every table of the path -- segment prefixes, node offsets, block and sample tables -- goes
+   through it): exclusive scan of `narrays` arrays of n items each, laid end to end in host memory; op 0 = sum, 1 = max; runs in the
+   calling thread's current context. */
+int bwtm_x_device_scan(const uint64_t* in, uint64_t* out, uint64_t n, uint64_t narrays, int op);
 
 
 #ifdef __cplusplus

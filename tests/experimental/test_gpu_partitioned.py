@@ -1,0 +1,144 @@
+"""The frontier search over PARTITIONED records (include/bwtm_experimental.h: bwtm_x_index_window, bwtm_fslice_set_cuts, bwtm_fslice_gather_cut;
+DESIGN.md section 6.3): G contexts of one GPU stand in for G GPUs.  Every one holds a window of A's and of B's records between fixed cuts
+(k-mer boundaries of the merged order) and advances the elements whose coordinates fall into its windows; elements travel between the
+GPUs at every step.  The union of the rank arrays must be the oracle's rank array, bit for bit, and every GPU's bits must lie inside its
+own output range."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(bwtm):
+    bwtm.init(0)
+    from bwt_merge_amd import experimental
+    assert experimental.loaded(), "these tests need BWTM_LIB=libbwtm_experimental.so"
+    yield bwtm
+    bwtm.make_default_current()
+    bwtm.trim()
+
+
+def oracle_ra(oracle, a, b):
+    ranks, counts, _ = oracle.search(a, b, threads=2)
+    return oracle.ra_from_runs(ranks, counts)
+
+
+def set_positions(words):
+    nz = np.nonzero(words)[0]
+    if nz.size == 0:
+        return np.zeros(0, dtype=np.uint64)
+    sh = np.arange(64, dtype=np.uint64)
+    on = ((words[nz][:, None] >> sh[None, :]) & np.uint64(1)).astype(bool)
+    return (nz.astype(np.uint64)[:, None] * np.uint64(64) + sh[None, :])[on]
+
+
+def run_partitioned(gpu, oracle, a, b, parts, k, contexts=True, combine=False):
+    from bwt_merge_amd.experimental import index_record_bytes, index_window, partition_cuts, search_partitioned
+    ctxs = [gpu.Context(0) for _ in range(parts)] if contexts else []
+
+    def enter(g):
+        if contexts:
+            ctxs[g].make_current()
+
+    enter(0)
+    A = gpu.Index.upload(a.data, a.sequences, a.bases); B = gpu.Index.upload(b.data, b.sequences, b.bases)
+    I, R = partition_cuts(A, B, parts, k)
+    assert I[0] == 0 and R[0] == 0 and I[-1] == a.bases and R[-1] == b.bases
+    assert all(I[g] <= I[g + 1] and R[g] <= R[g + 1] for g in range(parts))
+    whole_bytes = index_record_bytes(A) + index_record_bytes(B)
+    A.free(); B.free()
+    windows, ras, held = [], [], []
+    for g in range(parts):
+        enter(g)
+        A = gpu.Index.upload(a.data, a.sequences, a.bases); B = gpu.Index.upload(b.data, b.sequences, b.bases)
+        wa, wb = index_window(A, I[g], I[g + 1]), index_window(B, R[g], R[g + 1])
+        A.free(); B.free()                                              # only the windows stay
+        windows.append((wa, wb)); ras.append(gpu.RankArray(wa, wb)); held.append(index_record_bytes(wa) + index_record_bytes(wb))
+    steps, largest, work = search_partitioned(gpu, windows, ras, b.sequences, R, enter if contexts else None)
+    bits, runs = [], None
+    if combine:                                                         # one context: OR of the disjoint bit sets, then the reference's own form
+        for g in range(1, parts):
+            ras[0].or_from(ras[g])
+        ras[0].finalize()
+        runs = ras[0].runs()
+    else:
+        for g in range(parts):
+            enter(g)
+            bits.append(set_positions(ras[g].bits()))                   # positions of this GPU's set bits in the merged order
+    for g in range(parts):
+        enter(g)
+        ras[g].free(); windows[g][0].free(); windows[g][1].free()
+    gpu.make_default_current()
+    for c in ctxs:
+        c.destroy()
+    return dict(I=I, R=R, bits=bits, runs=runs, steps=steps, largest=largest, work=work, held=held, whole=whole_bytes)
+
+
+@pytest.mark.parametrize("parts,k", [(1, 2), (2, 1), (3, 3), (5, 4), (8, 4), (16, 3)])
+def test_partitioned_search_equals_oracle(gpu, oracle, parts, k):
+    ta = oracle.generate_reads(9400, 2500, 90)
+    tb = np.concatenate([oracle.generate_reads(9500 + j, 400, int(n)) for j, n in enumerate([1, 17, 60, 100, 139, 33])])
+    a, b = oracle.FMI.from_text(ta), oracle.FMI.from_text(tb)
+    expect = oracle_ra(oracle, a, b)
+    out = run_partitioned(gpu, oracle, a, b, parts, k)
+    assert out["steps"] == 140
+    got = np.sort(np.concatenate(out["bits"]))
+    assert got.size == b.bases
+    assert np.array_equal(got, expect + np.arange(b.bases, dtype=np.uint64))          # position of b's suffix r in the merged order = RA[r] + r
+    # every GPU set exactly the bits of its own output range [I_g + R_g, I_g+1 + R_g+1): nothing to exchange afterwards
+    for g in range(parts):
+        lo, hi = out["I"][g] + out["R"][g], out["I"][g + 1] + out["R"][g + 1]
+        assert out["bits"][g].size == out["R"][g + 1] - out["R"][g], g
+        if out["bits"][g].size:
+            assert lo <= int(out["bits"][g].min()) and int(out["bits"][g].max()) < hi, g
+    # records are partitioned, not replicated: all windows together hold the records once (+ at most two boundary records per window)
+    assert sum(out["held"]) <= out["whole"] + parts * 4 * 64
+    assert sum(out["work"]) == b.bases                                # every element of every step was advanced by exactly one GPU
+
+
+def test_cuts_are_insertion_points_of_kmers(gpu, oracle):
+    """partition_cuts' ranks against a direct count over the sorted suffixes of a small collection."""
+    from bwt_merge_amd.experimental import partition_cuts
+    ta = oracle.generate_reads(9601, 300, 40); tb = oracle.generate_reads(9602, 200, 55)
+    a, b = oracle.FMI.from_text(ta), oracle.FMI.from_text(tb)
+    A = gpu.Index.upload(a.data, a.sequences, a.bases); B = gpu.Index.upload(b.data, b.sequences, b.bases)
+    I, R = partition_cuts(A, B, 4, 3)
+    ra = oracle_ra(oracle, a, b)                                        # ra[r] = number of a's suffixes below b's suffix of rank r
+    assert len(set(zip(I, R))) >= 4                                      # 125 candidate 3-mers: four parts get four different cuts
+    for g in range(1, 4):
+        # (I_g, R_g) is a point of the merged order: b's suffixes from R_g on lie above I_g of a's suffixes, those before it below
+        if R[g] < b.bases:
+            assert int(ra[R[g]]) >= I[g]
+        if R[g] > 0:
+            assert int(ra[R[g] - 1]) <= I[g]
+    A.free(); B.free()
+
+
+def test_partitioned_search_wide_coordinates(gpu, oracle):
+    """Coordinates beyond 2^32: the high bytes travel through the cut counts and the gather."""
+    small_a = oracle.FMI.from_text(oracle.generate_reads(9301, 600, 60)); small_b = oracle.FMI.from_text(oracle.generate_reads(9302, 500, 70))
+    a = oracle.FMI.from_runs(small_a.symbols.astype(np.uint64), np.full(small_a.symbols.size, 120000, dtype=np.uint64))
+    assert a.bases > (1 << 32)
+    b = oracle.FMI.from_runs(small_b.symbols.astype(np.uint64), np.full(small_b.symbols.size, 2000, dtype=np.uint64))
+    ranks, counts, _ = oracle.search(a, b, capacity=1 << 20, threads=4)
+    gpu.tune("frontier_epoch", 5)
+    try:
+        out = run_partitioned(gpu, oracle, a, b, 3, 2, contexts=False, combine=True)
+    finally:
+        gpu.tune("frontier_epoch", 0)
+    assert np.array_equal(out["runs"][0], ranks) and np.array_equal(out["runs"][1], counts)
+
+
+def test_window_handles_are_refused_elsewhere(gpu, oracle):
+    from bwt_merge_amd.experimental import index_window
+    a = oracle.FMI.from_text(oracle.generate_reads(9701, 200, 50))
+    A = gpu.Index.upload(a.data, a.sequences, a.bases)
+    w = index_window(A, 1000, 5000)
+    with pytest.raises(gpu.BwtmError):
+        w.rank(np.array([1500], dtype=np.uint64), np.array([2], dtype=np.uint8))
+    with pytest.raises(gpu.BwtmError):
+        w.extract(1000, 10)
+    with pytest.raises(gpu.BwtmError):
+        gpu.merge(w, A)
+    w.free(); A.free()
