@@ -25,11 +25,14 @@ struct bwtm_fslice
     for(void* p : exported) { if(p) { (void)hipFree(p); } }
     if(host_pieces) { (void)hipHostFree(host_pieces); }
     if(host_below) { (void)hipHostFree(host_below); }
+    if(host_dense_pieces) { (void)hipHostFree(host_dense_pieces); }
   }
   bwtm_fslice(const bwtm_fslice&) = delete; bwtm_fslice& operator=(const bwtm_fslice&) = delete;
   const bwtm_index* a = nullptr; const bwtm_index* b = nullptr; bwtm_ra* ra = nullptr;
   u64 cap = 0, nbl = 0, nseg = 0, ntiles = 0;
   bool wide = false;
+  u64 nb_out = 1;                         // blocks of the last outputs' segment tables (class c's entries start at c * nb_out): the tables are laid out for the step's
+                                          // own size, not for the capacity, so that the per-step scans and the peers' lookups shrink with the frontier
   // exported to the peers (hipMalloc): this GPU's outputs of the last step
   uint2* lo_out = nullptr; unsigned short* hi_out = nullptr; u64* out_prefix = nullptr; u64* seg_phys_out = nullptr;
   std::vector<void*> exported;
@@ -40,7 +43,9 @@ struct bwtm_fslice
   u64 n_in = 0;
   DevBuf emit16, emit_base, bound; u64 emit_cap = 0, EPOCH = 1, in_epoch = 0, epoch_used = 0;
   // fixed cuts (bwtm_fslice_set_cuts): the cuts on the device, the counts below them of the last outputs (device and page-locked host)
-  DevBuf cuts, below; u64* host_below = nullptr; u32 ncuts = 0;
+  DevBuf cuts, below, dense_pieces; u64* host_below = nullptr; u32 ncuts = 0;
+  uint2* dense_lo = nullptr; unsigned short* dense_hi = nullptr;     // exported (hipMalloc): the outputs in logical order, the send buffer of the exchange
+  DensePiece* host_dense_pieces = nullptr;
 };
 
 namespace
@@ -48,12 +53,14 @@ namespace
 
 int fslice_scan_outputs(bwtm_fslice* fs)
 {
-  TRY(device_scan<0>(fs->seg_len_out.as<u64>(), fs->out_prefix, fs->nseg + 1));
-  for(u32 c = 0; c <= 5; c++) { TRY(fetch_u64(fs->out_prefix + (u64)c * fs->nbl, 96 + c)); }        // class boundaries -> totals (bwtm_fslice_export)
+  TRY(device_scan<0>(fs->seg_len_out.as<u64>(), fs->out_prefix, 5 * fs->nb_out + 1));
+  for(u32 c = 0; c <= 5; c++) { TRY(fetch_u64(fs->out_prefix + (u64)c * fs->nb_out, 96 + c)); }     // class boundaries -> totals (bwtm_fslice_export)
   if(fs->ncuts > 0)
   {
-    LAUNCH("cut_counts", k_cut_counts, 1, BLOCK_THREADS, (const uint2*)fs->lo_out, (const unsigned short*)fs->hi_out, (const u64*)fs->out_prefix, (const u64*)fs->seg_phys_out,
-      fs->nbl, fs->cuts.as<const u64>(), fs->ncuts, fs->below.as<u64>());
+    LAUNCH("compact_outputs", k_compact_outputs, fs->nb_out, FR_BLOCK, (const uint2*)fs->lo_out, (const unsigned short*)fs->hi_out, fs->seg_len_out.as<const u64>(), (const u64*)fs->seg_phys_out,
+      (const u64*)fs->out_prefix, fs->nb_out, fs->dense_lo, fs->dense_hi);
+    LAUNCH("cut_counts", k_cut_search, 1, BLOCK_THREADS, (const uint2*)fs->dense_lo, (const unsigned short*)fs->dense_hi, (const u64*)fs->out_prefix, fs->nb_out,
+      fs->cuts.as<const u64>(), fs->ncuts, fs->below.as<u64>());
     HIP_TRY(hipMemcpyAsync(fs->host_below, fs->below.p, 5ull * fs->ncuts * sizeof(u64), hipMemcpyDeviceToHost, CTX.stream));
   }
   return BWTM_OK;
@@ -131,8 +138,9 @@ extern "C" int bwtm_fslice_seed(bwtm_fslice* fs, uint64_t seq_first, uint64_t co
   ENTER(fs->ctx);
   if(count > fs->cap) { return fail(BWTM_EINVAL, "bwtm_fslice_seed: %llu sequences for a capacity of %llu", (unsigned long long)count, (unsigned long long)fs->cap); }
   if(count > 0 && seq_first + count > fs->b->m) { return fail(BWTM_EINVAL, "bwtm_fslice_seed: sequences out of range"); }
-  const u64 items = std::max<u64>(fs->nbl * FR_BLOCK, fs->nseg + 1);
-  LAUNCH("frontier_init", k_frontier_init, div_up(items, BLOCK_THREADS), BLOCK_THREADS, fs->lo_out, fs->hi_out, fs->seg_len_out.as<u64>(), fs->seg_phys_out, fs->nbl,
+  fs->nb_out = std::max<u64>(1, div_up(count, (u64)FR_BLOCK));
+  const u64 items = std::max<u64>(fs->nb_out * FR_BLOCK, 5 * fs->nb_out + 1);
+  LAUNCH("frontier_init", k_frontier_init, div_up(items, BLOCK_THREADS), BLOCK_THREADS, fs->lo_out, fs->hi_out, fs->seg_len_out.as<u64>(), fs->seg_phys_out, fs->nb_out,
     seq_first, count, fs->a->m);
   TRY(fslice_scan_outputs(fs));
   return BWTM_OK;
@@ -144,12 +152,14 @@ extern "C" int bwtm_fslice_export(bwtm_fslice* fs, bwtm_fslice_view* view)
   ENTER(fs->ctx);
   HIP_TRY(hipStreamSynchronize(CTX.stream));
   for(u32 c = 0; c < 5; c++) { fs->totals[c] = CTX.host_scratch[96 + c + 1] - CTX.host_scratch[96 + c]; view->totals[c] = fs->totals[c]; }
-  view->lo = fs->lo_out; view->hi = fs->hi_out; view->prefix = fs->out_prefix; view->phys = fs->seg_phys_out; view->blocks = fs->nbl;
+  view->lo = fs->lo_out; view->hi = fs->hi_out; view->prefix = fs->out_prefix; view->phys = fs->seg_phys_out; view->blocks = fs->nb_out;
   for(u32 c = 0; c < 5; c++)
   {
-    for(u32 k = 0; k <= BWTM_X_MAX_PARTS; k++) { view->below[c][k] = (k < fs->ncuts ? fs->host_below[c * fs->ncuts + k] : fs->totals[c]); }
-    if(fs->ncuts > 0) { view->below[c][0] = 0; view->below[c][fs->ncuts - 1] = fs->totals[c]; }      // R_0 = 0, R_parts = everything
+    for(u32 k = 0; k <= BWTM_X_MAX_PARTS; k++) { view->below[c][k] = (k + 1 < fs->ncuts ? fs->host_below[c * fs->ncuts + k] : fs->totals[c]); }      // past the last cut: everything
+    if(fs->ncuts > 0) { view->below[c][0] = 0; }                                                                                            // R_0 = 0
   }
+  view->dense_lo = fs->dense_lo; view->dense_hi = fs->dense_hi;
+  for(u32 c = 0; c <= 5; c++) { view->class_first[c] = CTX.host_scratch[96 + c]; }
   return BWTM_OK;
 }
 
@@ -193,7 +203,8 @@ extern "C" int bwtm_fslice_advance(bwtm_fslice* fs)
 {
   if(!fs) { return fail(BWTM_EINVAL, "bwtm_fslice_advance: null argument"); }
   ENTER(fs->ctx);
-  const u64 nbl = fs->nbl, nseg = fs->nseg;
+  const u64 nbl = std::max<u64>(1, div_up(fs->n_in, (u64)FR_BLOCK)), nseg = 5 * nbl;       // this step's tables: sized for its input, not for the capacity
+  fs->nb_out = nbl;
   const u64 scan_tiles = div_up(nseg + 1, (u64)SCAN_TILE);
   // the gathered slice in the layout of a fresh frontier: contiguous, class-0 segments
   LAUNCH("frontier_init", k_frontier_init_tables, div_up(nseg + 1, BLOCK_THREADS), BLOCK_THREADS, fs->seg_len_in.as<u64>(), fs->seg_phys_in.as<u64>(), nbl, fs->n_in);
@@ -258,6 +269,14 @@ extern "C" int bwtm_fslice_set_cuts(bwtm_fslice* fs, const uint64_t* r_cuts, int
   fs->ncuts = (u32)parts + 1;
   TRY(fs->cuts.alloc(fs->ncuts * sizeof(u64))); TRY(fs->below.alloc(5ull * fs->ncuts * sizeof(u64), true));
   if(!fs->host_below) { HIP_TRY(hipHostMalloc((void**)&fs->host_below, 5ull * (BWTM_X_MAX_PARTS + 1) * sizeof(u64), hipHostMallocDefault)); }
+  if(!fs->dense_lo)
+  {
+    const u64 fcap = fs->nbl * FR_BLOCK;
+    TRY(fslice_export_alloc(fs, fs->dense_lo, fcap));
+    if(fs->wide) { TRY(fslice_export_alloc(fs, fs->dense_hi, fcap)); }
+    TRY(fs->dense_pieces.alloc((u64)fs->max_pieces * sizeof(DensePiece)));
+    HIP_TRY(hipHostMalloc((void**)&fs->host_dense_pieces, (u64)fs->max_pieces * sizeof(DensePiece), hipHostMallocDefault));
+  }
   std::memset(fs->host_below, 0, 5ull * (BWTM_X_MAX_PARTS + 1) * sizeof(u64));
   u64 host_cuts[BWTM_X_MAX_PARTS + 1];
   for(int k = 0; k <= parts; k++) { host_cuts[k] = (k == parts ? ~0ull : r_cuts[k]); }
@@ -282,12 +301,10 @@ extern "C" int bwtm_fslice_gather_cut(bwtm_fslice* fs, const bwtm_fslice_view* v
       if(lo_x > hi_x || hi_x > views[h].totals[c]) { return fail(BWTM_EINVAL, "bwtm_fslice_gather_cut: counts of GPU %d, class %u are not monotone", h, c); }
       if(lo_x < hi_x)
       {
-        SlicePiece pc;
-        pc.lo = (const uint2*)views[h].lo; pc.hi = (const unsigned short*)views[h].hi;
-        pc.prefix = (const u64*)views[h].prefix; pc.phys = (const u64*)views[h].phys;
-        pc.seg_first = (u64)c * views[h].blocks; pc.seg_count = views[h].blocks;
-        pc.src_first = lo_x; pc.count = hi_x - lo_x; pc.dst_first = n_in;
-        fs->host_pieces[np++] = pc;
+        DensePiece pc;
+        pc.lo = (const uint2*)views[h].dense_lo; pc.hi = (const unsigned short*)views[h].dense_hi;
+        pc.src_first = views[h].class_first[c] + lo_x; pc.count = hi_x - lo_x; pc.dst_first = n_in;
+        fs->host_dense_pieces[np++] = pc;
         n_in += hi_x - lo_x;
       }
     }
@@ -295,8 +312,8 @@ extern "C" int bwtm_fslice_gather_cut(bwtm_fslice* fs, const bwtm_fslice_view* v
   if(n_in > fs->cap) { return fail(BWTM_EINVAL, "bwtm_fslice_gather_cut: %llu elements fall into this GPU's range, capacity %llu", (unsigned long long)n_in, (unsigned long long)fs->cap); }
   fs->n_in = n_in;
   if(n_in == 0) { return BWTM_OK; }
-  HIP_TRY(hipMemcpyAsync(fs->pieces.p, fs->host_pieces, (u64)np * sizeof(SlicePiece), hipMemcpyHostToDevice, CTX.stream));
-  LAUNCH("frontier_gather", k_frontier_gather, div_up(fs->n_in, BLOCK_THREADS), BLOCK_THREADS, fs->pieces.as<const SlicePiece>(), np, fs->n_in,
+  HIP_TRY(hipMemcpyAsync(fs->dense_pieces.p, fs->host_dense_pieces, (u64)np * sizeof(DensePiece), hipMemcpyHostToDevice, CTX.stream));
+  LAUNCH("frontier_gather", k_gather_dense, div_up(fs->n_in, BLOCK_THREADS), BLOCK_THREADS, fs->dense_pieces.as<const DensePiece>(), np, fs->n_in,
     fs->lo_in.as<uint2>(), fs->hi_in.as<unsigned short>());
   HIP_TRY(hipStreamSynchronize(CTX.stream));                       // the peers may overwrite their outputs once every GPU has returned from here
   return BWTM_OK;

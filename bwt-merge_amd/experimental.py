@@ -65,7 +65,8 @@ MAX_PARTS = 16                  # BWTM_X_MAX_PARTS
 
 
 class FSliceView(C.Structure):
-    _fields_ = [("lo", vp), ("hi", vp), ("prefix", vp), ("phys", vp), ("blocks", u64), ("totals", u64 * 5), ("below", (u64 * (MAX_PARTS + 1)) * 5)]
+    _fields_ = [("lo", vp), ("hi", vp), ("prefix", vp), ("phys", vp), ("blocks", u64), ("totals", u64 * 5), ("below", (u64 * (MAX_PARTS + 1)) * 5),
+                ("dense_lo", vp), ("dense_hi", vp), ("class_first", u64 * 6)]
 
 
 class FSlice:

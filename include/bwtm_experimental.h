@@ -37,6 +37,8 @@ typedef struct
   uint64_t blocks;
   uint64_t totals[5];                        /* elements per class (the symbols 1..5; the seed holds its sequences in class 0) */
   uint64_t below[5][BWTM_X_MAX_PARTS + 1];   /* after bwtm_fslice_set_cuts(): elements of class c whose B coordinate lies below cut k */
+  const void* dense_lo; const void* dense_hi; /* after bwtm_fslice_set_cuts(): the outputs in logical order (class, block): the send buffer of the exchange */
+  uint64_t class_first[6];                   /* where every class begins in it */
 } bwtm_fslice_view;
 /* `capacity` = the largest slice this GPU will be given (ceil(sequences / parts) + 1 is enough: the frontier only shrinks). */
 int bwtm_fslice_create(const bwtm_index* a, const bwtm_index* b, bwtm_ra* ra, uint64_t capacity, int parts, bwtm_fslice** out);

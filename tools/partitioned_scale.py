@@ -73,16 +73,16 @@ def main():
         ra.search(A, B, 0, m_b - 1); pkg.synchronize(); ra.free()               # warm-up (pool)
         ra = pkg.RankArray(A, B)
         _, wall, prof = profiled(lambda: ra.search(A, B, 0, m_b - 1))
-        rows.append((label, wall, ms(prof, "frontier_step"), prof.get("frontier_step", (0, 0))[1]))
+        rows.append((label, wall, ms(prof, "frontier_step"), prof.get("frontier_step", (0, 0))[1], sum(v[0] for v in prof.values())))
         if ratio == 0:
             whole_bits = ra                                                     # kept: the parts' union must equal it
         else:
             ra.free()
-    print("\n| search of input2's %d sequences | wall (ms) | k_frontier_step (ms) | launches |\n|---|---|---|---|" % m_b)
+    print("\n| search of input2's %d sequences | wall (ms) | k_frontier_step (ms) | launches | all kernels (ms) |\n|---|---|---|---|---|" % m_b)
     for r in rows:
-        print("| %s | %.1f | %.1f | %d |" % r)
+        print("| %s | %.1f | %.1f | %d | %.1f |" % r)
     # ---- what one GPU of G does today: 1 / G of the sequences over all records
-    print("\n| sequence shard of 1 / G (what a GPU of G runs today), as shipped | wall (ms) | k_frontier_step (ms) | x of the whole search / G |\n|---|---|---|---|")
+    print("\n| sequence shard of 1 / G (what a GPU of G runs today), as shipped | wall (ms) | k_frontier_step (ms) | x of the whole search / G | all kernels (ms) |\n|---|---|---|---|---|")
     pkg.tune("range_ratio", -1)
     parts_list = [int(x) for x in args.parts.split(",")]
     for G in parts_list:
@@ -90,11 +90,11 @@ def main():
         ra = pkg.RankArray(A, B)
         _, wall, prof = profiled(lambda: ra.search(A, B, 0, last))
         ra.free()
-        print("| G = %d | %.1f | %.1f | %.2f |" % (G, wall, ms(prof, "frontier_step"), ms(prof, "frontier_step") / (rows[0][2] / G)), flush=True)
+        print("| G = %d | %.1f | %.1f | %.2f | %.1f |" % (G, wall, ms(prof, "frontier_step"), ms(prof, "frontier_step") / (rows[0][2] / G), sum(v[0] for v in prof.values())), flush=True)
     whole_bytes = X.index_record_bytes(A) + X.index_record_bytes(B)
 
     # ---- partitioned records
-    print("\n| partitioned records | part | window (MB) | elements advanced (share) | k_frontier_step (ms) | gather (ms) | cut counts (ms) | scans + tiles (ms) |\n|---|---|---|---|---|---|---|---|")
+    print("\n| partitioned records | part | window (MB) | elements advanced (share) | k_frontier_step (ms) | compact (ms) | gather (ms) | cut search (ms) | scans, tables, tiles (ms) | all kernels (ms) |\n|---|---|---|---|---|---|---|---|---|---|")
     summary = []
     for G in parts_list:
         I, R = X.partition_cuts(A, B, G, args.k)
@@ -111,15 +111,17 @@ def main():
         t = time.perf_counter()
         steps, largest, work = X.search_partitioned(pkg, windows, ras, m_b, R, lambda g: ctxs[g].make_current())
         wall = (time.perf_counter() - t) * 1e3
-        per = []
+        per, alls = [], []
         for g in range(G):
             ctxs[g].make_current()
             prof = pkg.profile_read(); pkg.profile_enable(False)
             step_ms = ms(prof, "frontier_step")
             per.append(step_ms)
-            print("| G = %d | %d | %.0f | %d (%.3f) | %.1f | %.1f | %.1f | %.1f |" % (G, g, (X.index_record_bytes(windows[g][0]) + X.index_record_bytes(windows[g][1])) / 1e6,
-                  work[g], work[g] / max(1, sum(work)), step_ms, ms(prof, "frontier_gather"), ms(prof, "cut_counts"),
-                  ms(prof, "frontier_scan", "scan_reduce", "scan_apply", "frontier_init", "tile_build", "bound_seg_min", "bound_suffix_min")), flush=True)
+            all_ms = sum(v[0] for v in prof.values())
+            alls.append(all_ms)
+            print("| G = %d | %d | %.0f | %d (%.3f) | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f |" % (G, g, (X.index_record_bytes(windows[g][0]) + X.index_record_bytes(windows[g][1])) / 1e6,
+                  work[g], work[g] / max(1, sum(work)), step_ms, ms(prof, "compact_outputs"), ms(prof, "frontier_gather"), ms(prof, "cut_counts"),
+                  all_ms - step_ms - ms(prof, "compact_outputs", "frontier_gather", "cut_counts"), all_ms), flush=True)
         # parity: the union of the parts' bits is the whole search's bitvector (the parts' sets are disjoint: n_b bits in all)
         pkg.make_default_current()
         acc = pkg.RankArray(A, B)
@@ -128,16 +130,16 @@ def main():
         ones, outside = acc.subset_check(whole_bits)
         same = (ones == meta[1][1] and outside == 0)
         acc.free()
-        summary.append((G, steps, max(per), sum(per), rows[1][2], largest, same, wall))
+        summary.append((G, steps, max(per), sum(per), rows[1][2], largest, same, max(alls)))
         for g in range(G):
             ctxs[g].make_current()
             ras[g].free(); windows[g][0].free(); windows[g][1].free(); pkg.trim()
         pkg.make_default_current()
         for c in ctxs:
             c.destroy()
-    print("\n| G | LF steps | slowest part's k_frontier_step (ms) | all parts together (ms) | the whole search on one GPU, elements only (ms) | speed-up of the step kernel = whole / slowest part | largest frontier a part held | union of the parts' bits == the whole search's bitvector |\n|---|---|---|---|---|---|---|---|")
+    print("\n| G | LF steps | slowest part's k_frontier_step (ms) | all parts together (ms) | the whole search on one GPU, elements only (ms) | speed-up of the step kernel = whole / slowest part | largest frontier a part held | union of the parts' bits == the whole search's bitvector | slowest part, all its kernels (ms) |\n|---|---|---|---|---|---|---|---|---|")
     for G, steps, slow, total, whole, largest, same, wall in summary:
-        print("| %d | %d | %.1f | %.1f | %.1f | %.2f | %d | %s |" % (G, steps, slow, total, whole, whole / slow, largest, same))
+        print("| %d | %d | %.1f | %.1f | %.1f | %.2f | %d | %s | %.1f |" % (G, steps, slow, total, whole, whole / slow, largest, same, wall))
     print("\nrecords of both indexes: %.0f MB" % (whole_bytes / 1e6))
     whole_bits.free(); A.free(); B.free()
 
