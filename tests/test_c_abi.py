@@ -51,3 +51,28 @@ def test_product_package_exposes_no_experimental_names(bwtm):
         assert experimental.loaded() is False
         with pytest.raises(bwtm.BwtmError):
             experimental._bind()
+
+
+def test_struct_layouts_of_the_binding_match_the_headers(bwtm, tmp_path):
+    """ctypes mirrors of the C structs against the compiler's own layout of include/*.h: a binding (or a host binary) built against an older
+    layout hands the library wrong pointers without any error -- the experimental view struct grew in round 5 and a stale host binary faulted
+    on the device."""
+    import ctypes
+    import subprocess
+    from bwt_merge_amd import capi, experimental
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "bwtm.h"\n#include "bwtm_experimental.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %d %zu %zu %zu %zu %zu\\n", sizeof(bwtm_fslice_view), offsetof(bwtm_fslice_view, totals), offsetof(bwtm_fslice_view, below),\n'
+                   '  offsetof(bwtm_fslice_view, class_first), BWTM_X_MAX_PARTS, sizeof(bwtm_host_input), sizeof(bwtm_host_output), offsetof(bwtm_host_output, ms_total),\n'
+                   '  sizeof(bwtm_pool_info), offsetof(bwtm_pool_info, hipmalloc_fallbacks)); return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    (size, off_totals, off_below, off_class_first, max_parts, size_in, size_out, off_ms_total, size_pool,
+     off_fallbacks) = (int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split())
+    assert ctypes.sizeof(capi.HostInput) == size_in
+    assert ctypes.sizeof(capi.HostOutput) == size_out and capi.HostOutput.ms_total.offset == off_ms_total
+    assert ctypes.sizeof(capi.PoolInfo) == size_pool and capi.PoolInfo.hipmalloc_fallbacks.offset == off_fallbacks
+    V = experimental.FSliceView
+    assert max_parts == experimental.MAX_PARTS
+    assert ctypes.sizeof(V) == size
+    assert V.totals.offset == off_totals and V.below.offset == off_below and V.class_first.offset == off_class_first
