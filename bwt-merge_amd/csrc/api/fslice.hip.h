@@ -26,6 +26,7 @@ struct bwtm_fslice
     if(host_pieces) { (void)hipHostFree(host_pieces); }
     if(host_below) { (void)hipHostFree(host_below); }
     if(host_dense_pieces) { (void)hipHostFree(host_dense_pieces); }
+    if(host_node_pieces) { (void)hipHostFree(host_node_pieces); }
   }
   bwtm_fslice(const bwtm_fslice&) = delete; bwtm_fslice& operator=(const bwtm_fslice&) = delete;
   const bwtm_index* a = nullptr; const bwtm_index* b = nullptr; bwtm_ra* ra = nullptr;
@@ -46,6 +47,12 @@ struct bwtm_fslice
   DevBuf cuts, below, dense_pieces; u64* host_below = nullptr; u32 ncuts = 0;
   uint2* dense_lo = nullptr; unsigned short* dense_hi = nullptr;     // exported (hipMalloc): the outputs in logical order, the send buffer of the exchange
   DensePiece* host_dense_pieces = nullptr;
+  // node phase over partitioned records (bwtm_fslice_nodes_*): this level's nodes [0], their children [1] (exported, hipMalloc)
+  u64* node_sp[2] = {nullptr, nullptr}; u64* node_r[2] = {nullptr, nullptr}; u64* node_cnt[2] = {nullptr, nullptr};
+  u64 node_cap = 0, nodes = 0;
+  DevBuf node_flags, node_pieces, node_npieces, node_class_first, node_err, node_gather_pieces;
+  u32 node_piece_cap = 0;
+  NodePiece* host_node_pieces = nullptr;
 };
 
 namespace
@@ -348,4 +355,144 @@ extern "C" uint64_t bwtm_x_index_record_bytes(const bwtm_index* x)
 {
   if(!x) { return 0; }
   return (x->windowed ? x->win_count : x->nrecs) * 64;
+}
+
+extern "C" int bwtm_fslice_nodes_begin(bwtm_fslice* fs, uint64_t seq_first, uint64_t count, uint64_t node_capacity)
+{
+  if(!fs || node_capacity == 0) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_begin: bad argument"); }
+  ENTER(fs->ctx);
+  if(fs->ncuts == 0) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_begin: call bwtm_fslice_set_cuts first"); }
+  if(count > 0 && seq_first + count > fs->b->m) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_begin: sequences out of range"); }
+  if(!fs->node_sp[0])
+  {
+    fs->node_cap = node_capacity;
+    for(int k = 0; k < 2; k++)
+    {
+      TRY(fslice_export_alloc(fs, fs->node_sp[k], node_capacity)); TRY(fslice_export_alloc(fs, fs->node_r[k], node_capacity)); TRY(fslice_export_alloc(fs, fs->node_cnt[k], node_capacity));
+    }
+    TRY(fs->node_flags.alloc((5 * node_capacity + 1) * sizeof(u64)));
+    fs->node_piece_cap = (u32)std::min<u64>(fs->cap / 16 + 1024, 1ull << 24);
+    TRY(fs->node_pieces.alloc((u64)fs->node_piece_cap * sizeof(RangePiece)));
+    TRY(fs->node_npieces.alloc(sizeof(u32), true));
+    TRY(fs->node_class_first.alloc(6 * sizeof(u64)));
+    TRY(fs->node_err.alloc(sizeof(u32), true));
+    TRY(fs->node_gather_pieces.alloc((u64)fs->max_pieces * sizeof(NodePiece)));
+    HIP_TRY(hipHostMalloc((void**)&fs->host_node_pieces, (u64)fs->max_pieces * sizeof(NodePiece), hipHostMallocDefault));
+  }
+  else if(node_capacity > fs->node_cap) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_begin: the node buffers were created for %llu nodes", (unsigned long long)fs->node_cap); }
+  fs->nodes = 0;
+  if(count > 0)
+  {
+    LAUNCH("range_init", k_range_init, 1, BLOCK_THREADS, fs->node_sp[0], fs->node_r[0], fs->node_cnt[0], seq_first, count, fs->a->m);
+    fs->nodes = 1;
+  }
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_fslice_nodes_step(bwtm_fslice* fs, bwtm_fslice_nodes_view* view)
+{
+  if(!fs || !view) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_step: null argument"); }
+  ENTER(fs->ctx);
+  if(!fs->node_sp[0]) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_step: call bwtm_fslice_nodes_begin first"); }
+  const u64 N = fs->nodes;
+  std::memset(view, 0, sizeof(*view));
+  view->sp = fs->node_sp[1]; view->r = fs->node_r[1]; view->count = fs->node_cnt[1];
+  if(N == 0) { return BWTM_OK; }
+  if(N > fs->node_cap) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_step: %llu nodes, capacity %llu", (unsigned long long)N, (unsigned long long)fs->node_cap); }
+  const u64 grid = div_up(N, BLOCK_THREADS);
+  u64* flags = fs->node_flags.as<u64>();
+  LAUNCH("range_step", k_range_step<false>, grid, BLOCK_THREADS, fs->a->view(), fs->b->view(), (const u64*)fs->node_sp[0], (const u64*)fs->node_r[0], (const u64*)fs->node_cnt[0], N,
+    flags, (const u64*)nullptr, (u64*)nullptr, (u64*)nullptr, (u64*)nullptr, fs->ra->bits_as<u32>(), fs->node_pieces.as<RangePiece>(), fs->node_npieces.as<u32>(), fs->node_piece_cap);
+  LAUNCH("range_emit", k_range_emit, 2048, BLOCK_THREADS, fs->node_pieces.as<const RangePiece>(), fs->node_npieces.as<const u32>(), fs->node_piece_cap, fs->ra->bits_as<u32>());
+  HIP_TRY(hipMemsetAsync(fs->node_npieces.p, 0, sizeof(u32), CTX.stream));
+  TRY(device_scan<0>(flags, flags, 5 * N + 1));
+  TRY(fetch_u64(flags + 5 * N, 0));
+  HIP_TRY(hipStreamSynchronize(CTX.stream));
+  if(CTX.host_scratch[0] > fs->node_cap) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_step: %llu nodes have %llu children, capacity %llu", (unsigned long long)N, (unsigned long long)CTX.host_scratch[0], (unsigned long long)fs->node_cap); }
+  LAUNCH("range_children", k_range_step<true>, grid, BLOCK_THREADS, fs->a->view(), fs->b->view(), (const u64*)fs->node_sp[0], (const u64*)fs->node_r[0], (const u64*)fs->node_cnt[0], N,
+    (u64*)nullptr, (const u64*)flags, fs->node_sp[1], fs->node_r[1], fs->node_cnt[1], (u32*)nullptr, (RangePiece*)nullptr, (u32*)nullptr, 0u);
+  // class c's children are [flags[(c - 1) N], flags[c N]): the six boundaries, then the cut points inside every class
+  u64* cf = fs->node_class_first.as<u64>();
+  for(u32 c = 0; c <= 5; c++) { HIP_TRY(hipMemcpyAsync(cf + c, flags + (u64)c * N, sizeof(u64), hipMemcpyDeviceToDevice, CTX.stream)); }
+  HIP_TRY(hipMemsetAsync(fs->node_err.p, 0, sizeof(u32), CTX.stream));
+  LAUNCH("cut_counts", k_node_cut_search, 1, BLOCK_THREADS, (const u64*)fs->node_sp[1], (const u64*)fs->node_cnt[1], (const u64*)cf, fs->cuts.as<const u64>(), fs->ncuts, fs->below.as<u64>(),
+    fs->node_err.as<u32>());
+  HIP_TRY(hipMemcpyAsync(fs->host_below, fs->below.p, 5ull * fs->ncuts * sizeof(u64), hipMemcpyDeviceToHost, CTX.stream));
+  TRY(fetch_u64(cf, 96, 6));
+  HIP_TRY(hipMemcpyAsync(CTX.host_scratch + 104, fs->node_err.p, sizeof(u32), hipMemcpyDeviceToHost, CTX.stream));
+  HIP_TRY(hipStreamSynchronize(CTX.stream));
+  if((u32)CTX.host_scratch[104] != 0) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_step: a node crosses a cut (cuts must be k-mer boundaries of the merged order)"); }
+  for(u32 c = 0; c <= 5; c++) { view->class_first[c] = CTX.host_scratch[96 + c]; }
+  for(u32 c = 0; c < 5; c++)
+  {
+    const u64 total = view->class_first[c + 1] - view->class_first[c];
+    for(u32 k = 0; k <= BWTM_X_MAX_PARTS; k++) { view->below[c][k] = (k + 1 < fs->ncuts ? fs->host_below[c * fs->ncuts + k] : total); }
+    view->below[c][0] = 0;
+  }
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_fslice_nodes_gather(bwtm_fslice* fs, const bwtm_fslice_nodes_view* views, int parts, int part)
+{
+  if(!fs || !views || parts < 1 || part < 0 || part >= parts) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_gather: bad argument"); }
+  ENTER(fs->ctx);
+  if(fs->ncuts != (u32)parts + 1 || !fs->node_sp[0]) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_gather: cuts / node buffers were not set up for %d parts", parts); }
+  u32 np = 0; u64 n = 0;
+  for(u32 c = 0; c < 5; c++)
+  {
+    for(int h = 0; h < parts; h++)
+    {
+      const u64 lo_x = views[h].below[c][part], hi_x = views[h].below[c][part + 1];
+      if(lo_x > hi_x || hi_x > views[h].class_first[c + 1] - views[h].class_first[c]) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_gather: counts of GPU %d, class %u are not monotone", h, c); }
+      if(lo_x < hi_x)
+      {
+        NodePiece pc;
+        pc.sp = (const u64*)views[h].sp; pc.r = (const u64*)views[h].r; pc.cnt = (const u64*)views[h].count;
+        pc.src_first = views[h].class_first[c] + lo_x; pc.count = hi_x - lo_x; pc.dst_first = n;
+        fs->host_node_pieces[np++] = pc;
+        n += hi_x - lo_x;
+      }
+    }
+  }
+  if(n > fs->node_cap) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_gather: %llu nodes fall into this GPU's range, capacity %llu", (unsigned long long)n, (unsigned long long)fs->node_cap); }
+  fs->nodes = n;
+  if(n == 0) { return BWTM_OK; }
+  HIP_TRY(hipMemcpyAsync(fs->node_gather_pieces.p, fs->host_node_pieces, (u64)np * sizeof(NodePiece), hipMemcpyHostToDevice, CTX.stream));
+  LAUNCH("nodes_gather", k_gather_nodes, div_up(n, BLOCK_THREADS), BLOCK_THREADS, fs->node_gather_pieces.as<const NodePiece>(), np, n, fs->node_sp[0], fs->node_r[0], fs->node_cnt[0]);
+  HIP_TRY(hipStreamSynchronize(CTX.stream));                       // the peers may overwrite their children once every GPU has returned from here
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_fslice_nodes_expand(bwtm_fslice* fs)
+{
+  if(!fs) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_expand: null argument"); }
+  ENTER(fs->ctx);
+  if(!fs->node_sp[0]) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_expand: call bwtm_fslice_nodes_begin first"); }
+  const u64 N = fs->nodes;
+  u64 alive = 0;
+  DevBuf offsets;
+  if(N > 0)
+  {
+    TRY(offsets.alloc((N + 1) * sizeof(u64)));
+    HIP_TRY(hipMemcpyAsync(offsets.p, fs->node_cnt[0], N * sizeof(u64), hipMemcpyDeviceToDevice, CTX.stream));
+    HIP_TRY(hipMemsetAsync(offsets.as<u64>() + N, 0, sizeof(u64), CTX.stream));
+    TRY(device_scan<0>(offsets.as<u64>(), offsets.as<u64>(), N + 1));
+    TRY(fetch_u64(offsets.as<u64>() + N, 0));
+    HIP_TRY(hipStreamSynchronize(CTX.stream));
+    alive = CTX.host_scratch[0];
+  }
+  if(alive > fs->cap) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_expand: the nodes stand for %llu sequences, capacity %llu", (unsigned long long)alive, (unsigned long long)fs->cap); }
+  // the elements as the outputs of a step: contiguous, class 0 (the layout k_frontier_init produces for the roots)
+  fs->nb_out = std::max<u64>(1, div_up(alive, (u64)FR_BLOCK));
+  if(N > 0)
+  {
+    LAUNCH("range_expand", k_range_expand, div_up(N, BLOCK_THREADS), BLOCK_THREADS, (const u64*)fs->node_sp[0], (const u64*)fs->node_r[0], (const u64*)fs->node_cnt[0],
+      offsets.as<const u64>(), N, fs->lo_out, fs->hi_out, fs->node_pieces.as<RangePiece>(), fs->node_npieces.as<u32>(), fs->node_piece_cap);
+    LAUNCH("range_expand_pieces", k_range_expand_pieces, 2048, BLOCK_THREADS, fs->node_pieces.as<const RangePiece>(), fs->node_npieces.as<const u32>(), fs->node_piece_cap, fs->lo_out, fs->hi_out);
+    HIP_TRY(hipMemsetAsync(fs->node_npieces.p, 0, sizeof(u32), CTX.stream));
+  }
+  LAUNCH("frontier_init", k_frontier_init_tables, div_up(5 * fs->nb_out + 1, BLOCK_THREADS), BLOCK_THREADS, fs->seg_len_out.as<u64>(), fs->seg_phys_out, fs->nb_out, alive);
+  fs->nodes = 0;
+  TRY(fslice_scan_outputs(fs));
+  return BWTM_OK;
 }

@@ -75,3 +75,41 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_gather_dense(const DensePiece
   lo_in[j] = pc.lo[at];
   if(hi_in) { hi_in[j] = pc.hi[at]; }
 }
+
+// ---- the node phase over partitioned records.  A level's nodes (sp, count, r) live on the GPU that owns sp; with cuts at k-mer boundaries a
+// node never crosses a cut (the suffixes "x$" of a node x sort before every "x y...": a cut lies before or after all of them), so
+// k_range_step runs on a window unchanged.  Its children come out symbol-major, i.e. sorted by sp, class after class: the children of class
+// c that belong to GPU k are again a contiguous range, found here by binary search; a child that crosses a cut is reported (err).
+__global__ void __launch_bounds__(BLOCK_THREADS) k_node_cut_search(const u64* sp, const u64* cnt, const u64* class_first /* 6 */, const u64* cuts, u32 ncuts, u64* below, u32* err)
+{
+  const u32 t = threadIdx.x;
+  if(t >= 5 * ncuts) { return; }
+  const u32 c = t / ncuts, k = t - c * ncuts;
+  const u64 cut = cuts[k];
+  const u64 first = class_first[c], end = class_first[c + 1];
+  u64 lo_x = first, hi_x = end;
+  while(lo_x < hi_x)
+  {
+    const u64 mid = (lo_x + hi_x) >> 1;
+    if(sp[mid] < cut) { lo_x = mid + 1; } else { hi_x = mid; }
+  }
+  if(lo_x > first && cut != ~0ull && sp[lo_x - 1] + cnt[lo_x - 1] > cut) { atomicOr(err, 1u); }      // the node before the cut reaches across it
+  below[t] = lo_x - first;
+}
+
+struct NodePiece
+{
+  const u64* sp; const u64* r; const u64* cnt;     // the source GPU's children
+  u64 src_first, count, dst_first;
+};
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_gather_nodes(const NodePiece* pieces, u32 npieces, u64 n, u64* sp, u64* r, u64* cnt)
+{
+  const u64 j = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(j >= n) { return; }
+  u32 q = 0;
+  for(u32 k = 1; k < npieces; k++) { if(pieces[k].dst_first <= j) { q = k; } }
+  const NodePiece pc = pieces[q];
+  const u64 at = pc.src_first + (j - pc.dst_first);
+  sp[j] = pc.sp[at]; r[j] = pc.r[at]; cnt[j] = pc.cnt[at];
+}

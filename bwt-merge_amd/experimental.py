@@ -33,6 +33,10 @@ EXPERIMENTAL_SYMBOLS = [
     ("bwtm_x_index_record_bytes", u64, [vp]),
     ("bwtm_fslice_set_cuts", C.c_int, [vp, C.POINTER(u64), C.c_int]),
     ("bwtm_fslice_gather_cut", C.c_int, [vp, vp, C.c_int, C.c_int]),
+    ("bwtm_fslice_nodes_begin", C.c_int, [vp, u64, u64, u64]),
+    ("bwtm_fslice_nodes_step", C.c_int, [vp, vp]),
+    ("bwtm_fslice_nodes_gather", C.c_int, [vp, vp, C.c_int, C.c_int]),
+    ("bwtm_fslice_nodes_expand", C.c_int, [vp]),
 ]
 EXPERIMENTAL_LIB_PATH = os.path.join(HERE, "libbwtm_experimental.so")
 if not os.path.exists(EXPERIMENTAL_LIB_PATH):
@@ -67,6 +71,10 @@ MAX_PARTS = 16                  # BWTM_X_MAX_PARTS
 class FSliceView(C.Structure):
     _fields_ = [("lo", vp), ("hi", vp), ("prefix", vp), ("phys", vp), ("blocks", u64), ("totals", u64 * 5), ("below", (u64 * (MAX_PARTS + 1)) * 5),
                 ("dense_lo", vp), ("dense_hi", vp), ("class_first", u64 * 6)]
+
+
+class FSliceNodesView(C.Structure):
+    _fields_ = [("sp", vp), ("r", vp), ("count", vp), ("class_first", u64 * 6), ("below", (u64 * (MAX_PARTS + 1)) * 5)]
 
 
 class FSlice:
@@ -104,6 +112,18 @@ class FSlice:
 
     def gather_cut(self, views, parts, part):
         check(lib().bwtm_fslice_gather_cut(self.h, C.byref(views), parts, part))
+
+    def nodes_begin(self, seq_first, count, node_capacity):
+        check(lib().bwtm_fslice_nodes_begin(self.h, seq_first, count, node_capacity))
+
+    def nodes_step(self, view):
+        check(lib().bwtm_fslice_nodes_step(self.h, C.byref(view)))
+
+    def nodes_gather(self, views, parts, part):
+        check(lib().bwtm_fslice_nodes_gather(self.h, C.byref(views), parts, part))
+
+    def nodes_expand(self):
+        check(lib().bwtm_fslice_nodes_expand(self.h))
 
     def advance(self):
         check(lib().bwtm_fslice_advance(self.h))
@@ -212,24 +232,60 @@ def partition_cuts(a, b, parts, k=4):
     return I, R
 
 
-def search_partitioned(pkg, windows, ras, sequences, r_cuts, enter=None):
+def search_partitioned(pkg, windows, ras, sequences, r_cuts, enter=None, capacity=None, node_ratio=8, node_capacity=None):
     """The frontier search over partitioned records, driven from ONE host thread: windows[g] = (window of A, window of B) as GPU g holds
-    them (index_window over the cuts of partition_cuts), ras[g] = its rank array, r_cuts = the B ranks of the cuts.  Every GPU advances the
-    elements whose coordinates fall into its windows and ends up with the bits of its own output range.  Returns (LF steps, the largest
-    number of elements any GPU held in a step, elements advanced per GPU)."""
+    them (index_window over the cuts of partition_cuts), ras[g] = its rank array, r_cuts = the B ranks of the cuts.  The first levels run
+    on trie nodes (while a level has at most sequences / node_ratio of them; node_ratio = 0: elements from the roots on), every node on
+    the GPU that owns its range; then every GPU advances the elements whose coordinates fall into its windows.  Every GPU ends up with the
+    bits of its own output range.  capacity / node_capacity = elements / nodes a GPU can hold in a step / level (default: what ONE GPU
+    would need for all of them; with balanced cuts a GPU needs 1 / parts of that and some slack).  Returns (element steps, node
+    levels, the largest number of elements any GPU held in a step, elements advanced per GPU)."""
     parts = len(windows)
-    cap = sequences + 1                                             # the first steps sit on few GPUs: all roots lie below the first k-mer
+    cap = int(capacity) if capacity else sequences + 1
+    limit = sequences // node_ratio if node_ratio > 0 else 0
+    node_cap = int(node_capacity) if node_capacity else min(5 * max(limit, 1), sequences) + 1       # nodes (and children) a GPU can hold in a level
     views = (FSliceView * parts)()
+    nviews = (FSliceNodesView * parts)()
     fs = []
+    roots = []
     for g in range(parts):
         if enter:
             enter(g)
         f = FSlice(windows[g][0], windows[g][1], ras[g], cap, parts)
         f.set_cuts(r_cuts)
         first, last = min(int(r_cuts[g]), sequences), min(int(r_cuts[g + 1]), sequences)
-        f.seed(first, last - first)
-        f.export(views[g])
+        roots.append((first, last - first))
         fs.append(f)
+    levels = 0
+    if limit >= 1 and sum(1 for _, n in roots if n > 0) == 1:         # the root node "$" must lie on one GPU (k-mer cuts: the first)
+        for g in range(parts):
+            if enter:
+                enter(g)
+            fs[g].nodes_begin(roots[g][0], roots[g][1], node_cap)
+        level_nodes = 1
+        while 0 < level_nodes <= limit:
+            for g in range(parts):
+                if enter:
+                    enter(g)
+                fs[g].nodes_step(nviews[g])
+            level_nodes = 0
+            for g in range(parts):
+                if enter:
+                    enter(g)
+                fs[g].nodes_gather(nviews, parts, g)
+                level_nodes += sum(int(nviews[h].below[c][g + 1]) - int(nviews[h].below[c][g]) for h in range(parts) for c in range(5))
+            levels += 1
+        for g in range(parts):
+            if enter:
+                enter(g)
+            fs[g].nodes_expand()
+            fs[g].export(views[g])
+    else:
+        for g in range(parts):
+            if enter:
+                enter(g)
+            fs[g].seed(roots[g][0], roots[g][1])
+            fs[g].export(views[g])
     steps, largest, work = 0, 0, [0] * parts
     while True:
         total = sum(int(views[h].totals[c]) for h in range(parts) for c in range(5))
@@ -252,4 +308,4 @@ def search_partitioned(pkg, windows, ras, sequences, r_cuts, enter=None):
             enter(g)
         fs[g].finish()
         fs[g].free()
-    return steps, largest, work
+    return steps, levels, largest, work

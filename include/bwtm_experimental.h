@@ -70,6 +70,25 @@ uint64_t bwtm_x_index_record_bytes(const bwtm_index* index);       /* bytes of r
 int bwtm_fslice_set_cuts(bwtm_fslice* fs, const uint64_t* r_cuts, int parts);      /* r_cuts[0 .. parts]: R_0 = 0 <= R_1 <= ... ; R_parts is ignored (= everything) */
 int bwtm_fslice_gather_cut(bwtm_fslice* fs, const bwtm_fslice_view* views, int parts, int part);   /* synchronizes */
 
+/* The first levels on trie NODES over partitioned records (the node phase of bwtm_search, fmi.cpp:286-323, with the nodes routed like the
+   elements): a node (sp, count, r) lives on the GPU that owns sp; its children are exported class by class with their counts below every
+   cut, and every GPU assembles its next level from all peers' children.  With cuts at k-mer boundaries no node crosses a cut (a node that
+   does is reported as an error).  Per level, on every GPU:
+       bwtm_fslice_nodes_step(fs, &nview);   <barrier>   bwtm_fslice_nodes_gather(fs, nviews of all GPUs, parts, g);   <barrier>
+   while the level (the sum of the views' totals) is small; then bwtm_fslice_nodes_expand(fs) turns the GPU's nodes into its elements --
+   the outputs of a step, picked up by bwtm_fslice_export / bwtm_fslice_gather_cut -- and the element steps go on from there.  The bits of
+   the node levels are set by bwtm_fslice_nodes_step itself. */
+typedef struct
+{
+  const void* sp; const void* r; const void* count;   /* the GPU's children of this level: sorted by sp, class after class */
+  uint64_t class_first[6];                            /* where every class begins */
+  uint64_t below[5][BWTM_X_MAX_PARTS + 1];            /* children of class c with sp below cut k */
+} bwtm_fslice_nodes_view;
+int bwtm_fslice_nodes_begin(bwtm_fslice* fs, uint64_t seq_first, uint64_t count, uint64_t node_capacity);   /* the root "$" of these sequences (count = 0: no node); after bwtm_fslice_set_cuts */
+int bwtm_fslice_nodes_step(bwtm_fslice* fs, bwtm_fslice_nodes_view* view);                                   /* synchronizes */
+int bwtm_fslice_nodes_gather(bwtm_fslice* fs, const bwtm_fslice_nodes_view* views, int parts, int part);    /* synchronizes */
+int bwtm_fslice_nodes_expand(bwtm_fslice* fs);                                                               /* then bwtm_fslice_export */
+
 /* Test hook of the library's device scan (every table of the path -- segment prefixes, node offsets, block and sample tables -- goes
    through it): exclusive scan of `narrays` arrays of n items each, laid end to end in host memory; op 0 = sum, 1 = max; runs in the
    calling thread's current context. */

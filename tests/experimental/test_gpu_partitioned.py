@@ -33,7 +33,7 @@ def set_positions(words):
     return (nz.astype(np.uint64)[:, None] * np.uint64(64) + sh[None, :])[on]
 
 
-def run_partitioned(gpu, oracle, a, b, parts, k, contexts=True, combine=False):
+def run_partitioned(gpu, oracle, a, b, parts, k, contexts=True, combine=False, node_ratio=0, capacity=None):
     from bwt_merge_amd.experimental import index_record_bytes, index_window, partition_cuts, search_partitioned
     ctxs = [gpu.Context(0) for _ in range(parts)] if contexts else []
 
@@ -55,7 +55,7 @@ def run_partitioned(gpu, oracle, a, b, parts, k, contexts=True, combine=False):
         wa, wb = index_window(A, I[g], I[g + 1]), index_window(B, R[g], R[g + 1])
         A.free(); B.free()                                              # only the windows stay
         windows.append((wa, wb)); ras.append(gpu.RankArray(wa, wb)); held.append(index_record_bytes(wa) + index_record_bytes(wb))
-    steps, largest, work = search_partitioned(gpu, windows, ras, b.sequences, R, enter if contexts else None)
+    steps, levels, largest, work = search_partitioned(gpu, windows, ras, b.sequences, R, enter if contexts else None, capacity=capacity, node_ratio=node_ratio)
     bits, runs = [], None
     if combine:                                                         # one context: OR of the disjoint bit sets, then the reference's own form
         for g in range(1, parts):
@@ -72,17 +72,20 @@ def run_partitioned(gpu, oracle, a, b, parts, k, contexts=True, combine=False):
     gpu.make_default_current()
     for c in ctxs:
         c.destroy()
-    return dict(I=I, R=R, bits=bits, runs=runs, steps=steps, largest=largest, work=work, held=held, whole=whole_bytes)
+    return dict(I=I, R=R, bits=bits, runs=runs, steps=steps, levels=levels, largest=largest, work=work, held=held, whole=whole_bytes)
 
 
-@pytest.mark.parametrize("parts,k", [(1, 2), (2, 1), (3, 3), (5, 4), (8, 4), (16, 3)])
-def test_partitioned_search_equals_oracle(gpu, oracle, parts, k):
+@pytest.mark.parametrize("parts,k,node_ratio", [(1, 2, 0), (2, 1, 0), (3, 3, 0), (5, 4, 0), (8, 4, 0), (16, 3, 0),
+                                                # the first levels on trie nodes, routed like the elements: a few levels, many, the whole search
+                                                (1, 2, 8), (2, 1, 8), (3, 3, 40), (5, 4, 8), (8, 4, 3), (16, 3, 8), (4, 2, 1)])
+def test_partitioned_search_equals_oracle(gpu, oracle, parts, k, node_ratio):
     ta = oracle.generate_reads(9400, 2500, 90)
     tb = np.concatenate([oracle.generate_reads(9500 + j, 400, int(n)) for j, n in enumerate([1, 17, 60, 100, 139, 33])])
     a, b = oracle.FMI.from_text(ta), oracle.FMI.from_text(tb)
     expect = oracle_ra(oracle, a, b)
-    out = run_partitioned(gpu, oracle, a, b, parts, k)
-    assert out["steps"] == 140
+    out = run_partitioned(gpu, oracle, a, b, parts, k, node_ratio=node_ratio)
+    assert out["steps"] + out["levels"] == 140 or (node_ratio == 1 and out["steps"] == 0)
+    assert (out["levels"] > 0) == (node_ratio > 0)
     got = np.sort(np.concatenate(out["bits"]))
     assert got.size == b.bases
     assert np.array_equal(got, expect + np.arange(b.bases, dtype=np.uint64))          # position of b's suffix r in the merged order = RA[r] + r
@@ -94,7 +97,8 @@ def test_partitioned_search_equals_oracle(gpu, oracle, parts, k):
             assert lo <= int(out["bits"][g].min()) and int(out["bits"][g].max()) < hi, g
     # records are partitioned, not replicated: all windows together hold the records once (+ at most two boundary records per window)
     assert sum(out["held"]) <= out["whole"] + parts * 4 * 64
-    assert sum(out["work"]) == b.bases                                # every element of every step was advanced by exactly one GPU
+    if node_ratio == 0:
+        assert sum(out["work"]) == b.bases                            # every element of every step was advanced by exactly one GPU
 
 
 def test_cuts_are_insertion_points_of_kmers(gpu, oracle):
@@ -115,7 +119,8 @@ def test_cuts_are_insertion_points_of_kmers(gpu, oracle):
     A.free(); B.free()
 
 
-def test_partitioned_search_wide_coordinates(gpu, oracle):
+@pytest.mark.parametrize("nodes", [0, 4])
+def test_partitioned_search_wide_coordinates(gpu, oracle, nodes):
     """Coordinates beyond 2^32: the high bytes travel through the cut counts and the gather."""
     small_a = oracle.FMI.from_text(oracle.generate_reads(9301, 600, 60)); small_b = oracle.FMI.from_text(oracle.generate_reads(9302, 500, 70))
     a = oracle.FMI.from_runs(small_a.symbols.astype(np.uint64), np.full(small_a.symbols.size, 120000, dtype=np.uint64))
@@ -124,7 +129,7 @@ def test_partitioned_search_wide_coordinates(gpu, oracle):
     ranks, counts, _ = oracle.search(a, b, capacity=1 << 20, threads=4)
     gpu.tune("frontier_epoch", 5)
     try:
-        out = run_partitioned(gpu, oracle, a, b, 3, 2, contexts=False, combine=True)
+        out = run_partitioned(gpu, oracle, a, b, 3, 2, contexts=False, combine=True, node_ratio=nodes)
     finally:
         gpu.tune("frontier_epoch", 0)
     assert np.array_equal(out["runs"][0], ranks) and np.array_equal(out["runs"][1], counts)
