@@ -209,6 +209,15 @@ extern "C" int bwtm_interleave_range(const bwtm_index* a, const bwtm_index* b, b
     s->nsup = num_supers(s->n);
     TRY(s->recs.alloc((rec_last - s->rec_halo + 1) * 64));
     TRY(s->sup.alloc(s->nsup * SUP_STRIDE * sizeof(u64)));
+#ifdef BWTM_EXPERIMENTAL
+    if(a->windowed || b->windowed)
+    {
+      // windows hold the records of this range only: the super rows the slice refers to, from inside the range (kernels/search_partition.hip.h)
+      LAUNCH("interleave_sup", k_interleave_sup_window, div_up(s->nsup, BLOCK_THREADS), BLOCK_THREADS, a->view(), b->view(), ra->chunk_base.as<const u64>(),
+        s->sup.as<u64>(), s->nsup, ra->super_boff.as<const u64>(), (s->rec_halo >> 6) << 6, rec_last);
+    }
+    else
+#endif
     LAUNCH("interleave_sup", k_interleave_sup, div_up(s->nsup, BLOCK_THREADS), BLOCK_THREADS, a->view(), b->view(),
       ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), s->n, s->sup.as<u64>(), s->nsup, (ra->ranged ? ra->super_boff.as<const u64>() : (const u64*)nullptr));
     // an empty range (more GPUs than output chunks) interleaves nothing: its halo chunk was not installed by bwtm_ra_finalize_range either

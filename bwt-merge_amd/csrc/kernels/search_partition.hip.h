@@ -113,3 +113,29 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_gather_nodes(const NodePiece*
   const u64 at = pc.src_first + (j - pc.dst_first);
   sp[j] = pc.sp[at]; r[j] = pc.r[at]; cnt[j] = pc.cnt[at];
 }
+
+// ---- interleave of an output range from WINDOWS (bwtm_interleave_range on bwtm_x_index_window handles).  The super table of a slice only
+// serves the slice's own records, and a row only has to lie at or below the counts of every record that refers to it (header fields are
+// 25-bit offsets from it): the rows of the supers that BEGIN inside the range are the usual ones -- their positions lie inside the windows --
+// and the row of the super the range begins in, whose own beginning belongs to another GPU, is taken at the range's first chunk instead.
+// Rows of other supers stay zero: nothing of this slice refers to them.  (k_interleave_sup asks A and B at EVERY super of the output.)
+__global__ void __launch_bounds__(BLOCK_THREADS) k_interleave_sup_window(IndexView A, IndexView B, const u64* chunk_base, u64* sup, u64 nsup, const u64* super_boff,
+  u64 q_base, u64 q_end)
+{
+  const u64 s = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(s >= nsup) { return; }
+  u64 q = s << SUPER_REC_SHIFT;
+  bool have = (q >= q_base && q < q_end);
+  u64 b_off = 0;
+  if(have) { b_off = super_boff[s]; }
+  else if(s == (q_base >> SUPER_REC_SHIFT) && q_base < q_end) { q = q_base; b_off = chunk_base[q_base >> 6]; have = true; }      // q_base is the first record of a chunk
+  u64 ra[6] = {0, 0, 0, 0, 0, 0}, rb[6] = {0, 0, 0, 0, 0, 0};
+  if(have)
+  {
+    u64 a_off = (q << REC_SHIFT) - b_off;
+    if(a_off > A.n) { a_off = A.n; }
+    if(b_off > B.n) { b_off = B.n; }
+    index_ranks(A, a_off, ra); index_ranks(B, b_off, rb);
+  }
+  for(int c = 0; c < SUP_STRIDE; c++) { sup[s * SUP_STRIDE + c] = (c >= 1 && c < 6 ? ra[c] + rb[c] : 0); }
+}

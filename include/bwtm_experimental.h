@@ -64,7 +64,8 @@ int bwtm_fslice_finish(bwtm_fslice* fs);
        sequences [R_g, R_g+1) that exist.
    The loop is the sliced search's with bwtm_fslice_gather_cut in place of bwtm_fslice_gather.  Every GPU sets the bits of its own
    output range [I_g + R_g, I_g+1 + R_g+1) only: no bitvector exchange is needed afterwards (the prototype keeps whole-length bitvectors).
-   A window handle is only valid as an argument of bwtm_fslice_create / bwtm_ra_create; every other entry point refuses it. */
+   A window handle is only valid as an argument of bwtm_fslice_create, bwtm_ra_create and -- with a rank array finalized for an output range that
+   the windows cover, margins of two encoder segments included -- bwtm_interleave_range; every other entry point refuses it. */
 int bwtm_x_index_window(const bwtm_index* whole, uint64_t pos_first, uint64_t pos_last, bwtm_index** out);
 uint64_t bwtm_x_index_record_bytes(const bwtm_index* index);       /* bytes of records the handle holds (a window: its share) */
 int bwtm_fslice_set_cuts(bwtm_fslice* fs, const uint64_t* r_cuts, int parts);      /* r_cuts[0 .. parts]: R_0 = 0 <= R_1 <= ... ; R_parts is ignored (= everything) */

@@ -147,3 +147,97 @@ def test_window_handles_are_refused_elsewhere(gpu, oracle):
     with pytest.raises(gpu.BwtmError):
         gpu.merge(w, A)
     w.free(); A.free()
+
+
+def partitioned_merge(gpu, a, b, parts, k, node_ratio):
+    """The whole merge over partitioned records: search on windows, then every part finalizes, interleaves and encodes its own range of the
+    output from its windows (the range machinery of the product: bwtm_ra_range_counts / finalize_range / interleave_range / slice_*).  The
+    output ranges are the cuts rounded down to encoder segments; a part needs the bits of the neighbouring part inside its first and last
+    segment (8 KiB per boundary between real GPUs; the prototype's whole-length bitvectors are simply ORed)."""
+    from bwt_merge_amd.dist import fold_offsets, super_owners
+    from bwt_merge_amd.experimental import index_record_bytes, index_window, partition_cuts, search_partitioned
+    MARGIN = 2 * 65536                                                   # positions of A / B a part may read beyond its cuts: one segment + the halo chunk
+    ctxs = [gpu.Context(0) for _ in range(parts)]
+
+    def enter(g):
+        ctxs[g].make_current()
+
+    enter(0)
+    A = gpu.Index.upload(a.data, a.sequences, a.bases); B = gpu.Index.upload(b.data, b.sequences, b.bases)
+    I, R = partition_cuts(A, B, parts, k)
+    nrecs = gpu.merged_records(A, B)
+    A.free(); B.free()
+    windows, ras = [], []
+    for g in range(parts):
+        enter(g)
+        A = gpu.Index.upload(a.data, a.sequences, a.bases); B = gpu.Index.upload(b.data, b.sequences, b.bases)
+        wa = index_window(A, max(0, I[g] - MARGIN), min(a.bases, I[g + 1] + MARGIN))
+        wb = index_window(B, max(0, R[g] - MARGIN), min(b.bases, R[g + 1] + MARGIN))
+        A.free(); B.free()
+        windows.append((wa, wb)); ras.append(gpu.RankArray(wa, wb))
+    search_partitioned(gpu, windows, ras, b.sequences, R, enter, node_ratio=node_ratio)
+    # output ranges in records: the cuts' positions rounded down to 65 536-position segments (512 records)
+    seg = [0] + [(I[g] + R[g]) // 65536 for g in range(1, parts)]
+    bounds = [(min(nrecs, seg[g] * 512), nrecs if g == parts - 1 else min(nrecs, seg[g + 1] * 512)) for g in range(parts)]
+    for g in range(parts):                                               # the boundary segments' bits of the neighbours
+        enter(g)
+        for h in range(parts):
+            if h != g:
+                ras[g].or_from(ras[h])
+    counts = []
+    for g, (first, last) in enumerate(bounds):
+        enter(g)
+        counts.append(ras[g].range_counts(first, last))
+    totals = [c[0] for c in counts]
+    assert sum(totals) == b.bases
+    nsup = counts[0][1].size
+    owner = super_owners(nsup, bounds)
+    prefix = np.concatenate([[0], np.cumsum(totals)]).astype(np.uint64)
+    super_boff = prefix[owner] + sum(c[1] for c in counts)
+    slices = []
+    for g, (first, last) in enumerate(bounds):
+        enter(g)
+        halo = next((counts[h][2] for h in range(g - 1, -1, -1) if bounds[h][1] > bounds[h][0]), None)
+        ras[g].finalize_range(first, last, int(prefix[g]), int(prefix[parts]), super_boff, halo)
+        slices.append(gpu.Slice(windows[g][0], windows[g][1], ras[g], first, last))
+    heads = []
+    for g, s in enumerate(slices):
+        enter(g); heads.append(s.lasthead())
+    tables = []
+    for g, s in enumerate(slices):
+        enter(g); tables.append(s.size_table(max(heads[:g], default=0)))
+    offsets = fold_offsets(tables)
+    data, starts = [], []
+    for g, (s, off) in enumerate(zip(slices, offsets)):
+        enter(g); s.encode(off); data.append(s.data()); starts.append(s.first_block_start())
+    be, cum = [], []
+    for g, s in enumerate(slices):
+        enter(g)
+        nxt = next((p for p in starts[g + 1:] if p is not None), a.bases + b.bases)
+        x, y = s.samples(nxt)
+        be.append(x); cum.append(y)
+    held = [index_record_bytes(w[0]) + index_record_bytes(w[1]) for w in windows]
+    for g in range(parts):
+        enter(g)
+        slices[g].free(); ras[g].free(); windows[g][0].free(); windows[g][1].free()
+    gpu.make_default_current()
+    for c in ctxs:
+        c.destroy()
+    return np.concatenate(data), np.concatenate(be), np.concatenate(cum, axis=1), held, bounds
+
+
+@pytest.mark.parametrize("parts,k,node_ratio", [(1, 2, 8), (2, 1, 8), (3, 3, 0), (4, 4, 8), (8, 4, 8)])
+def test_partitioned_merge_equals_oracle(gpu, oracle, parts, k, node_ratio):
+    """Search, interleave and encode from windows only: the concatenation of the parts' bytes and samples is the oracle's merged stream.
+    Inputs large enough for several encoder segments per part (2.4 M + 1.9 M positions: 66 segments)."""
+    ta = oracle.generate_reads(9801, 24000, 100); tb = oracle.generate_reads(9802, 19000, 100)
+    a, b = oracle.FMI.from_text(ta), oracle.FMI.from_text(tb)
+    data, be, cum, held, bounds = partitioned_merge(gpu, a, b, parts, k, node_ratio)
+    m, _ = oracle.merge(a, b, threads=2)
+    assert np.array_equal(data, m.data)
+    obe, ocum = m.samples
+    assert np.array_equal(be, obe) and np.array_equal(cum, ocum[:, :-1])
+    if parts == 8:
+        assert all(x[1] > x[0] for x in bounds)                          # every part produced a piece of the output
+        whole = 64 * ((a.bases >> 7) + 1 + (b.bases >> 7) + 1)
+        assert max(held) < whole / 2                                     # a part holds its windows (+ margins), not the indexes
