@@ -31,6 +31,7 @@ EXPERIMENTAL_SYMBOLS = [
     ("bwtm_x_device_scan", C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), u64, u64, C.c_int]),
     ("bwtm_x_index_window", C.c_int, [vp, u64, u64, C.POINTER(vp)]),
     ("bwtm_x_index_record_bytes", u64, [vp]),
+    ("bwtm_x_index_upload_window", C.c_int, [C.c_void_p, u64, u64, C.POINTER(u64), u64, u64, C.POINTER(u64), C.POINTER(vp)]),
     ("bwtm_fslice_set_cuts", C.c_int, [vp, C.POINTER(u64), C.c_int]),
     ("bwtm_fslice_gather_cut", C.c_int, [vp, vp, C.c_int, C.c_int]),
     ("bwtm_fslice_nodes_begin", C.c_int, [vp, u64, u64, u64]),
@@ -309,3 +310,31 @@ def search_partitioned(pkg, windows, ras, sequences, r_cuts, enter=None, capacit
         fs[g].finish()
         fs[g].free()
     return steps, levels, largest, work
+
+
+def window_blocks(block_starts, nbytes, pos_first, pos_last, bases):
+    """The 64-byte blocks [b0, b1) of a native stream whose records cover the positions [pos_first, pos_last]: block_starts[b] = the position
+    block b begins at (block_starts[blocks] = bases; the cumulative sample arrays of a native file summed over the symbols)."""
+    import numpy as np
+    nb = len(block_starts) - 1
+    lo = int(pos_first) & ~127
+    hi = min(int(bases), (int(pos_last) | 127) + 1)
+    b0 = max(0, int(np.searchsorted(block_starts, lo, side="right")) - 1)
+    b1 = min(nb, int(np.searchsorted(block_starts, hi, side="left")))
+    return b0, max(b1, b0 + 1)
+
+
+def index_upload_window(data, cum, bases, sequences, pos_first, pos_last):
+    """A window of an index transcoded from its own share of the native bytes: data = the whole native stream in host memory (only the
+    share is copied to the device), cum[6][blocks + 1] = its cumulative sample arrays (counts of every symbol before every block)."""
+    import numpy as np
+    _bind()
+    starts = cum.sum(axis=0).astype(np.uint64)
+    b0, b1 = window_blocks(starts, data.size, pos_first, pos_last, bases)
+    share = np.ascontiguousarray(data[b0 * 64: min(b1 * 64, data.size)])
+    before = (u64 * 6)(*[int(cum[c][b0]) for c in range(6)])
+    totals = [int(cum[c][-1]) for c in range(6)]
+    Cs = (u64 * 7)(*[sum(totals[:c]) for c in range(7)])
+    out = vp()
+    check(lib().bwtm_x_index_upload_window(share.ctypes.data_as(C.c_void_p), share.size, int(starts[b0]), before, int(bases), int(sequences), Cs, C.byref(out)))
+    return capi.Index(out)

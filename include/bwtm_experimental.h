@@ -67,6 +67,13 @@ int bwtm_fslice_finish(bwtm_fslice* fs);
    A window handle is only valid as an argument of bwtm_fslice_create, bwtm_ra_create and -- with a rank array finalized for an output range that
    the windows cover, margins of two encoder segments included -- bwtm_interleave_range; every other entry point refuses it. */
 int bwtm_x_index_window(const bwtm_index* whole, uint64_t pos_first, uint64_t pos_last, bwtm_index** out);
+/* The same window transcoded from its OWN share of the native bytes (the sharded transcode of section 6.3): `data` = the whole 64-byte blocks
+   [b0, b1) of the index's native stream, first_position = the position block b0 begins at, counts_before[c] = occurrences of symbol c before
+   it (both are what the samples of a native file hold per block: bwt.cpp:489-511), bases / sequences / C = the header of the WHOLE index.
+   The handle serves the records that lie wholly inside the bytes: positions [first_position rounded up to 128, end rounded down to 128) -- or
+   to the end of the index when the bytes hold its last block.  No GPU ever holds the whole index this way. */
+int bwtm_x_index_upload_window(const uint8_t* data, uint64_t nbytes, uint64_t first_position, const uint64_t counts_before[6],
+                               uint64_t bases, uint64_t sequences, const uint64_t C[7], bwtm_index** out);
 uint64_t bwtm_x_index_record_bytes(const bwtm_index* index);       /* bytes of records the handle holds (a window: its share) */
 int bwtm_fslice_set_cuts(bwtm_fslice* fs, const uint64_t* r_cuts, int parts);      /* r_cuts[0 .. parts]: R_0 = 0 <= R_1 <= ... ; R_parts is ignored (= everything) */
 int bwtm_fslice_gather_cut(bwtm_fslice* fs, const bwtm_fslice_view* views, int parts, int part);   /* synchronizes */

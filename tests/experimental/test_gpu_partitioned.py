@@ -149,13 +149,27 @@ def test_window_handles_are_refused_elsewhere(gpu, oracle):
     w.free(); A.free()
 
 
-def partitioned_merge(gpu, a, b, parts, k, node_ratio):
+class HostIndex:
+    """What partition_cuts asks of an index, answered by the oracle's FM-index on the host."""
+
+    def __init__(self, x):
+        self.x = x; self.bases = x.bases
+
+    def find(self, patterns):
+        c = int(patterns[0][0])
+        return np.array([self.x.C[c]], dtype=np.uint64), None
+
+    def rank(self, positions, comps):
+        return np.array([self.x.rank(int(p), int(c)) for p, c in zip(positions, comps)], dtype=np.uint64)
+
+
+def partitioned_merge(gpu, a, b, parts, k, node_ratio, from_bytes=False):
     """The whole merge over partitioned records: search on windows, then every part finalizes, interleaves and encodes its own range of the
     output from its windows (the range machinery of the product: bwtm_ra_range_counts / finalize_range / interleave_range / slice_*).  The
     output ranges are the cuts rounded down to encoder segments; a part needs the bits of the neighbouring part inside its first and last
     segment (8 KiB per boundary between real GPUs; the prototype's whole-length bitvectors are simply ORed)."""
     from bwt_merge_amd.dist import fold_offsets, super_owners
-    from bwt_merge_amd.experimental import index_record_bytes, index_window, partition_cuts, search_partitioned
+    from bwt_merge_amd.experimental import index_record_bytes, index_upload_window, index_window, partition_cuts, search_partitioned
     MARGIN = 2 * 65536                                                   # positions of A / B a part may read beyond its cuts: one segment + the halo chunk
     ctxs = [gpu.Context(0) for _ in range(parts)]
 
@@ -163,17 +177,28 @@ def partitioned_merge(gpu, a, b, parts, k, node_ratio):
         ctxs[g].make_current()
 
     enter(0)
-    A = gpu.Index.upload(a.data, a.sequences, a.bases); B = gpu.Index.upload(b.data, b.sequences, b.bases)
-    I, R = partition_cuts(A, B, parts, k)
-    nrecs = gpu.merged_records(A, B)
-    A.free(); B.free()
+    if from_bytes:
+        # the cuts from the host's copy of the indexes (the oracle here): the device never sees a whole index
+        I, R = partition_cuts(HostIndex(a), HostIndex(b), parts, k)
+        nrecs = ((a.bases + b.bases) >> 7) + 1
+    else:
+        A = gpu.Index.upload(a.data, a.sequences, a.bases); B = gpu.Index.upload(b.data, b.sequences, b.bases)
+        I, R = partition_cuts(A, B, parts, k)
+        nrecs = gpu.merged_records(A, B)
+        A.free(); B.free()
     windows, ras = [], []
     for g in range(parts):
         enter(g)
-        A = gpu.Index.upload(a.data, a.sequences, a.bases); B = gpu.Index.upload(b.data, b.sequences, b.bases)
-        wa = index_window(A, max(0, I[g] - MARGIN), min(a.bases, I[g + 1] + MARGIN))
-        wb = index_window(B, max(0, R[g] - MARGIN), min(b.bases, R[g + 1] + MARGIN))
-        A.free(); B.free()
+        if from_bytes:
+            # every part transcodes its windows from its own share of the native bytes (the blocks named by the inputs' sample arrays):
+            # no context ever holds a whole index
+            wa = index_upload_window(a.data, a.samples[1], a.bases, a.sequences, max(0, I[g] - MARGIN), min(a.bases, I[g + 1] + MARGIN))
+            wb = index_upload_window(b.data, b.samples[1], b.bases, b.sequences, max(0, R[g] - MARGIN), min(b.bases, R[g + 1] + MARGIN))
+        else:
+            A = gpu.Index.upload(a.data, a.sequences, a.bases); B = gpu.Index.upload(b.data, b.sequences, b.bases)
+            wa = index_window(A, max(0, I[g] - MARGIN), min(a.bases, I[g + 1] + MARGIN))
+            wb = index_window(B, max(0, R[g] - MARGIN), min(b.bases, R[g + 1] + MARGIN))
+            A.free(); B.free()
         windows.append((wa, wb)); ras.append(gpu.RankArray(wa, wb))
     search_partitioned(gpu, windows, ras, b.sequences, R, enter, node_ratio=node_ratio)
     # output ranges in records: the cuts' positions rounded down to 65 536-position segments (512 records)
@@ -226,13 +251,14 @@ def partitioned_merge(gpu, a, b, parts, k, node_ratio):
     return np.concatenate(data), np.concatenate(be), np.concatenate(cum, axis=1), held, bounds
 
 
-@pytest.mark.parametrize("parts,k,node_ratio", [(1, 2, 8), (2, 1, 8), (3, 3, 0), (4, 4, 8), (8, 4, 8)])
-def test_partitioned_merge_equals_oracle(gpu, oracle, parts, k, node_ratio):
+@pytest.mark.parametrize("parts,k,node_ratio,from_bytes", [(1, 2, 8, False), (2, 1, 8, False), (3, 3, 0, False), (4, 4, 8, False), (8, 4, 8, False),
+                                                           (1, 2, 8, True), (2, 1, 0, True), (3, 3, 8, True), (8, 4, 8, True)])
+def test_partitioned_merge_equals_oracle(gpu, oracle, parts, k, node_ratio, from_bytes):
     """Search, interleave and encode from windows only: the concatenation of the parts' bytes and samples is the oracle's merged stream.
     Inputs large enough for several encoder segments per part (2.4 M + 1.9 M positions: 66 segments)."""
     ta = oracle.generate_reads(9801, 24000, 100); tb = oracle.generate_reads(9802, 19000, 100)
     a, b = oracle.FMI.from_text(ta), oracle.FMI.from_text(tb)
-    data, be, cum, held, bounds = partitioned_merge(gpu, a, b, parts, k, node_ratio)
+    data, be, cum, held, bounds = partitioned_merge(gpu, a, b, parts, k, node_ratio, from_bytes)
     m, _ = oracle.merge(a, b, threads=2)
     assert np.array_equal(data, m.data)
     obe, ocum = m.samples
@@ -241,3 +267,30 @@ def test_partitioned_merge_equals_oracle(gpu, oracle, parts, k, node_ratio):
         assert all(x[1] > x[0] for x in bounds)                          # every part produced a piece of the output
         whole = 64 * ((a.bases >> 7) + 1 + (b.bases >> 7) + 1)
         assert max(held) < whole / 2                                     # a part holds its windows (+ margins), not the indexes
+
+
+def test_window_from_bytes_equals_window_of_whole_records(gpu, oracle):
+    """bwtm_x_index_upload_window against bwtm_x_index_window: the searches over both kinds of windows set the same bits (above); here the
+    transcode itself -- shares that begin and end in the middle of records, at the very beginning and at the very end of the stream, a share of
+    one block -- through the one query a window answers: the element steps of a search that stays inside it."""
+    from bwt_merge_amd.experimental import index_record_bytes, index_upload_window, window_blocks
+    a = oracle.FMI.from_text(oracle.generate_reads(9901, 3000, 80))
+    be, cum = a.samples
+    starts = cum.sum(axis=0).astype(np.uint64)
+    for first, last in [(0, 5000), (12345, 54321), (a.bases - 3000, a.bases), (70000, 70001), (0, a.bases)]:
+        w = index_upload_window(a.data, cum, a.bases, a.sequences, first, last)
+        b0, b1 = window_blocks(starts, a.data.size, first, last, a.bases)
+        assert int(starts[b0]) <= (first & ~127) and int(starts[b1]) >= min(a.bases, (last | 127) + 1)
+        held = index_record_bytes(w) // 64
+        assert held >= (last >> 7) - (first >> 7) + 1                                    # every record of the range is there
+        assert held <= (int(starts[b1]) - int(starts[b0])) // 128 + 2                    # and nothing but the share's records
+        with pytest.raises(gpu.BwtmError):
+            w.extract(first, 1)                                                           # a window answers no queries of its own
+        w.free()
+    with pytest.raises(gpu.BwtmError):                                                    # counts that do not add up to the position
+        from bwt_merge_amd import experimental as X
+        import ctypes as C
+        bad = (C.c_uint64 * 6)(1, 2, 3, 4, 5, 6)
+        Cs = (C.c_uint64 * 7)(*[0] * 7)
+        out = C.c_void_p()
+        X.check(X.lib().bwtm_x_index_upload_window(a.data.ctypes.data_as(C.c_void_p), 64, 5, bad, int(a.bases), int(a.sequences), Cs, C.byref(out)))
