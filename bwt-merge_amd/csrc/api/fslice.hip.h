@@ -567,3 +567,48 @@ extern "C" int bwtm_x_index_upload_window(const uint8_t* data, uint64_t nbytes, 
   *out = x;
   return BWTM_OK;
 }
+
+extern "C" int bwtm_x_ra_create_range(const bwtm_index* a, const bwtm_index* b, uint64_t pos_first, uint64_t pos_last, bwtm_ra** out)
+{
+  if(!a || !b || !out || pos_first > pos_last) { return fail(BWTM_EINVAL, "bwtm_x_ra_create_range: bad argument"); }
+  if(a->ctx != b->ctx) { return fail(BWTM_EINVAL, "bwtm_x_ra_create_range: the two indexes live in different contexts"); }
+  ENTER(a->ctx);
+  bwtm_ra* ra = new bwtm_ra();
+  ra->ctx = t_ctx;
+  ra->na = a->n; ra->nb = b->n; ra->n_out = a->n + b->n;
+  ra->nrecs_out = num_records(ra->n_out);
+  ra->nchunks = div_up(ra->nrecs_out, 64);
+  const u64 tile_words = 1ull << (TILE_SHIFT - 6), nwords = ra->nchunks * CHUNK_WORDS;
+  const u64 t0 = (pos_first >> TILE_SHIFT), t1 = div_up(std::min<u64>(pos_last, ra->n_out) + 1, 1ull << TILE_SHIFT);
+  const u64 w0 = (t0 > 0 ? t0 - 1 : 0) * tile_words, w1 = std::min<u64>(nwords, (t1 + 1) * tile_words);
+  ra->windowed = true; ra->win_word_first = w0; ra->win_words = (w1 > w0 ? w1 - w0 : tile_words);
+  int rc = ra->owned_bits.alloc(ra->win_words * sizeof(u64), true);
+  if(rc == BWTM_OK) { ra->bits_ptr = (char*)ra->owned_bits.p - w0 * sizeof(u64); }
+  if(rc == BWTM_OK) { rc = ra->chunk_base.alloc((ra->nchunks + 1) * sizeof(u64), true); }
+  if(rc != BWTM_OK) { delete ra; return rc; }
+  *out = ra;
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_x_ra_or_range(bwtm_ra* dst, const bwtm_ra* src, uint64_t pos_first, uint64_t pos_last)
+{
+  if(!dst || !src || pos_first > pos_last) { return fail(BWTM_EINVAL, "bwtm_x_ra_or_range: bad argument"); }
+  ENTER(dst->ctx);
+  if(dst->n_out != src->n_out) { return fail(BWTM_EINVAL, "bwtm_x_ra_or_range: rank arrays of different shapes"); }
+  if(dst->finalized) { return fail(BWTM_EINVAL, "bwtm_x_ra_or_range: rank array already finalized"); }
+  if(pos_first == pos_last) { return BWTM_OK; }
+  const u64 nwords = dst->nchunks * CHUNK_WORDS;
+  const u64 w0 = pos_first >> 6, w1 = std::min<u64>(nwords, div_up(pos_last, 64));
+  auto holds = [&](const bwtm_ra* r) { return !r->windowed || (w0 >= r->win_word_first && w1 <= r->win_word_first + r->win_words); };
+  if(!holds(dst) || !holds(src)) { return fail(BWTM_EINVAL, "bwtm_x_ra_or_range: the positions [%llu, %llu) reach outside a rank array's window", (unsigned long long)pos_first, (unsigned long long)pos_last); }
+  // the source lives in another context of this device or on a peer: its stream must have finished writing (the caller's barrier)
+  LAUNCH("bits_or", k_bits_or, div_up(w1 - w0, BLOCK_THREADS), BLOCK_THREADS, dst->bits_as<u64>() + w0, src->bits_as<const u64>() + w0, w1 - w0);
+  HIP_TRY(hipStreamSynchronize(CTX.stream));
+  return BWTM_OK;
+}
+
+extern "C" uint64_t bwtm_x_ra_bytes(const bwtm_ra* ra)
+{
+  if(!ra) { return 0; }
+  return (ra->windowed ? ra->win_words : ra->nchunks * CHUNK_WORDS) * sizeof(u64);
+}

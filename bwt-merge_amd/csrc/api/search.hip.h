@@ -24,7 +24,20 @@ struct bwtm_ra
   u64 range_first = 0, range_last = 0;
   DevBuf range_rel;                   // chunk counts of the range, scanned (between bwtm_ra_range_counts and bwtm_ra_finalize_range)
   DevBuf super_boff;                  // set bits before every super block of the output (ranged form only)
+#ifdef BWTM_EXPERIMENTAL
+  // A WINDOW of the bitvector (bwtm_x_ra_create_range; partitioned records): owned_bits holds the words
+  // [win_word_first, win_word_first + win_words) only and bits_ptr is shifted back so that absolute word numbers address it unchanged.
+  bool windowed = false;
+  u64 win_word_first = 0, win_words = 0;
+#endif
 };
+
+// Entry points that walk the whole bitvector refuse a window of one (experimental build; nothing in the product build).
+#ifdef BWTM_EXPERIMENTAL
+#define WHOLE_RA(ra, who) if((ra)->windowed) { return fail(BWTM_EINVAL, who ": a window of a rank array (bwtm_x_ra_create_range) only serves bwtm_fslice_* and the output-range entry points"); }
+#else
+#define WHOLE_RA(ra, who)
+#endif
 
 namespace
 {
@@ -568,6 +581,7 @@ extern "C" int bwtm_search(const bwtm_index* a, const bwtm_index* b, uint64_t se
   if(!a || !b || !ra) { return fail(BWTM_EINVAL, "bwtm_search: null argument"); }
   if(a->ctx != ra->ctx || b->ctx != ra->ctx) { return fail(BWTM_EINVAL, "bwtm_search: handles of different contexts"); }
   ENTER(ra->ctx);
+  WHOLE_RA(ra, "bwtm_search");
   WHOLE_INDEX(a, "bwtm_search"); WHOLE_INDEX(b, "bwtm_search");
   if(ra->na != a->n || ra->nb != b->n) { return fail(BWTM_EINVAL, "bwtm_search: rank array was created for other inputs"); }
   if(ra->finalized) { return fail(BWTM_EINVAL, "bwtm_search: rank array already finalized"); }
@@ -594,6 +608,7 @@ extern "C" int bwtm_search(const bwtm_index* a, const bwtm_index* b, uint64_t se
 extern "C" int bwtm_ra_device_buffer(bwtm_ra* ra, void** device_ptr, uint64_t* nbytes)
 {
   if(!ra || !device_ptr || !nbytes) { return fail(BWTM_EINVAL, "bwtm_ra_device_buffer: null argument"); }
+  WHOLE_RA(ra, "bwtm_ra_device_buffer");
   ENTER(ra->ctx);
   HIP_TRY(hipStreamSynchronize(CTX.stream));
   *device_ptr = ra->bits_ptr; *nbytes = ra->nchunks * CHUNK_WORDS * sizeof(u64);
@@ -604,6 +619,7 @@ extern "C" int bwtm_ra_or_from(bwtm_ra* ra, const void* device_bits, uint64_t nb
 {
   if(!ra || !device_bits) { return fail(BWTM_EINVAL, "bwtm_ra_or_from: null argument"); }
   ENTER(ra->ctx);
+  WHOLE_RA(ra, "bwtm_ra_or_from");
   if(ra->finalized) { return fail(BWTM_EINVAL, "bwtm_ra_or_from: rank array already finalized"); }
   const u64 nwords = ra->nchunks * CHUNK_WORDS;
   if(nbytes != nwords * sizeof(u64)) { return fail(BWTM_EINVAL, "bwtm_ra_or_from: buffer of %llu bytes, expected %llu", (unsigned long long)nbytes, (unsigned long long)(nwords * sizeof(u64))); }
@@ -617,6 +633,7 @@ extern "C" int bwtm_ra_subset_check(bwtm_ra* part, bwtm_ra* whole, uint64_t* par
   if(!part || !whole || !part_bits || !words_outside) { return fail(BWTM_EINVAL, "bwtm_ra_subset_check: null argument"); }
   if(part->ctx != whole->ctx || part->n_out != whole->n_out) { return fail(BWTM_EINVAL, "bwtm_ra_subset_check: rank arrays of different contexts or shapes"); }
   ENTER(part->ctx);
+  WHOLE_RA(part, "bwtm_ra_subset_check"); WHOLE_RA(whole, "bwtm_ra_subset_check");
   const u64 nwords = part->nchunks * CHUNK_WORDS;
   DevBuf acc; TRY(acc.alloc(2 * sizeof(u64), true));
   LAUNCH("bits_subset", k_bits_subset, div_up(nwords, BLOCK_THREADS), BLOCK_THREADS, part->bits_as<const u64>(), whole->bits_as<const u64>(), nwords, acc.as<unsigned long long>());
@@ -643,6 +660,7 @@ int ra_finalize(bwtm_ra* ra)
 extern "C" int bwtm_ra_finalize(bwtm_ra* ra)
 {
   if(!ra) { return fail(BWTM_EINVAL, "null rank array"); }
+  WHOLE_RA(ra, "bwtm_ra_finalize");
   ENTER(ra->ctx);
   return ra_finalize(ra);
 }
@@ -653,6 +671,7 @@ extern "C" int bwtm_ra_download(bwtm_ra* ra, uint64_t* out, uint64_t capacity)
 {
   if(!ra || !out) { return fail(BWTM_EINVAL, "bwtm_ra_download: null argument"); }
   ENTER(ra->ctx);
+  WHOLE_RA(ra, "bwtm_ra_download");
   if(!ra->finalized) { return fail(BWTM_EINVAL, "bwtm_ra_download: rank array not finalized"); }
   if(capacity < ra->nb) { return fail(BWTM_EINVAL, "bwtm_ra_download: buffer too small"); }
   if(ra->nb == 0) { return BWTM_OK; }
@@ -668,6 +687,7 @@ extern "C" int bwtm_ra_download_bits(bwtm_ra* ra, uint64_t* out_words, uint64_t 
 {
   if(!ra || !out_words) { return fail(BWTM_EINVAL, "bwtm_ra_download_bits: null argument"); }
   ENTER(ra->ctx);
+  WHOLE_RA(ra, "bwtm_ra_download_bits");
   u64 words = div_up(ra->n_out, 64);
   if(capacity_words < words) { return fail(BWTM_EINVAL, "bwtm_ra_download_bits: buffer too small"); }
   if(words > 0) { HIP_TRY(hipMemcpyAsync(out_words, ra->bits_ptr, words * sizeof(u64), hipMemcpyDeviceToHost, CTX.stream)); }
@@ -678,6 +698,7 @@ extern "C" int bwtm_ra_download_bits(bwtm_ra* ra, uint64_t* out_words, uint64_t 
 extern "C" int bwtm_ra_download_runs(bwtm_ra* ra, uint64_t* ranks, uint64_t* counts, uint64_t capacity, uint64_t* nruns)
 {
   if(!ra || !nruns) { return fail(BWTM_EINVAL, "bwtm_ra_download_runs: null argument"); }
+  WHOLE_RA(ra, "bwtm_ra_download_runs");
   ENTER(ra->ctx);
   if(!ra->finalized) { return fail(BWTM_EINVAL, "bwtm_ra_download_runs: rank array not finalized"); }
   const u64 grid = div_up(ra->nchunks * WAVE, BLOCK_THREADS);

@@ -114,6 +114,14 @@ extern "C" int bwtm_ra_range_counts(bwtm_ra* ra, uint64_t rec_first, uint64_t re
   if(!ra || !ones) { return fail(BWTM_EINVAL, "bwtm_ra_range_counts: null argument"); }
   ENTER(ra->ctx);
   TRY(check_range(ra, rec_first, rec_last, "bwtm_ra_range_counts"));
+#ifdef BWTM_EXPERIMENTAL
+  if(ra->windowed && rec_first < rec_last)
+  {
+    // the chunks of the range and the one before it (the halo bwtm_ra_finalize_range installs) must lie inside the window
+    const u64 w0 = (rec_first >= 64 ? (rec_first >> 6) - 1 : 0) * CHUNK_WORDS, w1 = div_up(rec_last, 64) * CHUNK_WORDS;
+    if(w0 < ra->win_word_first || w1 > ra->win_word_first + ra->win_words) { return fail(BWTM_EINVAL, "bwtm_ra_range_counts: the records [%llu, %llu) reach outside the rank array's window", (unsigned long long)rec_first, (unsigned long long)rec_last); }
+  }
+#endif
   const u64 nsup = num_supers(ra->n_out);
   *ones = 0;
   if(super_local) { for(u64 k = 0; k < nsup; k++) { super_local[k] = 0; } }

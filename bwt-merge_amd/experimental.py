@@ -31,6 +31,9 @@ EXPERIMENTAL_SYMBOLS = [
     ("bwtm_x_device_scan", C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), u64, u64, C.c_int]),
     ("bwtm_x_index_window", C.c_int, [vp, u64, u64, C.POINTER(vp)]),
     ("bwtm_x_index_record_bytes", u64, [vp]),
+    ("bwtm_x_ra_create_range", C.c_int, [vp, vp, u64, u64, C.POINTER(vp)]),
+    ("bwtm_x_ra_or_range", C.c_int, [vp, vp, u64, u64]),
+    ("bwtm_x_ra_bytes", u64, [vp]),
     ("bwtm_x_index_upload_window", C.c_int, [C.c_void_p, u64, u64, C.POINTER(u64), u64, u64, C.POINTER(u64), C.POINTER(vp)]),
     ("bwtm_fslice_set_cuts", C.c_int, [vp, C.POINTER(u64), C.c_int]),
     ("bwtm_fslice_gather_cut", C.c_int, [vp, vp, C.c_int, C.c_int]),
@@ -338,3 +341,23 @@ def index_upload_window(data, cum, bases, sequences, pos_first, pos_last):
     out = vp()
     check(lib().bwtm_x_index_upload_window(share.ctypes.data_as(C.c_void_p), share.size, int(starts[b0]), before, int(bases), int(sequences), Cs, C.byref(out)))
     return capi.Index(out)
+
+
+def rank_array_range(a, b, pos_first, pos_last):
+    """The rank array of one part: the bits of the output positions [pos_first, pos_last) and a tile on either side (bwtm_x_ra_create_range)."""
+    _bind()
+    out = vp()
+    check(lib().bwtm_x_ra_create_range(a.h, b.h, int(pos_first), int(pos_last), C.byref(out)))
+    ra = capi.RankArray.__new__(capi.RankArray)
+    ra.h = out; ra.n_out = a.bases + b.bases; ra.nb = b.bases
+    return ra
+
+
+def ra_or_range(dst, src, pos_first, pos_last):
+    _bind()
+    check(lib().bwtm_x_ra_or_range(dst.h, src.h, int(pos_first), int(pos_last)))
+
+
+def ra_bytes(ra):
+    _bind()
+    return int(lib().bwtm_x_ra_bytes(ra.h))

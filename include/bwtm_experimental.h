@@ -74,6 +74,14 @@ int bwtm_x_index_window(const bwtm_index* whole, uint64_t pos_first, uint64_t po
    to the end of the index when the bytes hold its last block.  No GPU ever holds the whole index this way. */
 int bwtm_x_index_upload_window(const uint8_t* data, uint64_t nbytes, uint64_t first_position, const uint64_t counts_before[6],
                                uint64_t bases, uint64_t sequences, const uint64_t C[7], bwtm_index** out);
+/* The rank array of one part: the bits of the output positions [pos_first, pos_last) plus one 65 536-position tile on either side (the
+   boundary segments and the halo chunk of an output range), addressed by absolute positions like a whole one.  It serves bwtm_fslice_*,
+   bwtm_ra_range_counts / _finalize_range / bwtm_interleave_range for ranges inside it, and bwtm_x_ra_or_range; every entry point that walks
+   the whole bitvector refuses it.  bwtm_x_ra_or_range: dst |= src on the words of [pos_first, pos_last) (both must hold them; what crosses a
+   boundary between two GPUs: at most one segment). */
+int bwtm_x_ra_create_range(const bwtm_index* a, const bwtm_index* b, uint64_t pos_first, uint64_t pos_last, bwtm_ra** out);
+int bwtm_x_ra_or_range(bwtm_ra* dst, const bwtm_ra* src, uint64_t pos_first, uint64_t pos_last);
+uint64_t bwtm_x_ra_bytes(const bwtm_ra* ra);                        /* bytes of bitvector the handle holds */
 uint64_t bwtm_x_index_record_bytes(const bwtm_index* index);       /* bytes of records the handle holds (a window: its share) */
 int bwtm_fslice_set_cuts(bwtm_fslice* fs, const uint64_t* r_cuts, int parts);      /* r_cuts[0 .. parts]: R_0 = 0 <= R_1 <= ... ; R_parts is ignored (= everything) */
 int bwtm_fslice_gather_cut(bwtm_fslice* fs, const bwtm_fslice_view* views, int parts, int part);   /* synchronizes */

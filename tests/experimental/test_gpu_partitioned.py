@@ -169,7 +169,8 @@ def partitioned_merge(gpu, a, b, parts, k, node_ratio, from_bytes=False):
     output ranges are the cuts rounded down to encoder segments; a part needs the bits of the neighbouring part inside its first and last
     segment (8 KiB per boundary between real GPUs; the prototype's whole-length bitvectors are simply ORed)."""
     from bwt_merge_amd.dist import fold_offsets, super_owners
-    from bwt_merge_amd.experimental import index_record_bytes, index_upload_window, index_window, partition_cuts, search_partitioned
+    from bwt_merge_amd.experimental import (index_record_bytes, index_upload_window, index_window, partition_cuts, ra_bytes, ra_or_range, rank_array_range,
+                                            search_partitioned)
     MARGIN = 2 * 65536                                                   # positions of A / B a part may read beyond its cuts: one segment + the halo chunk
     ctxs = [gpu.Context(0) for _ in range(parts)]
 
@@ -186,6 +187,7 @@ def partitioned_merge(gpu, a, b, parts, k, node_ratio, from_bytes=False):
         I, R = partition_cuts(A, B, parts, k)
         nrecs = gpu.merged_records(A, B)
         A.free(); B.free()
+    P = [I[g] + R[g] for g in range(parts + 1)]                           # the parts' ranges of the output
     windows, ras = [], []
     for g in range(parts):
         enter(g)
@@ -199,15 +201,21 @@ def partitioned_merge(gpu, a, b, parts, k, node_ratio, from_bytes=False):
             wa = index_window(A, max(0, I[g] - MARGIN), min(a.bases, I[g + 1] + MARGIN))
             wb = index_window(B, max(0, R[g] - MARGIN), min(b.bases, R[g + 1] + MARGIN))
             A.free(); B.free()
-        windows.append((wa, wb)); ras.append(gpu.RankArray(wa, wb))
+        windows.append((wa, wb))
+        # from bytes: the part's rank array holds the bits of its own output range (and a tile on either side), not the whole length
+        ras.append(rank_array_range(wa, wb, P[g], P[g + 1]) if from_bytes else gpu.RankArray(wa, wb))
     search_partitioned(gpu, windows, ras, b.sequences, R, enter, node_ratio=node_ratio)
     # output ranges in records: the cuts' positions rounded down to 65 536-position segments (512 records)
-    seg = [0] + [(I[g] + R[g]) // 65536 for g in range(1, parts)]
+    seg = [0] + [P[g] // 65536 for g in range(1, parts)]
     bounds = [(min(nrecs, seg[g] * 512), nrecs if g == parts - 1 else min(nrecs, seg[g + 1] * 512)) for g in range(parts)]
-    for g in range(parts):                                               # the boundary segments' bits of the neighbours
+    for g in range(parts):                                               # the bits of the parts before it inside a part's first segment
         enter(g)
         for h in range(parts):
-            if h != g:
+            if from_bytes:
+                first, last = max(seg[g] * 65536, P[h]), min(P[g], P[h + 1])
+                if h < g and first < last:
+                    ra_or_range(ras[g], ras[h], first, last)
+            elif h != g:
                 ras[g].or_from(ras[h])
     counts = []
     for g, (first, last) in enumerate(bounds):
@@ -242,6 +250,8 @@ def partitioned_merge(gpu, a, b, parts, k, node_ratio, from_bytes=False):
         x, y = s.samples(nxt)
         be.append(x); cum.append(y)
     held = [index_record_bytes(w[0]) + index_record_bytes(w[1]) for w in windows]
+    if from_bytes:
+        assert sum(ra_bytes(r) for r in ras) <= (a.bases + b.bases) // 8 + parts * 4 * 8192 + 8192      # the bitvector is held once, too
     for g in range(parts):
         enter(g)
         slices[g].free(); ras[g].free(); windows[g][0].free(); windows[g][1].free()
@@ -294,3 +304,18 @@ def test_window_from_bytes_equals_window_of_whole_records(gpu, oracle):
         Cs = (C.c_uint64 * 7)(*[0] * 7)
         out = C.c_void_p()
         X.check(X.lib().bwtm_x_index_upload_window(a.data.ctypes.data_as(C.c_void_p), 64, 5, bad, int(a.bases), int(a.sequences), Cs, C.byref(out)))
+
+
+def test_windows_of_rank_arrays_are_refused_elsewhere(gpu, oracle):
+    from bwt_merge_amd.experimental import ra_bytes, ra_or_range, rank_array_range
+    a = oracle.FMI.from_text(oracle.generate_reads(9911, 3000, 100)); b = oracle.FMI.from_text(oracle.generate_reads(9912, 3000, 100))
+    A = gpu.Index.upload(a.data, a.sequences, a.bases); B = gpu.Index.upload(b.data, b.sequences, b.bases)
+    w = rank_array_range(A, B, 200000, 300000)
+    assert ra_bytes(w) == 4 * 8192                                                       # tiles 3 and 4 and one on either side
+    whole = gpu.RankArray(A, B)
+    for call in (lambda: w.search(A, B, 0, 10), lambda: w.finalize(), lambda: w.bits(), lambda: w.device_buffer(), lambda: whole.or_from(w),
+                 lambda: w.range_counts(0, 512), lambda: ra_or_range(w, whole, 0, 1000), lambda: ra_or_range(whole, w, 500000, 500100)):
+        with pytest.raises(gpu.BwtmError):
+            call()
+    ra_or_range(w, whole, 200000, 300000)                                                 # inside both: fine
+    w.free(); whole.free(); A.free(); B.free()
