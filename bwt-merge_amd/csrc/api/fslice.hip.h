@@ -12,6 +12,8 @@
       <barrier: every GPU has exported>
   Views hold raw device pointers: valid for contexts of one device, and across devices when the peers can access each other's
   memory (the exported buffers come from hipMalloc, not from the pool's device-local mapped blocks).
+
+  The same object also carries the state of the search over PARTITIONED records (fixed cuts, routed node phase): api/partition.hip.h.
 */
 #pragma once
 
@@ -264,351 +266,4 @@ extern "C" int bwtm_x_device_scan(const uint64_t* in, uint64_t* out, uint64_t n,
   HIP_TRY(hipMemcpyAsync(out, buf.p, n * narrays * sizeof(u64), hipMemcpyDeviceToHost, CTX.stream));
   HIP_TRY(hipStreamSynchronize(CTX.stream));
   return BWTM_OK;
-}
-
-extern "C" int bwtm_fslice_set_cuts(bwtm_fslice* fs, const uint64_t* r_cuts, int parts)
-{
-  if(!fs || !r_cuts || parts < 1 || parts > BWTM_X_MAX_PARTS) { return fail(BWTM_EINVAL, "bwtm_fslice_set_cuts: bad argument (at most %d parts)", BWTM_X_MAX_PARTS); }
-  for(int k = 0; k < parts; k++) { if(r_cuts[k] > r_cuts[k + 1] && k + 1 < parts) { return fail(BWTM_EINVAL, "bwtm_fslice_set_cuts: cuts must not decrease"); } }
-  if(r_cuts[0] != 0) { return fail(BWTM_EINVAL, "bwtm_fslice_set_cuts: the first cut is 0"); }
-  ENTER(fs->ctx);
-  if((u32)(5 * parts) > fs->max_pieces) { return fail(BWTM_EINVAL, "bwtm_fslice_set_cuts: more parts than the slice was created for"); }
-  fs->ncuts = (u32)parts + 1;
-  TRY(fs->cuts.alloc(fs->ncuts * sizeof(u64))); TRY(fs->below.alloc(5ull * fs->ncuts * sizeof(u64), true));
-  if(!fs->host_below) { HIP_TRY(hipHostMalloc((void**)&fs->host_below, 5ull * (BWTM_X_MAX_PARTS + 1) * sizeof(u64), hipHostMallocDefault)); }
-  if(!fs->dense_lo)
-  {
-    const u64 fcap = fs->nbl * FR_BLOCK;
-    TRY(fslice_export_alloc(fs, fs->dense_lo, fcap));
-    if(fs->wide) { TRY(fslice_export_alloc(fs, fs->dense_hi, fcap)); }
-    TRY(fs->dense_pieces.alloc((u64)fs->max_pieces * sizeof(DensePiece)));
-    HIP_TRY(hipHostMalloc((void**)&fs->host_dense_pieces, (u64)fs->max_pieces * sizeof(DensePiece), hipHostMallocDefault));
-  }
-  std::memset(fs->host_below, 0, 5ull * (BWTM_X_MAX_PARTS + 1) * sizeof(u64));
-  u64 host_cuts[BWTM_X_MAX_PARTS + 1];
-  for(int k = 0; k <= parts; k++) { host_cuts[k] = (k == parts ? ~0ull : r_cuts[k]); }
-  HIP_TRY(hipMemcpyAsync(fs->cuts.p, host_cuts, fs->ncuts * sizeof(u64), hipMemcpyHostToDevice, CTX.stream));
-  HIP_TRY(hipStreamSynchronize(CTX.stream));                       // host_cuts lives on this stack
-  return BWTM_OK;
-}
-
-extern "C" int bwtm_fslice_gather_cut(bwtm_fslice* fs, const bwtm_fslice_view* views, int parts, int part)
-{
-  if(!fs || !views || parts < 1 || part < 0 || part >= parts) { return fail(BWTM_EINVAL, "bwtm_fslice_gather_cut: bad argument"); }
-  ENTER(fs->ctx);
-  if(fs->ncuts != (u32)parts + 1) { return fail(BWTM_EINVAL, "bwtm_fslice_gather_cut: bwtm_fslice_set_cuts was not called for %d parts", parts); }
-  // The global order of the frontier is (class, GPU, block) and it is sorted by position: this GPU's elements are, in every (class, GPU)
-  // piece, the range between the piece's counts below this GPU's two cuts.
-  u32 np = 0; u64 n_in = 0;
-  for(u32 c = 0; c < 5; c++)
-  {
-    for(int h = 0; h < parts; h++)
-    {
-      const u64 lo_x = views[h].below[c][part], hi_x = views[h].below[c][part + 1];
-      if(lo_x > hi_x || hi_x > views[h].totals[c]) { return fail(BWTM_EINVAL, "bwtm_fslice_gather_cut: counts of GPU %d, class %u are not monotone", h, c); }
-      if(lo_x < hi_x)
-      {
-        DensePiece pc;
-        pc.lo = (const uint2*)views[h].dense_lo; pc.hi = (const unsigned short*)views[h].dense_hi;
-        pc.src_first = views[h].class_first[c] + lo_x; pc.count = hi_x - lo_x; pc.dst_first = n_in;
-        fs->host_dense_pieces[np++] = pc;
-        n_in += hi_x - lo_x;
-      }
-    }
-  }
-  if(n_in > fs->cap) { return fail(BWTM_EINVAL, "bwtm_fslice_gather_cut: %llu elements fall into this GPU's range, capacity %llu", (unsigned long long)n_in, (unsigned long long)fs->cap); }
-  fs->n_in = n_in;
-  if(n_in == 0) { return BWTM_OK; }
-  HIP_TRY(hipMemcpyAsync(fs->dense_pieces.p, fs->host_dense_pieces, (u64)np * sizeof(DensePiece), hipMemcpyHostToDevice, CTX.stream));
-  LAUNCH("frontier_gather", k_gather_dense, div_up(fs->n_in, BLOCK_THREADS), BLOCK_THREADS, fs->dense_pieces.as<const DensePiece>(), np, fs->n_in,
-    fs->lo_in.as<uint2>(), fs->hi_in.as<unsigned short>());
-  HIP_TRY(hipStreamSynchronize(CTX.stream));                       // the peers may overwrite their outputs once every GPU has returned from here
-  return BWTM_OK;
-}
-
-extern "C" int bwtm_x_index_window(const bwtm_index* whole, uint64_t pos_first, uint64_t pos_last, bwtm_index** out)
-{
-  if(!whole || !out || pos_first > pos_last) { return fail(BWTM_EINVAL, "bwtm_x_index_window: bad argument"); }
-  ENTER(whole->ctx);
-  WHOLE_INDEX(whole, "bwtm_x_index_window");
-  if(whole->nrecs == 0 || !whole->recs.p) { return fail(BWTM_EINVAL, "bwtm_x_index_window: the index holds no records"); }
-  const u64 q0 = std::min<u64>(pos_first >> REC_SHIFT, whole->nrecs - 1), q1 = std::min<u64>(pos_last >> REC_SHIFT, whole->nrecs - 1);
-  bwtm_index* w = new bwtm_index();
-  auto body = [&]() -> int
-  {
-    w->n = whole->n; w->m = whole->m; w->nrecs = whole->nrecs; w->nsup = whole->nsup;
-    for(int c = 0; c < 8; c++) { w->C[c] = whole->C[c]; }
-    w->windowed = true; w->win_first = q0; w->win_count = q1 - q0 + 1;
-    TRY(w->recs.alloc(w->win_count * 64));
-    HIP_TRY(hipMemcpyAsync(w->recs.p, (const char*)whole->recs.p + (q0 << 6), w->win_count * 64, hipMemcpyDeviceToDevice, CTX.stream));
-    TRY(w->sup.alloc(whole->nsup * SUP_STRIDE * sizeof(u64)));
-    HIP_TRY(hipMemcpyAsync(w->sup.p, whole->sup.p, whole->nsup * SUP_STRIDE * sizeof(u64), hipMemcpyDeviceToDevice, CTX.stream));
-    return BWTM_OK;
-  };
-  int rc = body();
-  if(rc != BWTM_OK) { delete w; return rc; }
-  *out = w;
-  return BWTM_OK;
-}
-
-extern "C" uint64_t bwtm_x_index_record_bytes(const bwtm_index* x)
-{
-  if(!x) { return 0; }
-  return (x->windowed ? x->win_count : x->nrecs) * 64;
-}
-
-extern "C" int bwtm_fslice_nodes_begin(bwtm_fslice* fs, uint64_t seq_first, uint64_t count, uint64_t node_capacity)
-{
-  if(!fs || node_capacity == 0) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_begin: bad argument"); }
-  ENTER(fs->ctx);
-  if(fs->ncuts == 0) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_begin: call bwtm_fslice_set_cuts first"); }
-  if(count > 0 && seq_first + count > fs->b->m) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_begin: sequences out of range"); }
-  if(!fs->node_sp[0])
-  {
-    fs->node_cap = node_capacity;
-    for(int k = 0; k < 2; k++)
-    {
-      TRY(fslice_export_alloc(fs, fs->node_sp[k], node_capacity)); TRY(fslice_export_alloc(fs, fs->node_r[k], node_capacity)); TRY(fslice_export_alloc(fs, fs->node_cnt[k], node_capacity));
-    }
-    TRY(fs->node_flags.alloc((5 * node_capacity + 1) * sizeof(u64)));
-    fs->node_piece_cap = (u32)std::min<u64>(fs->cap / 16 + 1024, 1ull << 24);
-    TRY(fs->node_pieces.alloc((u64)fs->node_piece_cap * sizeof(RangePiece)));
-    TRY(fs->node_npieces.alloc(sizeof(u32), true));
-    TRY(fs->node_class_first.alloc(6 * sizeof(u64)));
-    TRY(fs->node_err.alloc(sizeof(u32), true));
-    TRY(fs->node_gather_pieces.alloc((u64)fs->max_pieces * sizeof(NodePiece)));
-    HIP_TRY(hipHostMalloc((void**)&fs->host_node_pieces, (u64)fs->max_pieces * sizeof(NodePiece), hipHostMallocDefault));
-  }
-  else if(node_capacity > fs->node_cap) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_begin: the node buffers were created for %llu nodes", (unsigned long long)fs->node_cap); }
-  fs->nodes = 0;
-  if(count > 0)
-  {
-    LAUNCH("range_init", k_range_init, 1, BLOCK_THREADS, fs->node_sp[0], fs->node_r[0], fs->node_cnt[0], seq_first, count, fs->a->m);
-    fs->nodes = 1;
-  }
-  return BWTM_OK;
-}
-
-extern "C" int bwtm_fslice_nodes_step(bwtm_fslice* fs, bwtm_fslice_nodes_view* view)
-{
-  if(!fs || !view) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_step: null argument"); }
-  ENTER(fs->ctx);
-  if(!fs->node_sp[0]) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_step: call bwtm_fslice_nodes_begin first"); }
-  const u64 N = fs->nodes;
-  std::memset(view, 0, sizeof(*view));
-  view->sp = fs->node_sp[1]; view->r = fs->node_r[1]; view->count = fs->node_cnt[1];
-  if(N == 0) { return BWTM_OK; }
-  if(N > fs->node_cap) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_step: %llu nodes, capacity %llu", (unsigned long long)N, (unsigned long long)fs->node_cap); }
-  const u64 grid = div_up(N, BLOCK_THREADS);
-  u64* flags = fs->node_flags.as<u64>();
-  LAUNCH("range_step", k_range_step<false>, grid, BLOCK_THREADS, fs->a->view(), fs->b->view(), (const u64*)fs->node_sp[0], (const u64*)fs->node_r[0], (const u64*)fs->node_cnt[0], N,
-    flags, (const u64*)nullptr, (u64*)nullptr, (u64*)nullptr, (u64*)nullptr, fs->ra->bits_as<u32>(), fs->node_pieces.as<RangePiece>(), fs->node_npieces.as<u32>(), fs->node_piece_cap);
-  LAUNCH("range_emit", k_range_emit, 2048, BLOCK_THREADS, fs->node_pieces.as<const RangePiece>(), fs->node_npieces.as<const u32>(), fs->node_piece_cap, fs->ra->bits_as<u32>());
-  HIP_TRY(hipMemsetAsync(fs->node_npieces.p, 0, sizeof(u32), CTX.stream));
-  TRY(device_scan<0>(flags, flags, 5 * N + 1));
-  TRY(fetch_u64(flags + 5 * N, 0));
-  HIP_TRY(hipStreamSynchronize(CTX.stream));
-  if(CTX.host_scratch[0] > fs->node_cap) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_step: %llu nodes have %llu children, capacity %llu", (unsigned long long)N, (unsigned long long)CTX.host_scratch[0], (unsigned long long)fs->node_cap); }
-  LAUNCH("range_children", k_range_step<true>, grid, BLOCK_THREADS, fs->a->view(), fs->b->view(), (const u64*)fs->node_sp[0], (const u64*)fs->node_r[0], (const u64*)fs->node_cnt[0], N,
-    (u64*)nullptr, (const u64*)flags, fs->node_sp[1], fs->node_r[1], fs->node_cnt[1], (u32*)nullptr, (RangePiece*)nullptr, (u32*)nullptr, 0u);
-  // class c's children are [flags[(c - 1) N], flags[c N]): the six boundaries, then the cut points inside every class
-  u64* cf = fs->node_class_first.as<u64>();
-  for(u32 c = 0; c <= 5; c++) { HIP_TRY(hipMemcpyAsync(cf + c, flags + (u64)c * N, sizeof(u64), hipMemcpyDeviceToDevice, CTX.stream)); }
-  HIP_TRY(hipMemsetAsync(fs->node_err.p, 0, sizeof(u32), CTX.stream));
-  LAUNCH("cut_counts", k_node_cut_search, 1, BLOCK_THREADS, (const u64*)fs->node_sp[1], (const u64*)fs->node_cnt[1], (const u64*)cf, fs->cuts.as<const u64>(), fs->ncuts, fs->below.as<u64>(),
-    fs->node_err.as<u32>());
-  HIP_TRY(hipMemcpyAsync(fs->host_below, fs->below.p, 5ull * fs->ncuts * sizeof(u64), hipMemcpyDeviceToHost, CTX.stream));
-  TRY(fetch_u64(cf, 96, 6));
-  HIP_TRY(hipMemcpyAsync(CTX.host_scratch + 104, fs->node_err.p, sizeof(u32), hipMemcpyDeviceToHost, CTX.stream));
-  HIP_TRY(hipStreamSynchronize(CTX.stream));
-  if((u32)CTX.host_scratch[104] != 0) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_step: a node crosses a cut (cuts must be k-mer boundaries of the merged order)"); }
-  for(u32 c = 0; c <= 5; c++) { view->class_first[c] = CTX.host_scratch[96 + c]; }
-  for(u32 c = 0; c < 5; c++)
-  {
-    const u64 total = view->class_first[c + 1] - view->class_first[c];
-    for(u32 k = 0; k <= BWTM_X_MAX_PARTS; k++) { view->below[c][k] = (k + 1 < fs->ncuts ? fs->host_below[c * fs->ncuts + k] : total); }
-    view->below[c][0] = 0;
-  }
-  return BWTM_OK;
-}
-
-extern "C" int bwtm_fslice_nodes_gather(bwtm_fslice* fs, const bwtm_fslice_nodes_view* views, int parts, int part)
-{
-  if(!fs || !views || parts < 1 || part < 0 || part >= parts) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_gather: bad argument"); }
-  ENTER(fs->ctx);
-  if(fs->ncuts != (u32)parts + 1 || !fs->node_sp[0]) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_gather: cuts / node buffers were not set up for %d parts", parts); }
-  u32 np = 0; u64 n = 0;
-  for(u32 c = 0; c < 5; c++)
-  {
-    for(int h = 0; h < parts; h++)
-    {
-      const u64 lo_x = views[h].below[c][part], hi_x = views[h].below[c][part + 1];
-      if(lo_x > hi_x || hi_x > views[h].class_first[c + 1] - views[h].class_first[c]) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_gather: counts of GPU %d, class %u are not monotone", h, c); }
-      if(lo_x < hi_x)
-      {
-        NodePiece pc;
-        pc.sp = (const u64*)views[h].sp; pc.r = (const u64*)views[h].r; pc.cnt = (const u64*)views[h].count;
-        pc.src_first = views[h].class_first[c] + lo_x; pc.count = hi_x - lo_x; pc.dst_first = n;
-        fs->host_node_pieces[np++] = pc;
-        n += hi_x - lo_x;
-      }
-    }
-  }
-  if(n > fs->node_cap) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_gather: %llu nodes fall into this GPU's range, capacity %llu", (unsigned long long)n, (unsigned long long)fs->node_cap); }
-  fs->nodes = n;
-  if(n == 0) { return BWTM_OK; }
-  HIP_TRY(hipMemcpyAsync(fs->node_gather_pieces.p, fs->host_node_pieces, (u64)np * sizeof(NodePiece), hipMemcpyHostToDevice, CTX.stream));
-  LAUNCH("nodes_gather", k_gather_nodes, div_up(n, BLOCK_THREADS), BLOCK_THREADS, fs->node_gather_pieces.as<const NodePiece>(), np, n, fs->node_sp[0], fs->node_r[0], fs->node_cnt[0]);
-  HIP_TRY(hipStreamSynchronize(CTX.stream));                       // the peers may overwrite their children once every GPU has returned from here
-  return BWTM_OK;
-}
-
-extern "C" int bwtm_fslice_nodes_expand(bwtm_fslice* fs)
-{
-  if(!fs) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_expand: null argument"); }
-  ENTER(fs->ctx);
-  if(!fs->node_sp[0]) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_expand: call bwtm_fslice_nodes_begin first"); }
-  const u64 N = fs->nodes;
-  u64 alive = 0;
-  DevBuf offsets;
-  if(N > 0)
-  {
-    TRY(offsets.alloc((N + 1) * sizeof(u64)));
-    HIP_TRY(hipMemcpyAsync(offsets.p, fs->node_cnt[0], N * sizeof(u64), hipMemcpyDeviceToDevice, CTX.stream));
-    HIP_TRY(hipMemsetAsync(offsets.as<u64>() + N, 0, sizeof(u64), CTX.stream));
-    TRY(device_scan<0>(offsets.as<u64>(), offsets.as<u64>(), N + 1));
-    TRY(fetch_u64(offsets.as<u64>() + N, 0));
-    HIP_TRY(hipStreamSynchronize(CTX.stream));
-    alive = CTX.host_scratch[0];
-  }
-  if(alive > fs->cap) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_expand: the nodes stand for %llu sequences, capacity %llu", (unsigned long long)alive, (unsigned long long)fs->cap); }
-  // the elements as the outputs of a step: contiguous, class 0 (the layout k_frontier_init produces for the roots)
-  fs->nb_out = std::max<u64>(1, div_up(alive, (u64)FR_BLOCK));
-  if(N > 0)
-  {
-    LAUNCH("range_expand", k_range_expand, div_up(N, BLOCK_THREADS), BLOCK_THREADS, (const u64*)fs->node_sp[0], (const u64*)fs->node_r[0], (const u64*)fs->node_cnt[0],
-      offsets.as<const u64>(), N, fs->lo_out, fs->hi_out, fs->node_pieces.as<RangePiece>(), fs->node_npieces.as<u32>(), fs->node_piece_cap);
-    LAUNCH("range_expand_pieces", k_range_expand_pieces, 2048, BLOCK_THREADS, fs->node_pieces.as<const RangePiece>(), fs->node_npieces.as<const u32>(), fs->node_piece_cap, fs->lo_out, fs->hi_out);
-    HIP_TRY(hipMemsetAsync(fs->node_npieces.p, 0, sizeof(u32), CTX.stream));
-  }
-  LAUNCH("frontier_init", k_frontier_init_tables, div_up(5 * fs->nb_out + 1, BLOCK_THREADS), BLOCK_THREADS, fs->seg_len_out.as<u64>(), fs->seg_phys_out, fs->nb_out, alive);
-  fs->nodes = 0;
-  TRY(fslice_scan_outputs(fs));
-  return BWTM_OK;
-}
-
-extern "C" int bwtm_x_index_upload_window(const uint8_t* data, uint64_t nbytes, uint64_t first_position, const uint64_t counts_before[6],
-  uint64_t bases, uint64_t sequences, const uint64_t C[7], bwtm_index** out)
-{
-  ENTER(nullptr);
-  if(!out || !data || nbytes == 0 || !counts_before || !C) { return fail(BWTM_EINVAL, "bwtm_x_index_upload_window: null argument"); }
-  u64 before = 0; for(int c = 0; c < 6; c++) { before += counts_before[c]; }
-  if(before != first_position || first_position > bases) { return fail(BWTM_EINVAL, "bwtm_x_index_upload_window: the counts before the bytes add up to %llu, their first position is %llu", (unsigned long long)before, (unsigned long long)first_position); }
-  bwtm_index* x = new bwtm_index();
-  x->ctx = t_ctx; x->nbytes = nbytes;
-  auto body = [&]() -> int
-  {
-    TRY(alloc_native(x->data, nbytes));
-    // the product's upload pipeline on the share: block lengths and group counts, their scans; the stream's verdict and totals come back
-    int rc = upload_queue(x, data);
-    if(rc == BWTM_OK) { rc = upload_scan(x, 0); }
-    hipError_t e1 = hipStreamSynchronize(CTX.copy_stream), e2 = hipStreamSynchronize(CTX.stream);
-    if(rc != BWTM_OK) { return rc; }
-    if(e1 != hipSuccess || e2 != hipSuccess) { return fail(BWTM_ENODEV, "upload failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); }
-    const u32 flags = (u32)CTX.host_scratch[6];
-    x->flags.release();
-    if(flags & 1u) { return fail(BWTM_EINVAL, "not a canonical run-length stream: a full 64-byte block encodes fewer than 64 positions"); }
-    u64 held = 0; for(int c = 0; c < 6; c++) { held += CTX.host_scratch[c]; }
-    const u64 end_position = first_position + held;
-    if(end_position > bases) { return fail(BWTM_EINVAL, "bwtm_x_index_upload_window: the bytes decode to positions [%llu, %llu) of an index of %llu", (unsigned long long)first_position, (unsigned long long)end_position, (unsigned long long)bases); }
-    // absolute positions and counts: the scanned group tables start at the share's first block
-    const u64 gstride = x->ngroups + 1;
-    for(u32 c = 0; c < 7; c++)
-    {
-      const u64 v = (c < 6 ? counts_before[c] : first_position);
-      if(v != 0) { LAUNCH("add_offset", k_add_offset, div_up(gstride, BLOCK_THREADS), BLOCK_THREADS, x->gcum.as<u64>() + (u64)c * gstride, gstride, v); }
-    }
-    x->n = bases; x->m = sequences;
-    for(int c = 0; c < 7; c++) { x->C[c] = C[c]; }
-    x->C[7] = x->C[6];
-    x->nrecs = num_records(bases); x->nsup = num_supers(bases);
-    // records that begin inside the share (k_build_recs: a group owns the records that START in it; the last group owns the rest, here up to
-    // the record the share ends in, whose tail is only valid when the share holds the end of the index)
-    const u64 q0 = (first_position + REC_POS - 1) >> REC_SHIFT, q_end = (end_position >> REC_SHIFT) + 1;
-    if(q0 >= q_end) { return fail(BWTM_EINVAL, "bwtm_x_index_upload_window: the bytes hold no whole record"); }
-    x->windowed = true; x->win_first = q0; x->win_count = q_end - q0;
-    TRY(x->recs.alloc(x->win_count * 64));
-    TRY(x->sup.alloc(x->nsup * SUP_STRIDE * sizeof(u64)));
-    // super rows: k_build_sup gives a super that begins before the share the counts at the share's first position -- at or below the counts
-    // of every record of the window, which is all a row has to be (header fields are offsets from it)
-    LAUNCH("build_sup", k_build_sup, div_up(x->nsup * WAVE, BLOCK_THREADS), BLOCK_THREADS,
-      x->native_bytes(), x->nbytes, x->blen.as<const u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, end_position, x->sup.as<u64>(), x->nsup);
-    uint4* shifted = (uint4*)((char*)x->recs.p - (q0 << 6));
-    const u64 per_group = held / x->ngroups;
-    const bool long_runs = (x->nblocks > 0 && held / x->nblocks > 400);
-#define BUILD_RECS_W(W, WAVES, FILL) LAUNCH("build_recs", (k_build_recs<W, WAVES, FILL>), div_up(x->ngroups, WAVES), WAVES * WAVE, \
-    x->native_bytes(), x->nbytes, x->blen.as<const u64>(), x->block_start.as<u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, end_position, \
-    x->sup.as<const u64>(), shifted, q_end)
-    if(per_group <= 6500) { BUILD_RECS_W(8192, 4, false); }
-    else if(per_group <= 14000) { BUILD_RECS_W(16384, 4, false); }
-    else if(!long_runs) { BUILD_RECS_W(32768, 2, false); }
-    else { BUILD_RECS_W(32768, 2, true); }
-#undef BUILD_RECS_W
-    HIP_TRY(hipStreamSynchronize(CTX.stream));
-    x->blen.release(); x->block_start.release(); x->gcum.release(); x->data.release();          // a window keeps its records and super rows only
-    x->has_native = false; x->nbytes = 0; x->nblocks = 0; x->ngroups = 0;
-    // the record the share begins in and the one it ends in are incomplete unless they are the index's own first / last
-    if(end_position < bases) { x->win_count -= 1; }
-    if(x->win_count == 0) { return fail(BWTM_EINVAL, "bwtm_x_index_upload_window: the bytes hold no whole record"); }
-    return BWTM_OK;
-  };
-  int rc = body();
-  if(rc != BWTM_OK) { (void)hipStreamSynchronize(CTX.stream); delete x; return rc; }
-  *out = x;
-  return BWTM_OK;
-}
-
-extern "C" int bwtm_x_ra_create_range(const bwtm_index* a, const bwtm_index* b, uint64_t pos_first, uint64_t pos_last, bwtm_ra** out)
-{
-  if(!a || !b || !out || pos_first > pos_last) { return fail(BWTM_EINVAL, "bwtm_x_ra_create_range: bad argument"); }
-  if(a->ctx != b->ctx) { return fail(BWTM_EINVAL, "bwtm_x_ra_create_range: the two indexes live in different contexts"); }
-  ENTER(a->ctx);
-  bwtm_ra* ra = new bwtm_ra();
-  ra->ctx = t_ctx;
-  ra->na = a->n; ra->nb = b->n; ra->n_out = a->n + b->n;
-  ra->nrecs_out = num_records(ra->n_out);
-  ra->nchunks = div_up(ra->nrecs_out, 64);
-  const u64 tile_words = 1ull << (TILE_SHIFT - 6), nwords = ra->nchunks * CHUNK_WORDS;
-  const u64 t0 = (pos_first >> TILE_SHIFT), t1 = div_up(std::min<u64>(pos_last, ra->n_out) + 1, 1ull << TILE_SHIFT);
-  const u64 w0 = (t0 > 0 ? t0 - 1 : 0) * tile_words, w1 = std::min<u64>(nwords, (t1 + 1) * tile_words);
-  ra->windowed = true; ra->win_word_first = w0; ra->win_words = (w1 > w0 ? w1 - w0 : tile_words);
-  int rc = ra->owned_bits.alloc(ra->win_words * sizeof(u64), true);
-  if(rc == BWTM_OK) { ra->bits_ptr = (char*)ra->owned_bits.p - w0 * sizeof(u64); }
-  if(rc == BWTM_OK) { rc = ra->chunk_base.alloc((ra->nchunks + 1) * sizeof(u64), true); }
-  if(rc != BWTM_OK) { delete ra; return rc; }
-  *out = ra;
-  return BWTM_OK;
-}
-
-extern "C" int bwtm_x_ra_or_range(bwtm_ra* dst, const bwtm_ra* src, uint64_t pos_first, uint64_t pos_last)
-{
-  if(!dst || !src || pos_first > pos_last) { return fail(BWTM_EINVAL, "bwtm_x_ra_or_range: bad argument"); }
-  ENTER(dst->ctx);
-  if(dst->n_out != src->n_out) { return fail(BWTM_EINVAL, "bwtm_x_ra_or_range: rank arrays of different shapes"); }
-  if(dst->finalized) { return fail(BWTM_EINVAL, "bwtm_x_ra_or_range: rank array already finalized"); }
-  if(pos_first == pos_last) { return BWTM_OK; }
-  const u64 nwords = dst->nchunks * CHUNK_WORDS;
-  const u64 w0 = pos_first >> 6, w1 = std::min<u64>(nwords, div_up(pos_last, 64));
-  auto holds = [&](const bwtm_ra* r) { return !r->windowed || (w0 >= r->win_word_first && w1 <= r->win_word_first + r->win_words); };
-  if(!holds(dst) || !holds(src)) { return fail(BWTM_EINVAL, "bwtm_x_ra_or_range: the positions [%llu, %llu) reach outside a rank array's window", (unsigned long long)pos_first, (unsigned long long)pos_last); }
-  // the source lives in another context of this device or on a peer: its stream must have finished writing (the caller's barrier)
-  LAUNCH("bits_or", k_bits_or, div_up(w1 - w0, BLOCK_THREADS), BLOCK_THREADS, dst->bits_as<u64>() + w0, src->bits_as<const u64>() + w0, w1 - w0);
-  HIP_TRY(hipStreamSynchronize(CTX.stream));
-  return BWTM_OK;
-}
-
-extern "C" uint64_t bwtm_x_ra_bytes(const bwtm_ra* ra)
-{
-  if(!ra) { return 0; }
-  return (ra->windowed ? ra->win_words : ra->nchunks * CHUNK_WORDS) * sizeof(u64);
 }

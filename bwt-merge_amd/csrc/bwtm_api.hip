@@ -7,6 +7,7 @@
     api/index.hip.h     device index: pipelined upload + transcode, canonical encoder + pipelined download, queries
     api/search.hip.h    rank array: frontier search / per-chain walk, finalize, downloads
     api/fslice.hip.h    one GPU's state of the sliced frontier search (only with -DBWTM_EXPERIMENTAL; include/bwtm_experimental.h)
+    api/partition.hip.h the merge over partitioned records: windows of indexes and rank arrays, fixed cuts, routed node phase (same build only)
     api/merge.hip.h     interleave, whole-path entry points (device-resident, consuming, host-to-host)
     api/slices.hip.h    output-range-sharded interleave + encode (one slice per GPU)
 */
@@ -36,6 +37,7 @@ using namespace bwtm;
 #ifdef BWTM_EXPERIMENTAL
 #include "../../include/bwtm_experimental.h"
 #include "api/fslice.hip.h"
+#include "api/partition.hip.h"
 #endif
 #include "api/merge.hip.h"
 #include "api/slices.hip.h"
