@@ -319,3 +319,29 @@ def test_windows_of_rank_arrays_are_refused_elsewhere(gpu, oracle):
             call()
     ra_or_range(w, whole, 200000, 300000)                                                 # inside both: fine
     w.free(); whole.free(); A.free(); B.free()
+
+
+def repetitive_reads(seed, genome_len, nreads, readlen):
+    """Reads of one random genome at high coverage: a BWT of long runs (the other window sizes of k_build_recs and its fill path)."""
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(1, 5, genome_len, dtype=np.uint8)
+    starts = rng.integers(0, genome_len - readlen, nreads)
+    out = np.zeros((nreads, readlen + 1), dtype=np.uint8)
+    for k, s in enumerate(starts):
+        out[k, :readlen] = genome[s: s + readlen]
+    return out.reshape(-1)
+
+
+@pytest.mark.parametrize("glen,coverage", [(300000, 2), (200000, 4), (6000, 60)])
+def test_partitioned_merge_of_repetitive_reads(gpu, oracle, glen, coverage):
+    """Windows transcoded from byte shares of compressible streams, cuts inside long runs: ~150, ~250 and ~760 positions per 64-byte block are
+    the three other window sizes of k_build_recs (16 384 positions, 32 768, 32 768 with the cooperative fill of long runs)."""
+    nreads = coverage * glen // 100
+    a = oracle.FMI.from_text(repetitive_reads(31, glen, nreads, 100)); b = oracle.FMI.from_text(repetitive_reads(32, glen, nreads * 3 // 4, 100))
+    per_block = a.bases / a.blocks
+    assert {2: 105 < per_block < 225, 4: 225 < per_block < 400, 60: per_block > 400}[coverage], per_block
+    data, be, cum, held, bounds = partitioned_merge(gpu, a, b, 3, 3, 8, from_bytes=True)
+    m, _ = oracle.merge(a, b, threads=2)
+    assert np.array_equal(data, m.data)
+    obe, ocum = m.samples
+    assert np.array_equal(be, obe) and np.array_equal(cum, ocum[:, :-1])
