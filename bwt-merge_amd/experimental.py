@@ -361,3 +361,125 @@ def ra_or_range(dst, src, pos_first, pos_last):
 def ra_bytes(ra):
     _bind()
     return int(lib().bwtm_x_ra_bytes(ra.h))
+
+
+MERGE_MARGIN = 2 * 65536        # positions of A / B a part may read beyond its cuts: one encoder segment + the halo chunk
+
+
+def merge_partitioned(pkg, a, b, parts, cuts, from_bytes=True, node_ratio=8, capacity=None, node_capacity=None, profile=False, keep_data=True):
+    """The whole merge over partitioned records, driven from ONE host thread over `parts` contexts of one GPU (one GPU each on a real machine):
+    a, b = the inputs on the HOST (objects with .data = the native bytes, .samples = (block_end, cum[6][blocks + 1]), .bases, .sequences);
+    cuts = (I, R) from partition_cuts.  Every part
+      1. transcodes its windows of A and B from its own share of the native bytes (from_bytes = False: cuts them from whole records, which it
+         uploads first) and creates the rank array of its own output range,
+      2. searches: node phase and element steps with the elements routed by position (search_partitioned),
+      3. takes the earlier parts' bits inside its first output segment, and finalizes / interleaves / encodes its range of the output from its
+         windows with the product's range entry points (the output ranges are the cuts rounded down to 65 536-position segments).
+    Returns a dict: data (the parts' native bytes, in order), block_end / cum (their sample arrays), bounds, held (bytes of records per part),
+    ra_bytes, and with profile = True the kernel milliseconds of every part by phase."""
+    import numpy as np
+    from .dist import fold_offsets, super_owners
+    I, R = cuts
+    na, nb = int(a.bases), int(b.bases)
+    nrecs = ((na + nb) >> 7) + 1
+    P = [I[g] + R[g] for g in range(parts + 1)]                           # the parts' ranges of the output
+    ctxs = [pkg.Context(0) for _ in range(parts)]
+    phases = [dict() for _ in range(parts)]
+
+    def enter(g):
+        ctxs[g].make_current()
+
+    def begin(g):
+        enter(g)
+        if profile:
+            pkg.profile_only(None); pkg.profile_reset(); pkg.profile_enable(True)
+
+    def end(g, name):
+        if profile:
+            enter(g)
+            pkg.synchronize()
+            phases[g][name] = phases[g].get(name, 0.0) + sum(v[0] for v in pkg.profile_read().values())
+            pkg.profile_enable(False)
+
+    windows, ras = [], []
+    for g in range(parts):
+        begin(g)
+        a_lo, a_hi = max(0, I[g] - MERGE_MARGIN), min(na, I[g + 1] + MERGE_MARGIN)
+        b_lo, b_hi = max(0, R[g] - MERGE_MARGIN), min(nb, R[g + 1] + MERGE_MARGIN)
+        if from_bytes:
+            wa = index_upload_window(a.data, a.samples[1], na, a.sequences, a_lo, a_hi)
+            wb = index_upload_window(b.data, b.samples[1], nb, b.sequences, b_lo, b_hi)
+        else:
+            A = pkg.Index.upload(a.data, a.sequences, na); B = pkg.Index.upload(b.data, b.sequences, nb)
+            wa, wb = index_window(A, a_lo, a_hi), index_window(B, b_lo, b_hi)
+            A.free(); B.free()
+        windows.append((wa, wb))
+        ras.append(rank_array_range(wa, wb, P[g], P[g + 1]) if from_bytes else pkg.RankArray(wa, wb))
+        end(g, "transcode")
+    for g in range(parts):
+        begin(g)
+    steps, levels, largest, work = search_partitioned(pkg, windows, ras, int(b.sequences), R, enter, capacity=capacity, node_ratio=node_ratio, node_capacity=node_capacity)
+    for g in range(parts):
+        end(g, "search")
+    seg = [0] + [P[g] // 65536 for g in range(1, parts)]
+    bounds = [(min(nrecs, seg[g] * 512), nrecs if g == parts - 1 else min(nrecs, seg[g + 1] * 512)) for g in range(parts)]
+    for g in range(parts):
+        begin(g)
+        for h in range(parts):
+            if from_bytes:
+                first, last = max(seg[g] * 65536, P[h]), min(P[g], P[h + 1])
+                if h < g and first < last:
+                    ra_or_range(ras[g], ras[h], first, last)
+            elif h != g:
+                ras[g].or_from(ras[h])
+    counts = []
+    for g, (first, last) in enumerate(bounds):
+        enter(g)
+        counts.append(ras[g].range_counts(first, last))
+    totals = [c[0] for c in counts]
+    if sum(totals) != nb:
+        raise BwtmError("the parts' ranges hold %d set bits, b has %d positions" % (sum(totals), nb))
+    nsup = counts[0][1].size
+    owner = super_owners(nsup, bounds)
+    prefix = np.concatenate([[0], np.cumsum(totals)]).astype(np.uint64)
+    super_boff = prefix[owner] + sum(c[1] for c in counts)
+    slices = []
+    for g, (first, last) in enumerate(bounds):
+        enter(g)
+        halo = next((counts[h][2] for h in range(g - 1, -1, -1) if bounds[h][1] > bounds[h][0]), None)
+        ras[g].finalize_range(first, last, int(prefix[g]), int(prefix[parts]), super_boff, halo)
+        slices.append(pkg.Slice(windows[g][0], windows[g][1], ras[g], first, last))
+    heads = []
+    for g, s in enumerate(slices):
+        enter(g); heads.append(s.lasthead())
+    tables = []
+    for g, s in enumerate(slices):
+        enter(g); tables.append(s.size_table(max(heads[:g], default=0)))
+    offsets = fold_offsets(tables)
+    data, starts, nbytes = [], [], []
+    for g, (s, off) in enumerate(zip(slices, offsets)):
+        enter(g); s.encode(off); starts.append(s.first_block_start()); nbytes.append(s.nbytes)
+    for g in range(parts):
+        end(g, "finalize_interleave_encode")
+    be, cum = [], []
+    for g, s in enumerate(slices):
+        enter(g)
+        if keep_data:
+            data.append(s.data())
+        nxt = next((p for p in starts[g + 1:] if p is not None), na + nb)
+        x, y = s.samples(nxt)
+        be.append(x); cum.append(y)
+    out = dict(data=data, block_end=be, cum=cum, bounds=bounds, offsets=offsets, nbytes=nbytes, steps=steps, levels=levels, largest=largest, work=work,
+               held=[index_record_bytes(w[0]) + index_record_bytes(w[1]) for w in windows], ra_bytes=[ra_bytes(r) if from_bytes else (na + nb) // 8 for r in ras],
+               phases=phases, slices=slices)
+    out["release"] = lambda: _release_partitioned(pkg, ctxs, slices, ras, windows)
+    return out
+
+
+def _release_partitioned(pkg, ctxs, slices, ras, windows):
+    for g in range(len(ctxs)):
+        ctxs[g].make_current()
+        slices[g].free(); ras[g].free(); windows[g][0].free(); windows[g][1].free()
+    pkg.make_default_current()
+    for c in ctxs:
+        c.destroy()

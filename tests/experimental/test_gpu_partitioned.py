@@ -164,101 +164,22 @@ class HostIndex:
 
 
 def partitioned_merge(gpu, a, b, parts, k, node_ratio, from_bytes=False):
-    """The whole merge over partitioned records: search on windows, then every part finalizes, interleaves and encodes its own range of the
-    output from its windows (the range machinery of the product: bwtm_ra_range_counts / finalize_range / interleave_range / slice_*).  The
-    output ranges are the cuts rounded down to encoder segments; a part needs the bits of the neighbouring part inside its first and last
-    segment (8 KiB per boundary between real GPUs; the prototype's whole-length bitvectors are simply ORed)."""
-    from bwt_merge_amd.dist import fold_offsets, super_owners
-    from bwt_merge_amd.experimental import (index_record_bytes, index_upload_window, index_window, partition_cuts, ra_bytes, ra_or_range, rank_array_range,
-                                            search_partitioned)
-    MARGIN = 2 * 65536                                                   # positions of A / B a part may read beyond its cuts: one segment + the halo chunk
-    ctxs = [gpu.Context(0) for _ in range(parts)]
-
-    def enter(g):
-        ctxs[g].make_current()
-
-    enter(0)
+    """experimental.merge_partitioned on G contexts of one GPU: windows (from byte shares: no context ever holds a whole index, the cuts come
+    from the host's copy, the oracle here), search with routing, then every part finalizes, interleaves and encodes its own range."""
+    from bwt_merge_amd.experimental import merge_partitioned, partition_cuts
     if from_bytes:
-        # the cuts from the host's copy of the indexes (the oracle here): the device never sees a whole index
-        I, R = partition_cuts(HostIndex(a), HostIndex(b), parts, k)
-        nrecs = ((a.bases + b.bases) >> 7) + 1
+        cuts = partition_cuts(HostIndex(a), HostIndex(b), parts, k)
     else:
         A = gpu.Index.upload(a.data, a.sequences, a.bases); B = gpu.Index.upload(b.data, b.sequences, b.bases)
-        I, R = partition_cuts(A, B, parts, k)
-        nrecs = gpu.merged_records(A, B)
+        cuts = partition_cuts(A, B, parts, k)
         A.free(); B.free()
-    P = [I[g] + R[g] for g in range(parts + 1)]                           # the parts' ranges of the output
-    windows, ras = [], []
-    for g in range(parts):
-        enter(g)
+    out = merge_partitioned(gpu, a, b, parts, cuts, from_bytes=from_bytes, node_ratio=node_ratio)
+    try:
         if from_bytes:
-            # every part transcodes its windows from its own share of the native bytes (the blocks named by the inputs' sample arrays):
-            # no context ever holds a whole index
-            wa = index_upload_window(a.data, a.samples[1], a.bases, a.sequences, max(0, I[g] - MARGIN), min(a.bases, I[g + 1] + MARGIN))
-            wb = index_upload_window(b.data, b.samples[1], b.bases, b.sequences, max(0, R[g] - MARGIN), min(b.bases, R[g + 1] + MARGIN))
-        else:
-            A = gpu.Index.upload(a.data, a.sequences, a.bases); B = gpu.Index.upload(b.data, b.sequences, b.bases)
-            wa = index_window(A, max(0, I[g] - MARGIN), min(a.bases, I[g + 1] + MARGIN))
-            wb = index_window(B, max(0, R[g] - MARGIN), min(b.bases, R[g + 1] + MARGIN))
-            A.free(); B.free()
-        windows.append((wa, wb))
-        # from bytes: the part's rank array holds the bits of its own output range (and a tile on either side), not the whole length
-        ras.append(rank_array_range(wa, wb, P[g], P[g + 1]) if from_bytes else gpu.RankArray(wa, wb))
-    search_partitioned(gpu, windows, ras, b.sequences, R, enter, node_ratio=node_ratio)
-    # output ranges in records: the cuts' positions rounded down to 65 536-position segments (512 records)
-    seg = [0] + [P[g] // 65536 for g in range(1, parts)]
-    bounds = [(min(nrecs, seg[g] * 512), nrecs if g == parts - 1 else min(nrecs, seg[g + 1] * 512)) for g in range(parts)]
-    for g in range(parts):                                               # the bits of the parts before it inside a part's first segment
-        enter(g)
-        for h in range(parts):
-            if from_bytes:
-                first, last = max(seg[g] * 65536, P[h]), min(P[g], P[h + 1])
-                if h < g and first < last:
-                    ra_or_range(ras[g], ras[h], first, last)
-            elif h != g:
-                ras[g].or_from(ras[h])
-    counts = []
-    for g, (first, last) in enumerate(bounds):
-        enter(g)
-        counts.append(ras[g].range_counts(first, last))
-    totals = [c[0] for c in counts]
-    assert sum(totals) == b.bases
-    nsup = counts[0][1].size
-    owner = super_owners(nsup, bounds)
-    prefix = np.concatenate([[0], np.cumsum(totals)]).astype(np.uint64)
-    super_boff = prefix[owner] + sum(c[1] for c in counts)
-    slices = []
-    for g, (first, last) in enumerate(bounds):
-        enter(g)
-        halo = next((counts[h][2] for h in range(g - 1, -1, -1) if bounds[h][1] > bounds[h][0]), None)
-        ras[g].finalize_range(first, last, int(prefix[g]), int(prefix[parts]), super_boff, halo)
-        slices.append(gpu.Slice(windows[g][0], windows[g][1], ras[g], first, last))
-    heads = []
-    for g, s in enumerate(slices):
-        enter(g); heads.append(s.lasthead())
-    tables = []
-    for g, s in enumerate(slices):
-        enter(g); tables.append(s.size_table(max(heads[:g], default=0)))
-    offsets = fold_offsets(tables)
-    data, starts = [], []
-    for g, (s, off) in enumerate(zip(slices, offsets)):
-        enter(g); s.encode(off); data.append(s.data()); starts.append(s.first_block_start())
-    be, cum = [], []
-    for g, s in enumerate(slices):
-        enter(g)
-        nxt = next((p for p in starts[g + 1:] if p is not None), a.bases + b.bases)
-        x, y = s.samples(nxt)
-        be.append(x); cum.append(y)
-    held = [index_record_bytes(w[0]) + index_record_bytes(w[1]) for w in windows]
-    if from_bytes:
-        assert sum(ra_bytes(r) for r in ras) <= (a.bases + b.bases) // 8 + parts * 4 * 8192 + 8192      # the bitvector is held once, too
-    for g in range(parts):
-        enter(g)
-        slices[g].free(); ras[g].free(); windows[g][0].free(); windows[g][1].free()
-    gpu.make_default_current()
-    for c in ctxs:
-        c.destroy()
-    return np.concatenate(data), np.concatenate(be), np.concatenate(cum, axis=1), held, bounds
+            assert sum(out["ra_bytes"]) <= (a.bases + b.bases) // 8 + parts * 4 * 8192 + 8192      # the bitvector is held once, too
+        return np.concatenate(out["data"]), np.concatenate(out["block_end"]), np.concatenate(out["cum"], axis=1), out["held"], out["bounds"]
+    finally:
+        out["release"]()
 
 
 @pytest.mark.parametrize("parts,k,node_ratio,from_bytes", [(1, 2, 8, False), (2, 1, 8, False), (3, 3, 0, False), (4, 4, 8, False), (8, 4, 8, False),
