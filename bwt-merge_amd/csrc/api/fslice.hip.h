@@ -49,6 +49,7 @@ struct bwtm_fslice
   DevBuf cuts, below, dense_pieces; u64* host_below = nullptr; u32 ncuts = 0;
   uint2* dense_lo = nullptr; unsigned short* dense_hi = nullptr;     // exported (hipMalloc): the outputs in logical order, the send buffer of the exchange
   DensePiece* host_dense_pieces = nullptr;
+  uint2* recv_lo = nullptr; unsigned short* recv_hi = nullptr;       // (hipMalloc, so that a collective of another library may write them) where an exchange between processes delivers the next input
   // node phase over partitioned records (bwtm_fslice_nodes_*): this level's nodes [0], their children [1] (exported, hipMalloc)
   u64* node_sp[2] = {nullptr, nullptr}; u64* node_r[2] = {nullptr, nullptr}; u64* node_cnt[2] = {nullptr, nullptr};
   u64 node_cap = 0, nodes = 0;

@@ -75,6 +75,37 @@ extern "C" int bwtm_fslice_gather_cut(bwtm_fslice* fs, const bwtm_fslice_view* v
   return BWTM_OK;
 }
 
+extern "C" int bwtm_fslice_input_buffers(bwtm_fslice* fs, void** lo, void** hi, uint64_t* capacity)
+{
+  if(!fs || !lo || !hi || !capacity) { return fail(BWTM_EINVAL, "bwtm_fslice_input_buffers: null argument"); }
+  ENTER(fs->ctx);
+  if(!fs->recv_lo)
+  {
+    // plain hipMalloc blocks like everything a peer or a collective touches (the pool's large blocks are mapped for their own device only)
+    const u64 fcap = fs->nbl * FR_BLOCK;
+    TRY(fslice_export_alloc(fs, fs->recv_lo, fcap));
+    if(fs->wide) { TRY(fslice_export_alloc(fs, fs->recv_hi, fcap)); }
+  }
+  *lo = fs->recv_lo; *hi = fs->recv_hi; *capacity = fs->cap;
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_fslice_set_input(bwtm_fslice* fs, uint64_t count)
+{
+  if(!fs) { return fail(BWTM_EINVAL, "bwtm_fslice_set_input: null argument"); }
+  ENTER(fs->ctx);
+  if(!fs->recv_lo) { return fail(BWTM_EINVAL, "bwtm_fslice_set_input: call bwtm_fslice_input_buffers first"); }
+  if(count > fs->cap) { return fail(BWTM_EINVAL, "bwtm_fslice_set_input: %llu elements, capacity %llu", (unsigned long long)count, (unsigned long long)fs->cap); }
+  // the caller has waited for its exchange: the elements are in the receive buffers (a production version would step on them in place)
+  if(count > 0)
+  {
+    HIP_TRY(hipMemcpyAsync(fs->lo_in.p, fs->recv_lo, count * sizeof(uint2), hipMemcpyDeviceToDevice, CTX.stream));
+    if(fs->wide) { HIP_TRY(hipMemcpyAsync(fs->hi_in.p, fs->recv_hi, count * sizeof(unsigned short), hipMemcpyDeviceToDevice, CTX.stream)); }
+  }
+  fs->n_in = count;
+  return BWTM_OK;
+}
+
 extern "C" int bwtm_x_index_window(const bwtm_index* whole, uint64_t pos_first, uint64_t pos_last, bwtm_index** out)
 {
   if(!whole || !out || pos_first > pos_last) { return fail(BWTM_EINVAL, "bwtm_x_index_window: bad argument"); }

@@ -37,6 +37,8 @@ EXPERIMENTAL_SYMBOLS = [
     ("bwtm_x_index_upload_window", C.c_int, [C.c_void_p, u64, u64, C.POINTER(u64), u64, u64, C.POINTER(u64), C.POINTER(vp)]),
     ("bwtm_fslice_set_cuts", C.c_int, [vp, C.POINTER(u64), C.c_int]),
     ("bwtm_fslice_gather_cut", C.c_int, [vp, vp, C.c_int, C.c_int]),
+    ("bwtm_fslice_input_buffers", C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]),
+    ("bwtm_fslice_set_input", C.c_int, [vp, u64]),
     ("bwtm_fslice_nodes_begin", C.c_int, [vp, u64, u64, u64]),
     ("bwtm_fslice_nodes_step", C.c_int, [vp, vp]),
     ("bwtm_fslice_nodes_gather", C.c_int, [vp, vp, C.c_int, C.c_int]),
@@ -116,6 +118,16 @@ class FSlice:
 
     def gather_cut(self, views, parts, part):
         check(lib().bwtm_fslice_gather_cut(self.h, C.byref(views), parts, part))
+
+    def input_buffers(self):
+        """(device address of the input coordinates, of their high bytes or None, capacity in elements): where an exchange between processes
+        delivers this slice's next input (experimental_dist.py)."""
+        lo, hi, cap = vp(), vp(), u64(0)
+        check(lib().bwtm_fslice_input_buffers(self.h, C.byref(lo), C.byref(hi), C.byref(cap)))
+        return lo.value, hi.value, int(cap.value)
+
+    def set_input(self, count):
+        check(lib().bwtm_fslice_set_input(self.h, int(count)))
 
     def nodes_begin(self, seq_first, count, node_capacity):
         check(lib().bwtm_fslice_nodes_begin(self.h, seq_first, count, node_capacity))

@@ -1,0 +1,88 @@
+"""The per-step exchange of the partitioned search between PROCESSES (one per GPU, torch.distributed: RCCL on GPUs, gloo on CPU) -- the
+multi-process form of experimental.search_partitioned, which drives contexts of one GPU from one thread.
+
+After a step every rank holds its outputs as ONE dense array in logical order: class after class, increasing position inside a class, and
+knows per class how many of them lie below every cut (bwtm_fslice_view.below).  Class c's range of that array is therefore already ordered
+by destination, and what a rank receives for class c, source after source, is increasing position again: the exchange is one
+all_to_all_single per class on the send buffer as it is, and the concatenation of the five results is the rank's next input.
+
+  exchange_plan         the split sizes of those calls from the all-gathered counts
+  all_to_all_classes    the five calls
+  search_partitioned_dist   the element steps of the search on this rank's windows (needs libbwtm_experimental.so and a GPU)
+The plan and the calls are plain tensor code: tests/test_partition_dist_host.py runs them over gloo with 2 and 3 ranks on the CPU.
+"""
+
+
+def exchange_plan(below_all, rank, world):
+    """below_all[h][c][k] = elements of rank h's class c below cut k (k = 0 .. world; below[..][0] = 0, below[..][world] = all of the class).
+    Returns (send[c][k] = this rank's elements of class c that go to rank k, recv[c][h] = elements of class c it gets from rank h)."""
+    send = [[int(below_all[rank][c][k + 1]) - int(below_all[rank][c][k]) for k in range(world)] for c in range(5)]
+    recv = [[int(below_all[h][c][rank + 1]) - int(below_all[h][c][rank]) for h in range(world)] for c in range(5)]
+    return send, recv
+
+
+def all_to_all_classes(dist, send_buf, class_first, send, recv, recv_buf):
+    """Five all_to_all_single calls, one per class: class c's elements leave from send_buf[class_first[c] ...] (ordered by destination) and
+    arrive behind the classes before it, source after source.  Returns the number of elements received."""
+    off = 0
+    for c in range(5):
+        n_send, n_recv = sum(send[c]), sum(recv[c])
+        dist.all_to_all_single(recv_buf[off: off + n_recv], send_buf[int(class_first[c]): int(class_first[c]) + n_send],
+                               output_split_sizes=recv[c], input_split_sizes=send[c])
+        off += n_recv
+    return off
+
+
+class _DeviceArray:
+    """A device pointer of the library as something torch.as_tensor takes without a copy."""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def device_tensor(torch, device, ptr, count, typestr):
+    return torch.as_tensor(_DeviceArray(ptr, count, typestr), device=device)
+
+
+def search_partitioned_dist(pkg, wa, wb, ra, sequences, r_cuts, rank, world, dist, torch, device, capacity=None):
+    """The element steps of the partitioned search on this rank (GPU `device`): wa / wb = its windows, ra = its rank array, r_cuts = the B
+    ranks of the cuts (world + 1 of them).  Roots are seeded on the rank that owns them.  Returns the number of steps."""
+    import ctypes as C
+    import numpy as np
+    from . import experimental as X
+    cap = int(capacity) if capacity else int(sequences) + 1
+    fs = X.FSlice(wa, wb, ra, cap, world)
+    fs.set_cuts(r_cuts)
+    first, last = min(int(r_cuts[rank]), sequences), min(int(r_cuts[rank + 1]), sequences)
+    fs.seed(first, last - first)
+    view = X.FSliceView()
+    lo_in, hi_in, in_cap = fs.input_buffers()
+    recv_lo = device_tensor(torch, device, lo_in, in_cap, "<i8")
+    recv_hi = device_tensor(torch, device, hi_in, in_cap, "<i2") if hi_in else None
+    steps = 0
+    while True:
+        fs.export(view)                                              # synchronizes the library's stream: the dense outputs are complete
+        mine = torch.tensor([[int(view.below[c][k]) for k in range(world + 1)] for c in range(5)], dtype=torch.int64, device=device)
+        everyone = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        below_all = [t.cpu().numpy() for t in everyone]
+        if sum(int(b[c][world]) for b in below_all for c in range(5)) == 0:
+            break
+        send, recv = exchange_plan(below_all, rank, world)
+        n_in = sum(sum(x) for x in recv)
+        if n_in > cap:
+            raise X.BwtmError("%d elements fall into rank %d's range, capacity %d" % (n_in, rank, cap))
+        held = sum(int(view.totals[c]) for c in range(5))
+        class_first = [int(view.class_first[c]) for c in range(6)]
+        send_lo = device_tensor(torch, device, view.dense_lo, max(held, 1), "<i8")
+        all_to_all_classes(dist, send_lo, class_first, send, recv, recv_lo)
+        if recv_hi is not None:
+            all_to_all_classes(dist, device_tensor(torch, device, view.dense_hi, max(held, 1), "<i2"), class_first, send, recv, recv_hi)
+        torch.cuda.synchronize(device)                               # the collectives ran on torch's stream
+        dist.barrier()                                               # every rank has received: the send buffers may be overwritten
+        fs.set_input(n_in)
+        fs.advance()
+        steps += 1
+    fs.finish()
+    fs.free()
+    return steps

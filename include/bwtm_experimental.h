@@ -85,6 +85,10 @@ uint64_t bwtm_x_ra_bytes(const bwtm_ra* ra);                        /* bytes of 
 uint64_t bwtm_x_index_record_bytes(const bwtm_index* index);       /* bytes of records the handle holds (a window: its share) */
 int bwtm_fslice_set_cuts(bwtm_fslice* fs, const uint64_t* r_cuts, int parts);      /* r_cuts[0 .. parts]: R_0 = 0 <= R_1 <= ... ; R_parts is ignored (= everything) */
 int bwtm_fslice_gather_cut(bwtm_fslice* fs, const bwtm_fslice_view* views, int parts, int part);   /* synchronizes */
+/* The same step between processes (one per GPU): the caller moves the elements itself -- an all-to-all-v over the views' dense send buffers,
+   bwt-merge_amd/experimental_dist.py -- straight into the slice's input buffers, and says how many arrived. */
+int bwtm_fslice_input_buffers(bwtm_fslice* fs, void** lo, void** hi, uint64_t* capacity);      /* hi: NULL below 2^32 positions */
+int bwtm_fslice_set_input(bwtm_fslice* fs, uint64_t count);
 
 /* The first levels on trie NODES over partitioned records (the node phase of bwtm_search, fmi.cpp:286-323, with the nodes routed like the
    elements): a node (sp, count, r) lives on the GPU that owns sp; its children are exported class by class with their counts below every

@@ -1,0 +1,46 @@
+"""experimental_dist.search_partitioned_dist on ONE rank over RCCL: the library's device buffers handed to torch.distributed without a copy
+(the dense send buffer, the receive buffers), the all-gathered counts, five all_to_all_single calls per step -- with itself here.  More
+ranks run the same code; their exchange logic is covered over gloo on the CPU (tests/test_partition_dist_host.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(bwtm):
+    bwtm.init(0)
+    from bwt_merge_amd import experimental
+    assert experimental.loaded(), "these tests need BWTM_LIB=libbwtm_experimental.so"
+    yield bwtm
+    bwtm.make_default_current()
+    bwtm.trim()
+
+
+def test_one_rank_over_rccl_equals_oracle(gpu, oracle):
+    import torch
+    import torch.distributed as dist
+    from bwt_merge_amd.experimental_dist import search_partitioned_dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        ta = oracle.generate_reads(9951, 2000, 80)
+        tb = np.concatenate([oracle.generate_reads(9952 + j, 300, int(n)) for j, n in enumerate([1, 25, 80, 121])])
+        a, b = oracle.FMI.from_text(ta), oracle.FMI.from_text(tb)
+        ranks, counts, _ = oracle.search(a, b, threads=2)
+        A = gpu.Index.upload(a.data, a.sequences, a.bases); B = gpu.Index.upload(b.data, b.sequences, b.bases)
+        ra = gpu.RankArray(A, B)
+        steps = search_partitioned_dist(gpu, A, B, ra, b.sequences, [0, b.bases], 0, 1, dist, torch, dev)
+        assert steps == 122
+        ra.finalize()
+        got_r, got_c = ra.runs()
+        assert np.array_equal(got_r, ranks) and np.array_equal(got_c, counts)
+        ra.free(); A.free(); B.free()
+    finally:
+        dist.destroy_process_group()
