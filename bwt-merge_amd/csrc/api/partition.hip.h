@@ -387,6 +387,42 @@ extern "C" int bwtm_x_ra_or_range(bwtm_ra* dst, const bwtm_ra* src, uint64_t pos
   return BWTM_OK;
 }
 
+namespace
+{
+// the words [w0, w1) of a rank array that the handle holds: [h0, h1)
+void ra_held_words(const bwtm_ra* ra, u64 w0, u64 w1, u64& h0, u64& h1)
+{
+  const u64 lo = (ra->windowed ? ra->win_word_first : 0), hi = (ra->windowed ? ra->win_word_first + ra->win_words : ra->nchunks * CHUNK_WORDS);
+  h0 = std::max(w0, lo); h1 = std::min(w1, hi);
+  if(h0 > h1) { h0 = h1 = w0; }
+}
+} // namespace
+
+extern "C" int bwtm_x_ra_read_words(const bwtm_ra* ra, uint64_t pos_first, uint64_t pos_last, void* device_out)
+{
+  if(!ra || !device_out || pos_first > pos_last) { return fail(BWTM_EINVAL, "bwtm_x_ra_read_words: bad argument"); }
+  ENTER(ra->ctx);
+  const u64 w0 = pos_first >> 6, w1 = div_up(pos_last, 64);
+  if(w1 == w0) { return BWTM_OK; }
+  u64 h0, h1; ra_held_words(ra, w0, w1, h0, h1);
+  HIP_TRY(hipMemsetAsync(device_out, 0, (w1 - w0) * sizeof(u64), CTX.stream));
+  if(h1 > h0) { HIP_TRY(hipMemcpyAsync((u64*)device_out + (h0 - w0), ra->bits_as<const u64>() + h0, (h1 - h0) * sizeof(u64), hipMemcpyDeviceToDevice, CTX.stream)); }
+  HIP_TRY(hipStreamSynchronize(CTX.stream));
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_x_ra_or_words(bwtm_ra* ra, uint64_t pos_first, uint64_t pos_last, const void* device_in)
+{
+  if(!ra || !device_in || pos_first > pos_last) { return fail(BWTM_EINVAL, "bwtm_x_ra_or_words: bad argument"); }
+  ENTER(ra->ctx);
+  if(ra->finalized) { return fail(BWTM_EINVAL, "bwtm_x_ra_or_words: rank array already finalized"); }
+  const u64 w0 = pos_first >> 6, w1 = div_up(pos_last, 64);
+  u64 h0, h1; ra_held_words(ra, w0, w1, h0, h1);
+  if(h1 > h0) { LAUNCH("bits_or", k_bits_or, div_up(h1 - h0, BLOCK_THREADS), BLOCK_THREADS, ra->bits_as<u64>() + h0, (const u64*)device_in + (h0 - w0), h1 - h0); }
+  HIP_TRY(hipStreamSynchronize(CTX.stream));
+  return BWTM_OK;
+}
+
 extern "C" uint64_t bwtm_x_ra_bytes(const bwtm_ra* ra)
 {
   if(!ra) { return 0; }

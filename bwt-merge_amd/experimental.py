@@ -34,6 +34,8 @@ EXPERIMENTAL_SYMBOLS = [
     ("bwtm_x_ra_create_range", C.c_int, [vp, vp, u64, u64, C.POINTER(vp)]),
     ("bwtm_x_ra_or_range", C.c_int, [vp, vp, u64, u64]),
     ("bwtm_x_ra_bytes", u64, [vp]),
+    ("bwtm_x_ra_read_words", C.c_int, [vp, u64, u64, vp]),
+    ("bwtm_x_ra_or_words", C.c_int, [vp, u64, u64, vp]),
     ("bwtm_x_index_upload_window", C.c_int, [C.c_void_p, u64, u64, C.POINTER(u64), u64, u64, C.POINTER(u64), C.POINTER(vp)]),
     ("bwtm_fslice_set_cuts", C.c_int, [vp, C.POINTER(u64), C.c_int]),
     ("bwtm_fslice_gather_cut", C.c_int, [vp, vp, C.c_int, C.c_int]),
@@ -495,3 +497,13 @@ def _release_partitioned(pkg, ctxs, slices, ras, windows):
     pkg.make_default_current()
     for c in ctxs:
         c.destroy()
+
+
+def ra_read_words(ra, pos_first, pos_last, device_ptr):
+    _bind()
+    check(lib().bwtm_x_ra_read_words(ra.h, int(pos_first), int(pos_last), vp(device_ptr)))
+
+
+def ra_or_words(ra, pos_first, pos_last, device_ptr):
+    _bind()
+    check(lib().bwtm_x_ra_or_words(ra.h, int(pos_first), int(pos_last), vp(device_ptr)))

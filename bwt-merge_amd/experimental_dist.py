@@ -86,3 +86,44 @@ def search_partitioned_dist(pkg, wa, wb, ra, sequences, r_cuts, rank, world, dis
     fs.finish()
     fs.free()
     return steps
+
+
+def merge_partitioned_dist(pkg, a, b, cuts, rank, world, dist, torch, device):
+    """The whole partitioned merge as ONE rank of `world` processes sees it (experimental.merge_partitioned is the one-thread form over
+    contexts): its windows from its byte shares, its range of the bitvector, the search with the exchange above (elements from the roots
+    on), the earlier ranks' bits inside its first output segment (one all-gather of 8 KiB per pair), then the product's range finalize /
+    interleave / encode with the product's own small exchanges (dist.combine_range_counts, dist.exchange_encoder_carries).
+    Returns the encoded pkg.Slice of this rank's range (total_nbytes = the size of the whole merged stream) and what to free."""
+    from . import experimental as X
+    from .dist import combine_range_counts, exchange_encoder_carries
+    I, R = cuts
+    na, nb = int(a.bases), int(b.bases)
+    nrecs = ((na + nb) >> 7) + 1
+    P = [I[g] + R[g] for g in range(world + 1)]
+    M = X.MERGE_MARGIN
+    wa = X.index_upload_window(a.data, a.samples[1], na, a.sequences, max(0, I[rank] - M), min(na, I[rank + 1] + M))
+    wb = X.index_upload_window(b.data, b.samples[1], nb, b.sequences, max(0, R[rank] - M), min(nb, R[rank + 1] + M))
+    ra = X.rank_array_range(wa, wb, P[rank], P[rank + 1])
+    steps = search_partitioned_dist(pkg, wa, wb, ra, int(b.sequences), R, rank, world, dist, torch, device)
+    seg = [0] + [P[g] // 65536 for g in range(1, world)]
+    bounds = [(min(nrecs, seg[g] * 512), nrecs if g == world - 1 else min(nrecs, seg[g + 1] * 512)) for g in range(world)]
+    # boundary bits: row k of `mine` = this rank's bits inside rank k's first segment; after the all-gather rank k ORs its column
+    mine = torch.zeros((world, 1024), dtype=torch.int64, device=device)
+    for k in range(rank + 1, world):
+        if max(seg[k] * 65536, P[rank]) < min(P[k], P[rank + 1]):
+            X.ra_read_words(ra, seg[k] * 65536, seg[k] * 65536 + 65536, mine[k].data_ptr())
+    everyone = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(everyone, mine)
+    torch.cuda.synchronize(device)
+    for h in range(rank):
+        X.ra_or_words(ra, seg[rank] * 65536, seg[rank] * 65536 + 65536, everyone[h][rank].data_ptr())
+    rec_first, rec_last = bounds[rank]
+    ones, local, tail = ra.range_counts(rec_first, rec_last)
+    before, total, super_boff, halo = combine_range_counts(ones, local, tail, bounds, rank, world, dist, torch, device)
+    ra.finalize_range(rec_first, rec_last, before, total, super_boff, halo)
+    S = pkg.Slice(wa, wb, ra, rec_first, rec_last)
+    _, offset, total_bytes = exchange_encoder_carries(S.lasthead(), S.size_table, rank, world, dist, torch, device)
+    S.encode(offset)
+    S.total_nbytes = total_bytes
+    pkg.synchronize()
+    return S, (ra, wa, wb), steps

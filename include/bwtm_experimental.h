@@ -81,6 +81,10 @@ int bwtm_x_index_upload_window(const uint8_t* data, uint64_t nbytes, uint64_t fi
    boundary between two GPUs: at most one segment). */
 int bwtm_x_ra_create_range(const bwtm_index* a, const bwtm_index* b, uint64_t pos_first, uint64_t pos_last, bwtm_ra** out);
 int bwtm_x_ra_or_range(bwtm_ra* dst, const bwtm_ra* src, uint64_t pos_first, uint64_t pos_last);
+/* The same boundary exchange between processes: the words of [pos_first, pos_last) to / from a caller's device buffer (words the handle does
+   not hold read as zero and are not written). */
+int bwtm_x_ra_read_words(const bwtm_ra* ra, uint64_t pos_first, uint64_t pos_last, void* device_out);
+int bwtm_x_ra_or_words(bwtm_ra* ra, uint64_t pos_first, uint64_t pos_last, const void* device_in);
 uint64_t bwtm_x_ra_bytes(const bwtm_ra* ra);                        /* bytes of bitvector the handle holds */
 uint64_t bwtm_x_index_record_bytes(const bwtm_index* index);       /* bytes of records the handle holds (a window: its share) */
 int bwtm_fslice_set_cuts(bwtm_fslice* fs, const uint64_t* r_cuts, int parts);      /* r_cuts[0 .. parts]: R_0 = 0 <= R_1 <= ... ; R_parts is ignored (= everything) */

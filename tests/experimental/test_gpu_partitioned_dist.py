@@ -44,3 +44,27 @@ def test_one_rank_over_rccl_equals_oracle(gpu, oracle):
         ra.free(); A.free(); B.free()
     finally:
         dist.destroy_process_group()
+
+
+def test_whole_merge_of_one_rank_over_rccl_equals_oracle(gpu, oracle):
+    """merge_partitioned_dist with one rank: windows from bytes, ranged bitvector, the search's exchange, the boundary all-gather, the
+    product's range exchanges -- every collective runs (with itself); the slice is the oracle's merged stream."""
+    import torch
+    import torch.distributed as dist
+    from bwt_merge_amd.experimental_dist import merge_partitioned_dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        a = oracle.FMI.from_text(oracle.generate_reads(9961, 6000, 100)); b = oracle.FMI.from_text(oracle.generate_reads(9962, 5000, 100))
+        S, keep, steps = merge_partitioned_dist(gpu, a, b, ([0, a.bases], [0, b.bases]), 0, 1, dist, torch, dev)
+        m, _ = oracle.merge(a, b, threads=2)
+        assert steps == 101 and S.total_nbytes == m.data.size
+        assert np.array_equal(S.data(), m.data)
+        S.free()
+        for x in keep:
+            x.free()
+    finally:
+        dist.destroy_process_group()
