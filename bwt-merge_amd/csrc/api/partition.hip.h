@@ -243,6 +243,24 @@ extern "C" int bwtm_fslice_nodes_gather(bwtm_fslice* fs, const bwtm_fslice_nodes
   return BWTM_OK;
 }
 
+extern "C" int bwtm_fslice_nodes_input_buffers(bwtm_fslice* fs, void** sp, void** r, void** count, uint64_t* capacity)
+{
+  if(!fs || !sp || !r || !count || !capacity) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_input_buffers: null argument"); }
+  ENTER(fs->ctx);
+  if(!fs->node_sp[0]) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_input_buffers: call bwtm_fslice_nodes_begin first"); }
+  HIP_TRY(hipStreamSynchronize(CTX.stream));                       // this level's step has read them
+  *sp = fs->node_sp[0]; *r = fs->node_r[0]; *count = fs->node_cnt[0]; *capacity = fs->node_cap;      // plain hipMalloc blocks
+  return BWTM_OK;
+}
+
+extern "C" int bwtm_fslice_nodes_set_input(bwtm_fslice* fs, uint64_t nodes)
+{
+  if(!fs) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_set_input: null argument"); }
+  if(!fs->node_sp[0] || nodes > fs->node_cap) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_set_input: %llu nodes, capacity %llu", (unsigned long long)nodes, (unsigned long long)fs->node_cap); }
+  fs->nodes = nodes;
+  return BWTM_OK;
+}
+
 extern "C" int bwtm_fslice_nodes_expand(bwtm_fslice* fs)
 {
   if(!fs) { return fail(BWTM_EINVAL, "bwtm_fslice_nodes_expand: null argument"); }

@@ -45,6 +45,8 @@ EXPERIMENTAL_SYMBOLS = [
     ("bwtm_fslice_nodes_step", C.c_int, [vp, vp]),
     ("bwtm_fslice_nodes_gather", C.c_int, [vp, vp, C.c_int, C.c_int]),
     ("bwtm_fslice_nodes_expand", C.c_int, [vp]),
+    ("bwtm_fslice_nodes_input_buffers", C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]),
+    ("bwtm_fslice_nodes_set_input", C.c_int, [vp, u64]),
 ]
 EXPERIMENTAL_LIB_PATH = os.path.join(HERE, "libbwtm_experimental.so")
 if not os.path.exists(EXPERIMENTAL_LIB_PATH):
@@ -139,6 +141,14 @@ class FSlice:
 
     def nodes_gather(self, views, parts, part):
         check(lib().bwtm_fslice_nodes_gather(self.h, C.byref(views), parts, part))
+
+    def nodes_input_buffers(self):
+        sp, r, cnt, cap = vp(), vp(), vp(), u64(0)
+        check(lib().bwtm_fslice_nodes_input_buffers(self.h, C.byref(sp), C.byref(r), C.byref(cnt), C.byref(cap)))
+        return sp.value, r.value, cnt.value, int(cap.value)
+
+    def nodes_set_input(self, nodes):
+        check(lib().bwtm_fslice_nodes_set_input(self.h, int(nodes)))
 
     def nodes_expand(self):
         check(lib().bwtm_fslice_nodes_expand(self.h))

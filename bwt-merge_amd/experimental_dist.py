@@ -44,28 +44,61 @@ def device_tensor(torch, device, ptr, count, typestr):
     return torch.as_tensor(_DeviceArray(ptr, count, typestr), device=device)
 
 
-def search_partitioned_dist(pkg, wa, wb, ra, sequences, r_cuts, rank, world, dist, torch, device, capacity=None):
-    """The element steps of the partitioned search on this rank (GPU `device`): wa / wb = its windows, ra = its rank array, r_cuts = the B
-    ranks of the cuts (world + 1 of them).  Roots are seeded on the rank that owns them.  Returns the number of steps."""
-    import ctypes as C
-    import numpy as np
+def _gather_counts(dist, torch, device, below, world):
+    mine = torch.tensor([[int(below[c][k]) for k in range(world + 1)] for c in range(5)], dtype=torch.int64, device=device)
+    everyone = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(everyone, mine)
+    return [t.cpu().numpy() for t in everyone]
+
+
+def search_partitioned_dist(pkg, wa, wb, ra, sequences, r_cuts, rank, world, dist, torch, device, capacity=None, node_ratio=8, node_capacity=None):
+    """The partitioned search on this rank (GPU `device`): wa / wb = its windows, ra = its rank array, r_cuts = the B ranks of the cuts
+    (world + 1 of them).  The first levels run on trie nodes (while a level has at most sequences / node_ratio of them; 0: elements from the
+    roots on) when all roots lie on one rank -- cuts at k-mer boundaries: the first --, the children exchanged like the elements, with three
+    arrays.  Returns (element steps, node levels)."""
     from . import experimental as X
     cap = int(capacity) if capacity else int(sequences) + 1
     fs = X.FSlice(wa, wb, ra, cap, world)
     fs.set_cuts(r_cuts)
     first, last = min(int(r_cuts[rank]), sequences), min(int(r_cuts[rank + 1]), sequences)
-    fs.seed(first, last - first)
+    limit = sequences // node_ratio if node_ratio > 0 else 0
+    owners = torch.tensor([1 if last > first else 0], dtype=torch.int64, device=device)
+    dist.all_reduce(owners)
+    levels = 0
     view = X.FSliceView()
+    if limit >= 1 and int(owners.item()) == 1:
+        ncap = int(node_capacity) if node_capacity else min(5 * limit, sequences) + 1
+        fs.nodes_begin(first, last - first, ncap)
+        nview = X.FSliceNodesView()
+        sp_in, r_in, cnt_in, _ = fs.nodes_input_buffers()
+        recv = [device_tensor(torch, device, p, ncap, "<i8") for p in (sp_in, r_in, cnt_in)]
+        level_nodes = 1
+        while 0 < level_nodes <= limit:
+            fs.nodes_step(nview)                                     # synchronizes: the children are complete
+            below_all = _gather_counts(dist, torch, device, nview.below, world)
+            send, rcv = exchange_plan(below_all, rank, world)
+            n_in = sum(sum(x) for x in rcv)
+            if n_in > ncap:
+                raise X.BwtmError("%d nodes fall into rank %d's range, capacity %d" % (n_in, rank, ncap))
+            held = int(nview.class_first[5])
+            class_first = [int(nview.class_first[c]) for c in range(6)]
+            for src, dst in zip((nview.sp, nview.r, nview.count), recv):
+                all_to_all_classes(dist, device_tensor(torch, device, src, max(held, 1), "<i8"), class_first, send, rcv, dst)
+            torch.cuda.synchronize(device)
+            dist.barrier()
+            fs.nodes_set_input(n_in)
+            level_nodes = sum(int(b[c][world]) for b in below_all for c in range(5))
+            levels += 1
+        fs.nodes_expand()
+    else:
+        fs.seed(first, last - first)
     lo_in, hi_in, in_cap = fs.input_buffers()
     recv_lo = device_tensor(torch, device, lo_in, in_cap, "<i8")
     recv_hi = device_tensor(torch, device, hi_in, in_cap, "<i2") if hi_in else None
     steps = 0
     while True:
         fs.export(view)                                              # synchronizes the library's stream: the dense outputs are complete
-        mine = torch.tensor([[int(view.below[c][k]) for k in range(world + 1)] for c in range(5)], dtype=torch.int64, device=device)
-        everyone = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(everyone, mine)
-        below_all = [t.cpu().numpy() for t in everyone]
+        below_all = _gather_counts(dist, torch, device, view.below, world)
         if sum(int(b[c][world]) for b in below_all for c in range(5)) == 0:
             break
         send, recv = exchange_plan(below_all, rank, world)
@@ -85,13 +118,12 @@ def search_partitioned_dist(pkg, wa, wb, ra, sequences, r_cuts, rank, world, dis
         steps += 1
     fs.finish()
     fs.free()
-    return steps
+    return steps, levels
 
 
 def merge_partitioned_dist(pkg, a, b, cuts, rank, world, dist, torch, device):
     """The whole partitioned merge as ONE rank of `world` processes sees it (experimental.merge_partitioned is the one-thread form over
-    contexts): its windows from its byte shares, its range of the bitvector, the search with the exchange above (elements from the roots
-    on), the earlier ranks' bits inside its first output segment (one all-gather of 8 KiB per pair), then the product's range finalize /
+    contexts): its windows from its byte shares, its range of the bitvector, the search with the exchange above, the earlier ranks' bits inside its first output segment (one all-gather of 8 KiB per pair), then the product's range finalize /
     interleave / encode with the product's own small exchanges (dist.combine_range_counts, dist.exchange_encoder_carries).
     Returns the encoded pkg.Slice of this rank's range (total_nbytes = the size of the whole merged stream) and what to free."""
     from . import experimental as X
@@ -104,7 +136,7 @@ def merge_partitioned_dist(pkg, a, b, cuts, rank, world, dist, torch, device):
     wa = X.index_upload_window(a.data, a.samples[1], na, a.sequences, max(0, I[rank] - M), min(na, I[rank + 1] + M))
     wb = X.index_upload_window(b.data, b.samples[1], nb, b.sequences, max(0, R[rank] - M), min(nb, R[rank + 1] + M))
     ra = X.rank_array_range(wa, wb, P[rank], P[rank + 1])
-    steps = search_partitioned_dist(pkg, wa, wb, ra, int(b.sequences), R, rank, world, dist, torch, device)
+    steps, levels = search_partitioned_dist(pkg, wa, wb, ra, int(b.sequences), R, rank, world, dist, torch, device)
     seg = [0] + [P[g] // 65536 for g in range(1, world)]
     bounds = [(min(nrecs, seg[g] * 512), nrecs if g == world - 1 else min(nrecs, seg[g + 1] * 512)) for g in range(world)]
     # boundary bits: row k of `mine` = this rank's bits inside rank k's first segment; after the all-gather rank k ORs its column
@@ -126,4 +158,4 @@ def merge_partitioned_dist(pkg, a, b, cuts, rank, world, dist, torch, device):
     S.encode(offset)
     S.total_nbytes = total_bytes
     pkg.synchronize()
-    return S, (ra, wa, wb), steps
+    return S, (ra, wa, wb), (steps, levels)

@@ -111,6 +111,9 @@ typedef struct
 int bwtm_fslice_nodes_begin(bwtm_fslice* fs, uint64_t seq_first, uint64_t count, uint64_t node_capacity);   /* the root "$" of these sequences (count = 0: no node); after bwtm_fslice_set_cuts */
 int bwtm_fslice_nodes_step(bwtm_fslice* fs, bwtm_fslice_nodes_view* view);                                   /* synchronizes */
 int bwtm_fslice_nodes_gather(bwtm_fslice* fs, const bwtm_fslice_nodes_view* views, int parts, int part);    /* synchronizes */
+/* Between processes: the caller moves the children itself (three all-to-alls per class: experimental_dist.py) into the node buffers. */
+int bwtm_fslice_nodes_input_buffers(bwtm_fslice* fs, void** sp, void** r, void** count, uint64_t* capacity);
+int bwtm_fslice_nodes_set_input(bwtm_fslice* fs, uint64_t nodes);
 int bwtm_fslice_nodes_expand(bwtm_fslice* fs);                                                               /* then bwtm_fslice_export */
 
 /* Test hook of the library's device scan (every table of the path -- segment prefixes, node offsets, block and sample tables -- goes

@@ -35,13 +35,15 @@ def test_one_rank_over_rccl_equals_oracle(gpu, oracle):
         a, b = oracle.FMI.from_text(ta), oracle.FMI.from_text(tb)
         ranks, counts, _ = oracle.search(a, b, threads=2)
         A = gpu.Index.upload(a.data, a.sequences, a.bases); B = gpu.Index.upload(b.data, b.sequences, b.bases)
-        ra = gpu.RankArray(A, B)
-        steps = search_partitioned_dist(gpu, A, B, ra, b.sequences, [0, b.bases], 0, 1, dist, torch, dev)
-        assert steps == 122
-        ra.finalize()
-        got_r, got_c = ra.runs()
-        assert np.array_equal(got_r, ranks) and np.array_equal(got_c, counts)
-        ra.free(); A.free(); B.free()
+        for node_ratio in (0, 8, 1):                                        # elements from the roots on; a few node levels; the whole search on nodes
+            ra = gpu.RankArray(A, B)
+            steps, levels = search_partitioned_dist(gpu, A, B, ra, b.sequences, [0, b.bases], 0, 1, dist, torch, dev, node_ratio=node_ratio)
+            assert (steps + levels == 122 or node_ratio == 1) and (levels > 0) == (node_ratio > 0), (node_ratio, steps, levels)
+            ra.finalize()
+            got_r, got_c = ra.runs()
+            assert np.array_equal(got_r, ranks) and np.array_equal(got_c, counts), node_ratio
+            ra.free()
+        A.free(); B.free()
     finally:
         dist.destroy_process_group()
 
@@ -61,7 +63,7 @@ def test_whole_merge_of_one_rank_over_rccl_equals_oracle(gpu, oracle):
         a = oracle.FMI.from_text(oracle.generate_reads(9961, 6000, 100)); b = oracle.FMI.from_text(oracle.generate_reads(9962, 5000, 100))
         S, keep, steps = merge_partitioned_dist(gpu, a, b, ([0, a.bases], [0, b.bases]), 0, 1, dist, torch, dev)
         m, _ = oracle.merge(a, b, threads=2)
-        assert steps == 101 and S.total_nbytes == m.data.size
+        assert steps[0] + steps[1] == 101 and steps[1] > 0 and S.total_nbytes == m.data.size
         assert np.array_equal(S.data(), m.data)
         S.free()
         for x in keep:
