@@ -351,12 +351,20 @@ def window_blocks(block_starts, nbytes, pos_first, pos_last, bases):
     return b0, max(b1, b0 + 1)
 
 
-def index_upload_window(data, cum, bases, sequences, pos_first, pos_last):
+def block_starts(cum):
+    """The position every block of a native stream begins at, from its cumulative sample arrays (blocks + 1 entries; the last = bases)."""
+    import numpy as np
+    return cum.sum(axis=0).astype(np.uint64)
+
+
+def index_upload_window(data, cum, bases, sequences, pos_first, pos_last, starts=None):
     """A window of an index transcoded from its own share of the native bytes: data = the whole native stream in host memory (only the
-    share is copied to the device), cum[6][blocks + 1] = its cumulative sample arrays (counts of every symbol before every block)."""
+    share is copied to the device), cum[6][blocks + 1] = its cumulative sample arrays (counts of every symbol before every block);
+    starts = block_starts(cum) when the caller has it already (a pass over 48 bytes per block otherwise)."""
     import numpy as np
     _bind()
-    starts = cum.sum(axis=0).astype(np.uint64)
+    if starts is None:
+        starts = block_starts(cum)
     b0, b1 = window_blocks(starts, data.size, pos_first, pos_last, bases)
     share = np.ascontiguousarray(data[b0 * 64: min(b1 * 64, data.size)])
     before = (u64 * 6)(*[int(cum[c][b0]) for c in range(6)])
@@ -431,8 +439,8 @@ def merge_partitioned(pkg, a, b, parts, cuts, from_bytes=True, node_ratio=8, cap
         a_lo, a_hi = max(0, I[g] - MERGE_MARGIN), min(na, I[g + 1] + MERGE_MARGIN)
         b_lo, b_hi = max(0, R[g] - MERGE_MARGIN), min(nb, R[g + 1] + MERGE_MARGIN)
         if from_bytes:
-            wa = index_upload_window(a.data, a.samples[1], na, a.sequences, a_lo, a_hi)
-            wb = index_upload_window(b.data, b.samples[1], nb, b.sequences, b_lo, b_hi)
+            wa = index_upload_window(a.data, a.samples[1], na, a.sequences, a_lo, a_hi, starts=_starts_of(a))
+            wb = index_upload_window(b.data, b.samples[1], nb, b.sequences, b_lo, b_hi, starts=_starts_of(b))
         else:
             A = pkg.Index.upload(a.data, a.sequences, na); B = pkg.Index.upload(b.data, b.sequences, nb)
             wa, wb = index_window(A, a_lo, a_hi), index_window(B, b_lo, b_hi)
@@ -498,6 +506,18 @@ def merge_partitioned(pkg, a, b, parts, cuts, from_bytes=True, node_ratio=8, cap
                phases=phases, slices=slices)
     out["release"] = lambda: _release_partitioned(pkg, ctxs, slices, ras, windows)
     return out
+
+
+def _starts_of(x):
+    """block_starts of a host input, computed once per object."""
+    st = getattr(x, "_block_starts", None)
+    if st is None:
+        st = block_starts(x.samples[1])
+        try:
+            x._block_starts = st
+        except AttributeError:
+            pass
+    return st
 
 
 def _release_partitioned(pkg, ctxs, slices, ras, windows):

@@ -21,14 +21,16 @@ def exchange_plan(below_all, rank, world):
     return send, recv
 
 
-def all_to_all_classes(dist, send_buf, class_first, send, recv, recv_buf):
+def all_to_all_classes(dist, send_buf, class_first, send, recv, recv_buf, units=1):
     """Five all_to_all_single calls, one per class: class c's elements leave from send_buf[class_first[c] ...] (ordered by destination) and
-    arrive behind the classes before it, source after source.  Returns the number of elements received."""
+    arrive behind the classes before it, source after source.  units = tensor items per element (the 2-byte high parts travel as byte
+    pairs: RCCL has no 16-bit integer type).  Returns the number of elements received."""
     off = 0
     for c in range(5):
         n_send, n_recv = sum(send[c]), sum(recv[c])
-        dist.all_to_all_single(recv_buf[off: off + n_recv], send_buf[int(class_first[c]): int(class_first[c]) + n_send],
-                               output_split_sizes=recv[c], input_split_sizes=send[c])
+        first = int(class_first[c])
+        dist.all_to_all_single(recv_buf[units * off: units * (off + n_recv)], send_buf[units * first: units * (first + n_send)],
+                               output_split_sizes=[units * x for x in recv[c]], input_split_sizes=[units * x for x in send[c]])
         off += n_recv
     return off
 
@@ -94,7 +96,7 @@ def search_partitioned_dist(pkg, wa, wb, ra, sequences, r_cuts, rank, world, dis
         fs.seed(first, last - first)
     lo_in, hi_in, in_cap = fs.input_buffers()
     recv_lo = device_tensor(torch, device, lo_in, in_cap, "<i8")
-    recv_hi = device_tensor(torch, device, hi_in, in_cap, "<i2") if hi_in else None
+    recv_hi = device_tensor(torch, device, hi_in, 2 * in_cap, "|u1") if hi_in else None
     steps = 0
     while True:
         fs.export(view)                                              # synchronizes the library's stream: the dense outputs are complete
@@ -110,7 +112,7 @@ def search_partitioned_dist(pkg, wa, wb, ra, sequences, r_cuts, rank, world, dis
         send_lo = device_tensor(torch, device, view.dense_lo, max(held, 1), "<i8")
         all_to_all_classes(dist, send_lo, class_first, send, recv, recv_lo)
         if recv_hi is not None:
-            all_to_all_classes(dist, device_tensor(torch, device, view.dense_hi, max(held, 1), "<i2"), class_first, send, recv, recv_hi)
+            all_to_all_classes(dist, device_tensor(torch, device, view.dense_hi, 2 * max(held, 1), "|u1"), class_first, send, recv, recv_hi, units=2)
         torch.cuda.synchronize(device)                               # the collectives ran on torch's stream
         dist.barrier()                                               # every rank has received: the send buffers may be overwritten
         fs.set_input(n_in)
@@ -121,22 +123,29 @@ def search_partitioned_dist(pkg, wa, wb, ra, sequences, r_cuts, rank, world, dis
     return steps, levels
 
 
-def merge_partitioned_dist(pkg, a, b, cuts, rank, world, dist, torch, device):
+def merge_partitioned_dist(pkg, a, b, cuts, rank, world, dist, torch, device, times=None):
     """The whole partitioned merge as ONE rank of `world` processes sees it (experimental.merge_partitioned is the one-thread form over
     contexts): its windows from its byte shares, its range of the bitvector, the search with the exchange above, the earlier ranks' bits inside its first output segment (one all-gather of 8 KiB per pair), then the product's range finalize /
     interleave / encode with the product's own small exchanges (dist.combine_range_counts, dist.exchange_encoder_carries).
-    Returns the encoded pkg.Slice of this rank's range (total_nbytes = the size of the whole merged stream) and what to free."""
+    Returns the encoded pkg.Slice of this rank's range (total_nbytes = the size of the whole merged stream), what to free, and (element
+    steps, node levels).  times (a dict, optional) receives this rank's wall milliseconds by phase."""
+    import time as _time
     from . import experimental as X
+    t0 = _time.perf_counter()
     from .dist import combine_range_counts, exchange_encoder_carries
     I, R = cuts
     na, nb = int(a.bases), int(b.bases)
     nrecs = ((na + nb) >> 7) + 1
     P = [I[g] + R[g] for g in range(world + 1)]
     M = X.MERGE_MARGIN
-    wa = X.index_upload_window(a.data, a.samples[1], na, a.sequences, max(0, I[rank] - M), min(na, I[rank + 1] + M))
-    wb = X.index_upload_window(b.data, b.samples[1], nb, b.sequences, max(0, R[rank] - M), min(nb, R[rank + 1] + M))
+    wa = X.index_upload_window(a.data, a.samples[1], na, a.sequences, max(0, I[rank] - M), min(na, I[rank + 1] + M), starts=X._starts_of(a))
+    wb = X.index_upload_window(b.data, b.samples[1], nb, b.sequences, max(0, R[rank] - M), min(nb, R[rank + 1] + M), starts=X._starts_of(b))
     ra = X.rank_array_range(wa, wb, P[rank], P[rank + 1])
+    pkg.synchronize()
+    t1 = _time.perf_counter()
     steps, levels = search_partitioned_dist(pkg, wa, wb, ra, int(b.sequences), R, rank, world, dist, torch, device)
+    pkg.synchronize()
+    t2 = _time.perf_counter()
     seg = [0] + [P[g] // 65536 for g in range(1, world)]
     bounds = [(min(nrecs, seg[g] * 512), nrecs if g == world - 1 else min(nrecs, seg[g + 1] * 512)) for g in range(world)]
     # boundary bits: row k of `mine` = this rank's bits inside rank k's first segment; after the all-gather rank k ORs its column
@@ -158,4 +167,9 @@ def merge_partitioned_dist(pkg, a, b, cuts, rank, world, dist, torch, device):
     S.encode(offset)
     S.total_nbytes = total_bytes
     pkg.synchronize()
+    if times is not None:
+        t3 = _time.perf_counter()
+        for k, v in (("ms_windows_from_host_bytes", t1 - t0), ("ms_search", t2 - t1), ("ms_finalize_interleave_encode", t3 - t2)):
+            times[k] = times.get(k, 0.0) + v * 1e3
+        times["merges"] = times.get("merges", 0) + 1
     return S, (ra, wa, wb), (steps, levels)
