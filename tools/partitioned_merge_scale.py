@@ -65,6 +65,7 @@ def main():
     ref = np.empty(M.nbytes, dtype=np.uint8)
     M.download_into(ref)
     M.free()
+    pkg.trim()                                                       # the default context's pool gives its blocks back: the parts' contexts need the memory
     transcode = sum(prof.get(n, (0, 0))[0] for n in ("block_len", "build_recs", "build_sup"))
     tail = sum(v[0] for n, v in prof.items() if n in ("interleave", "interleave_base", "interleave_sup", "enc_emit", "enc_size", "enc_lasthead", "fold_top", "fold_group", "fold_seg",
                                                       "chunk_popc", "block_cum"))
