@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--emit-budget", type=int, default=2 << 30)
     ap.add_argument("--slack", type=float, default=1.25)
+    ap.add_argument("--workload", choices=("iid", "genome"), default="iid", help="genome: reads of a shared random genome (bench.py's secondary workload): a compressible BWT of long runs")
+    ap.add_argument("--coverage", type=int, default=30)
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -39,7 +41,8 @@ def main():
     t0 = time.time()
     hosts = []
     for seed in (1001, 1002):
-        ix = synth.build_index(pkg, seed, args.reads, args.readlen, device=dev)
+        wargs = ({"coverage": args.coverage, "error_percent": 1} if args.workload == "genome" else {})
+        ix = synth.build_index(pkg, seed, args.reads, args.readlen, device=dev, workload=args.workload, **wargs)
         ix.encode()
         data = np.empty(ix.nbytes, dtype=np.uint8)
         ix.download_into(data)
