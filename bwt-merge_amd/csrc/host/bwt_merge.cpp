@@ -32,6 +32,8 @@ static void printUsage()
 #ifdef BWTM_EXPERIMENTAL
   std::cerr << "  -S            With several GPUs: sliced search (every GPU advances a contiguous slice of the sorted frontier" << std::endl;
   std::cerr << "                instead of a block of sequences; experimental build only)" << std::endl;
+  std::cerr << "  -P            With several GPUs: partitioned records (every GPU holds one window of each input and of the" << std::endl;
+  std::cerr << "                bitvector, transcoded from its share of the bytes; elements travel; experimental build only)" << std::endl;
 #endif
   std::cerr << std::endl;
   printFormats(std::cerr);
@@ -77,6 +79,7 @@ static void verifyFMI(const FMI& fmi, const std::string& name, const std::vector
   std::cout << std::endl;
 }
 
+static bool partitioned_merge = false; // -P: with several GPUs, partitioned records (nothing replicated; multi_gpu.h)
 static bool sliced_search = false;      // -S: with several GPUs, every GPU advances a slice of the sorted frontier (multi_gpu.h)
 
 static void merge(FMI& index, FMI& increment, const MergeParameters& parameters, const std::vector<int>& devices)
@@ -86,11 +89,11 @@ static void merge(FMI& index, FMI& increment, const MergeParameters& parameters,
   if(devices.size() > 1)
   {
     FMI temp; MultiGPUTimes times;
-    mergeMultiGPU(index, increment, devices, temp, &times, sliced_search);      // one host thread per GPU, result assembled on the host
+    mergeMultiGPU(index, increment, devices, temp, &times, sliced_search, partitioned_merge);      // one host thread per GPU, result assembled on the host
     index.swap(temp);
 #ifdef VERBOSE_STATUS_INFO
     // the phases of the sharded merge as GPU 0's thread saw them (stderr, like the reference's status lines): what a SCALE session reads
-    std::cerr << "mergeMultiGPU(): " << devices.size() << " GPUs" << (sliced_search ? " (sliced search)" : "") << ": upload " << times.upload << " s, search " << times.search
+    std::cerr << "mergeMultiGPU(): " << devices.size() << " GPUs" << (partitioned_merge ? " (partitioned records)" : (sliced_search ? " (sliced search)" : "")) << ": upload " << times.upload << " s, search " << times.search
               << " s, exchange " << times.exchange << " s, interleave + encode " << times.interleave_encode << " s, download " << times.download
               << " s, total " << times.total << " s; exchanged " << times.exchange_bytes << " bytes per GPU; host bytes to GPU 0 " << times.host_bytes_gpu0 << std::endl;
 #endif
@@ -119,7 +122,7 @@ int main(int argc, char** argv)
   std::vector<std::string> input_formats;
   while((c = getopt(argc, argv,
 #ifdef BWTM_EXPERIMENTAL
-    "b:m:r:s:t:d:v:i:o:g:S"
+    "b:m:r:s:t:d:v:i:o:g:SP"
 #else
     "b:m:r:s:t:d:v:i:o:g:"
 #endif
@@ -141,6 +144,7 @@ int main(int argc, char** argv)
       break;
 #ifdef BWTM_EXPERIMENTAL
     case 'S': sliced_search = true; break;
+    case 'P': partitioned_merge = true; break;
 #endif
     case 'v': pattern_name = optarg; verify = true; break;
     case 'i':

@@ -44,6 +44,7 @@ int main(int argc, char** argv)
   load(a, argv[1], "plain_default"); load(b, argv[2], "plain_default");
   FMI a2 = a, b2 = b, a3 = a, b3 = b, b4 = b, b5 = b;
   FMI a6 = a, b6 = b, a7 = a, b7 = b, a8 = a, b8 = b, a9 = a, b9 = b, a10 = a, b10 = b;
+  FMI a11 = a, b11 = b, a12 = a, b12 = b, a13 = a, b13 = b;                 // (the partitioned merges of the experimental build)
   std::vector<byte_type> sa = symbolsOf(a), sb = symbolsOf(b);
   size_type na = a.size(), nb = b.size();
 
@@ -170,6 +171,22 @@ int main(int argc, char** argv)
     CHECK(sliced.bwt.data.bytes == expected);
     CHECK(sliced.bwt.blockEnds() == merged.bwt.blockEnds());
     for(size_type c = 0; c < 6; c++) { CHECK(sliced.bwt.cumulative(c) == merged.bwt.cumulative(c)); }
+  }
+  // Partitioned records: contexts standing in for 1, 3 and 5 GPUs, each with windows transcoded from its share of the bytes.
+  {
+    FMI* pa[3] = { &a11, &a12, &a13 }; FMI* pb[3] = { &b11, &b12, &b13 };
+    const size_type counts[3] = { 1, 3, 5 };
+    for(size_type k = 0; k < 3; k++)
+    {
+      const size_type input_bytes = pa[k]->bwt.bytes() + pb[k]->bwt.bytes();
+      FMI part; MultiGPUTimes times;
+      mergeMultiGPU(*pa[k], *pb[k], std::vector<int>(counts[k], 0), part, &times, false, true);
+      CHECK(part.bwt.data.bytes == expected);
+      CHECK(part.bwt.blockEnds() == merged.bwt.blockEnds());
+      for(size_type c = 0; c < 6; c++) { CHECK(part.bwt.cumulative(c) == merged.bwt.cumulative(c)); }
+      CHECK(part.alpha.C == merged.alpha.C && part.size() == merged.size() && part.sequences() == merged.sequences());
+      CHECK(times.host_bytes_gpu0 <= input_bytes && times.total > 0);     // a part uploads the blocks of its windows, never more than the inputs
+    }
   }
 #endif
 

@@ -165,7 +165,11 @@ struct MultiGPUTimes
 // libbwtm_experimental.so): the sliced frontier search (bwtm_fslice_*, include/bwtm_experimental.h): GPU g advances slice g of the sorted
 // frontier and pulls its next slice from all GPUs' outputs -- every GPU then streams 1 / G of both rank structures per LF step
 // instead of a thinned 100 % (contexts of one GPU, or devices with peer access).
-inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& result, MultiGPUTimes* times = nullptr, bool sliced = false)
+// partitioned = true (same builds only): nothing is replicated -- every GPU transcodes one window of each input from its own
+// share of the native bytes (the blocks the inputs' samples name for a position range), holds its own range of the bitvector, and the frontier's
+// nodes and elements travel to the GPU that owns their position (cuts at k-mer boundaries, found with the host's rank queries); the ranges of
+// the output follow the cuts, so there is no bulk exchange afterwards, only the earlier parts' bits inside a part's first segment (8 KiB).
+inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& result, MultiGPUTimes* times = nullptr, bool sliced = false, bool partitioned = false)
 {
   if(a.alpha != b.alpha)
   {
@@ -198,10 +202,13 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
 #endif
 
 #ifndef BWTM_EXPERIMENTAL
-  if(sliced) { std::cerr << "mergeMultiGPU(): the sliced search is not part of this build" << std::endl; std::exit(EXIT_FAILURE); }
+  if(sliced || partitioned) { std::cerr << "mergeMultiGPU(): the sliced / partitioned search is not part of this build" << std::endl; std::exit(EXIT_FAILURE); }
+#endif
+#if defined(BWTM_EXPERIMENTAL) && !defined(BWTM_WITH_RCCL)
+  if(partitioned) { std::cerr << "mergeMultiGPU(): the partitioned merge needs the HIP runtime headers (built without RCCL)" << std::endl; std::exit(EXIT_FAILURE); }
 #endif
 #if defined(BWTM_WITH_RCCL) && defined(BWTM_EXPERIMENTAL)
-  if(distinct && G > 1 && sliced)
+  if(distinct && G > 1 && (sliced || partitioned))
   {
     // the sliced search reads its peers' frontier buffers directly (plain hipMalloc memory, bwtm_fslice_export): peers must be mapped
     for(size_type i = 0; i < G; i++)
@@ -232,6 +239,56 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
   std::vector<uint64_t> range_first(G, 0), range_last(G, 0), range_ones(G, 0), super_local(G * nsup, 0), tails(G * 128, 0);
 #ifdef BWTM_EXPERIMENTAL
   std::vector<bwtm_fslice_view> views(G);
+  std::vector<bwtm_fslice_nodes_view> nviews(G);
+  std::vector<bwtm_ra*> part_ra(G, nullptr);
+  std::vector<void*> boundary_stage(G, nullptr);
+  // Partitioned records: the cuts (I_g, R_g) = (suffixes of a below w_g, suffixes of b below w_g) for G - 1 of the 5^k k-mers, chosen so that the parts'
+  // shares of the output are as equal as the candidates allow; sp(c w) = C[c] + rank_c(sp(w)) on the host's indexes (support.h / bwt.h queries).
+  std::vector<uint64_t> cut_a(G + 1, 0), cut_b(G + 1, 0);
+  if(partitioned)
+  {
+    cut_a[G] = a.size(); cut_b[G] = b.size();
+    auto points = [&](const FMI& x, unsigned k) -> std::vector<uint64_t>
+    {
+      std::vector<uint64_t> sp(1, 0);
+      for(unsigned round = 0; round < k; round++)
+      {
+        std::vector<uint64_t> next; next.reserve(5 * sp.size());
+        for(comp_type c = 1; c <= 5; c++) { for(uint64_t p : sp) { next.push_back(x.alpha.C[c] + x.bwt.rank(p, c)); } }
+        sp.swap(next);
+      }
+      return sp;
+    };
+    if(G > 1)
+    {
+      const unsigned k = 5;
+      const std::vector<uint64_t> pa = points(a, k), pb = points(b, k);
+      const double total = (double)a.size() + (double)b.size();
+      for(size_type g = 1; g < G; g++)
+      {
+        size_type best = 0; double dist = -1;
+        for(size_type j = 0; j < pa.size(); j++)
+        {
+          const double d = std::abs((double)pa[j] + (double)pb[j] - total * g / G);
+          if(dist < 0 || d < dist) { dist = d; best = j; }
+        }
+        cut_a[g] = std::max(cut_a[g - 1], pa[best]); cut_b[g] = std::max(cut_b[g - 1], pb[best]);
+      }
+    }
+  }
+  // the blocks [b0, b1) of a native stream whose records cover the positions [lo, hi]: block starts from the samples (bwt.cpp:489-511)
+  auto blockStartOf = [](const BWT& x, size_type k) { uint64_t p = 0; for(size_type c = 0; c < BWT::SIGMA; c++) { p += x.cum(c, k); } return p; };
+  auto blocksFor = [&](const BWT& x, uint64_t lo, uint64_t hi, size_type& b0, size_type& b1)
+  {
+    const size_type nb = x.blocks();
+    const uint64_t first = lo & ~(uint64_t)127, end = std::min<uint64_t>(x.size(), (hi | 127) + 1);
+    size_type l = 0, r = nb;                                   // last block that begins at or before `first`
+    while(r - l > 1) { const size_type mid = (l + r) / 2; if(blockStartOf(x, mid) <= first) { l = mid; } else { r = mid; } }
+    b0 = l;
+    l = b0; r = nb;                                             // first block that begins at or after `end` (nb: none)
+    while(l < r) { const size_type mid = (l + r) / 2; if(blockStartOf(x, mid) >= end) { r = mid; } else { l = mid + 1; } }
+    b1 = std::max<size_type>(l, b0 + 1);
+  };
 #endif
   BWT& out = result.bwt;
   double t0 = readTimer();
@@ -318,6 +375,27 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
     gpuCheck(bwtm_context_create(devices[g], &ctx), "mergeMultiGPU()");
     gpuCheck(bwtm_context_make_current(ctx), "mergeMultiGPU()");
     bwtm_index *A = nullptr, *B = nullptr; bwtm_ra* ra = nullptr; bwtm_slice* slice = nullptr;
+#ifdef BWTM_EXPERIMENTAL
+    const uint64_t PART_MARGIN = 2 * 65536;                        // positions a part reads beyond its cuts in the merge's second half: a segment + the halo chunk
+    if(partitioned)
+    {
+      auto window = [&](const BWT& x, const BlockArray& data, uint64_t lo, uint64_t hi, const uint64_t* C, bwtm_index** w)
+      {
+        size_type b0 = 0, b1 = 0;
+        blocksFor(x, lo, hi, b0, b1);
+        uint64_t before[6];
+        for(size_type c = 0; c < 6; c++) { before[c] = x.cum(c, b0); }
+        const uint64_t from = (uint64_t)b0 * Run::BLOCK_SIZE, to = std::min<uint64_t>((uint64_t)b1 * Run::BLOCK_SIZE, data.size());
+        gpuCheck(bwtm_x_index_upload_window(data.data() + from, to - from, blockStartOf(x, b0), before, x.size(), x.sequences(), C, w), "mergeMultiGPU()");
+#ifdef BWTM_WITH_RCCL
+        host_bytes_per_gpu[g] += to - from;
+#endif
+      };
+      window(a.bwt, adata, (cut_a[g] > PART_MARGIN ? cut_a[g] - PART_MARGIN : 0), std::min<uint64_t>(a.size(), cut_a[g + 1] + PART_MARGIN), ca.data(), &A);
+      window(b.bwt, bdata, (cut_b[g] > PART_MARGIN ? cut_b[g] - PART_MARGIN : 0), std::min<uint64_t>(b.size(), cut_b[g + 1] + PART_MARGIN), cb.data(), &B);
+    }
+    else
+#endif
 #ifdef BWTM_WITH_RCCL
     if(G > 1)
     {
@@ -340,10 +418,30 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
     // Equal output ranges (the collective wants equal shares): range g = records [rec_first, rec_last), shard_bytes of bitvector each.
     uint64_t rec_first = 0, rec_last = 0, shard_bytes = 0;
     gpuCheck(bwtm_slice_bounds_equal(bwtm_merged_records(A, B), (int)G, (int)g, &rec_first, &rec_last, &shard_bytes), "mergeMultiGPU()");
+#ifdef BWTM_EXPERIMENTAL
+    // partitioned: the ranges follow the cuts, rounded down to the encoder's 65 536-position segments (512 records)
+    auto partPosition = [&](size_type h) { return cut_a[h] + cut_b[h]; };
+    auto partSegment = [&](size_type h) { return (h == 0 ? (uint64_t)0 : partPosition(h) >> 16); };
+    if(partitioned)
+    {
+      const uint64_t nrecs = bwtm_merged_records(A, B);
+      rec_first = std::min<uint64_t>(nrecs, partSegment(g) * 512);
+      rec_last = (g + 1 == G ? nrecs : std::min<uint64_t>(nrecs, partSegment(g + 1) * 512));
+      shard_bytes = 0;
+    }
+#endif
     range_first[g] = rec_first; range_last[g] = rec_last;
     // Across devices the bitvector is handed to ncclReduceScatter, which (all ranks in one process) may let a peer GPU read or write the
     // buffer directly: the library's pooled blocks are mapped for their own device only, so this buffer is a cached hipMalloc block.
     void* shared_bits = nullptr;
+#ifdef BWTM_EXPERIMENTAL
+    if(partitioned)
+    {
+      gpuCheck(bwtm_x_ra_create_range(A, B, partPosition(g), partPosition(g + 1), &ra), "mergeMultiGPU()");
+      part_ra[g] = ra;
+    }
+    else
+#endif
     if(distinct && G > 1)
     {
 #ifdef BWTM_WITH_RCCL
@@ -358,7 +456,52 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
     }
     else { gpuCheck(bwtm_ra_create(A, B, &ra), "mergeMultiGPU()"); }
 #ifdef BWTM_EXPERIMENTAL
-    if(sliced && b.sequences() > 0)
+    if(partitioned && b.sequences() > 0)
+    {
+      const uint64_t m = b.sequences(), limit = m / 8;
+      const bool roots_on_one = (G == 1 || cut_b[1] >= m);        // k-mer cuts: all roots lie below the first cut
+      const bool nodes = (limit >= 1 && roots_on_one);
+      // with the node phase a part holds ~m / G elements; small inputs (and a search from the roots on) may put everything on one part
+      const uint64_t capacity = (nodes && m >= (1u << 20) ? (uint64_t)(1.5 * m / G) + 65536 : m + 1);
+      const uint64_t node_capacity = (m >= (1u << 20) ? (uint64_t)(1.5 * std::min<uint64_t>(5 * limit, m) / G) + 65536 : std::min<uint64_t>(5 * std::max<uint64_t>(limit, 1), m) + 1);
+      bwtm_fslice* fs = nullptr;
+      gpuCheck(bwtm_fslice_create(A, B, ra, capacity, (int)G, &fs), "mergeMultiGPU()");
+      gpuCheck(bwtm_fslice_set_cuts(fs, cut_b.data(), (int)G), "mergeMultiGPU()");
+      const uint64_t root_first = std::min<uint64_t>(cut_b[g], m), root_last = std::min<uint64_t>(cut_b[g + 1], m);
+      if(nodes)
+      {
+        gpuCheck(bwtm_fslice_nodes_begin(fs, root_first, root_last - root_first, node_capacity), "mergeMultiGPU()");
+        uint64_t level = 1;
+        while(level > 0 && level <= limit)
+        {
+          gpuCheck(bwtm_fslice_nodes_step(fs, &nviews[g]), "mergeMultiGPU()");
+          barrier.wait();                                          // every GPU's children and their counts are visible
+          gpuCheck(bwtm_fslice_nodes_gather(fs, nviews.data(), (int)G, (int)g), "mergeMultiGPU()");
+          level = 0;
+          for(size_type h = 0; h < G; h++) { level += nviews[h].class_first[5]; }
+          barrier.wait();                                          // every GPU has taken its nodes: the children may be overwritten
+        }
+        gpuCheck(bwtm_fslice_nodes_expand(fs), "mergeMultiGPU()");
+      }
+      else { gpuCheck(bwtm_fslice_seed(fs, root_first, root_last - root_first), "mergeMultiGPU()"); }
+      gpuCheck(bwtm_fslice_export(fs, &views[g]), "mergeMultiGPU()");
+      barrier.wait();
+      while(true)
+      {
+        uint64_t total = 0;
+        for(size_type h = 0; h < G; h++) { for(int c = 0; c < 5; c++) { total += views[h].totals[c]; } }
+        if(total == 0) { break; }
+        gpuCheck(bwtm_fslice_gather_cut(fs, views.data(), (int)G, (int)g), "mergeMultiGPU()");
+        barrier.wait();                                            // every GPU has pulled its elements: the send buffers may be overwritten
+        gpuCheck(bwtm_fslice_advance(fs), "mergeMultiGPU()");
+        gpuCheck(bwtm_fslice_export(fs, &views[g]), "mergeMultiGPU()");
+        barrier.wait();
+      }
+      gpuCheck(bwtm_fslice_finish(fs), "mergeMultiGPU()");
+      bwtm_fslice_free(fs);
+    }
+    else if(partitioned) { }
+    else if(sliced && b.sequences() > 0)
     {
       const uint64_t capacity = (b.sequences() + G - 1) / G + 1;
       bwtm_fslice* fs = nullptr;
@@ -384,12 +527,42 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
     else
 #endif
     if(g < blocks.size()) { gpuCheck(bwtm_search(A, B, blocks[g].first, blocks[g].second, ra), "mergeMultiGPU()"); }
-    gpuCheck(bwtm_ra_device_buffer(ra, &bits[g], &bits_bytes[g]), "mergeMultiGPU()");      // synchronizes: the search is done
+    if(partitioned) { gpuCheck(bwtm_synchronize(), "mergeMultiGPU()"); }
+    else { gpuCheck(bwtm_ra_device_buffer(ra, &bits[g], &bits_bytes[g]), "mergeMultiGPU()"); }      // synchronizes: the search is done
     if(g == 0) { local.search = readTimer() - t0 - local.upload; }
 
     // The one bulk exchange: every GPU receives the union of all shards inside ITS output range.
     barrier.wait();
     double t_x = readTimer();
+#if defined(BWTM_EXPERIMENTAL) && defined(BWTM_WITH_RCCL)
+    if(partitioned && G > 1)
+    {
+      // What crosses a boundary: the bits of the parts before it inside a part's first segment.  Every part writes its share of every later
+      // part's first segment into a plain hipMalloc block (8 KiB per pair: peers can read it), the owner ORs them in.
+      const uint64_t seg_bytes = 65536 / 8;
+      auto hipOk = [&](hipError_t e, const char* what) { if(e != hipSuccess) { std::cerr << "mergeMultiGPU(): " << what << ": " << hipGetErrorString(e) << std::endl; std::exit(EXIT_FAILURE); } };
+      hipOk(hipSetDevice(devices[g]), "hipSetDevice");
+      hipOk(hipMalloc(&boundary_stage[g], G * seg_bytes), "hipMalloc of the boundary block");
+      auto touches = [&](size_type h, size_type k)                 // part h has bits inside part k's first segment (h < k)
+      {
+        const uint64_t lo = std::max<uint64_t>(partSegment(k) << 16, partPosition(h)), hi = std::min<uint64_t>(partPosition(k), partPosition(h + 1));
+        return lo < hi;
+      };
+      for(size_type k = g + 1; k < G; k++)
+      {
+        if(touches(g, k)) { gpuCheck(bwtm_x_ra_read_words(ra, partSegment(k) << 16, (partSegment(k) << 16) + 65536, (char*)boundary_stage[g] + k * seg_bytes), "mergeMultiGPU()"); }
+      }
+      barrier.wait();
+      for(size_type h = 0; h < g; h++)
+      {
+        if(touches(h, g)) { gpuCheck(bwtm_x_ra_or_words(ra, partSegment(g) << 16, (partSegment(g) << 16) + 65536, (const char*)boundary_stage[h] + g * seg_bytes), "mergeMultiGPU()"); }
+      }
+      barrier.wait();
+      hipOk(hipFree(boundary_stage[g]), "hipFree"); boundary_stage[g] = nullptr;
+      if(g == 0) { local.exchange_bytes = seg_bytes; }
+    }
+    else
+#endif
     if(G > 1)
     {
       if(distinct)
@@ -428,7 +601,7 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
     // The small exchange: set bits of every range, local offsets of the supers that start in it, its last chunk of bits.
     gpuCheck(bwtm_ra_range_counts(ra, rec_first, rec_last, &range_ones[g], super_local.data() + g * nsup, tails.data() + g * 128), "mergeMultiGPU()");
     barrier.wait();
-    if(g == 0) { local.exchange = readTimer() - t_x; local.exchange_bytes = (G > 1 ? (G - 1) * shard_bytes : 0); }
+    if(g == 0) { local.exchange = readTimer() - t_x; if(!partitioned) { local.exchange_bytes = (G > 1 ? (G - 1) * shard_bytes : 0); } }
 
     // This thread's range of the output.
     double t_i = readTimer();

@@ -1,4 +1,4 @@
-"""The C++ host built against libbwtm_experimental.so: `bwt_merge -S` and the sliced section of host_api_test."""
+"""The C++ host built against libbwtm_experimental.so: `bwt_merge -S` / `-P` and the sliced and partitioned sections of host_api_test."""
 import os
 import subprocess
 
@@ -50,3 +50,24 @@ def test_cli_sliced_search_equals_the_product_tool(bwtm, oracle, tmp_path):
     assert np.array_equal(outs["one"], outs["sliced"])
     direct = oracle.FMI.from_text(np.concatenate(sets))
     assert np.array_equal(outs["sliced"][32:32 + direct.nbytes], direct.data)
+
+
+def test_cli_partitioned_merge_equals_the_product_tool(bwtm, oracle, tmp_path):
+    """bwt_merge_experimental -g 0,0,0,0 -P (four contexts, each with windows transcoded from its share of the bytes, nodes and elements
+    routed by position, a range of the bitvector each) == bwt_merge -g 0, on a chained merge of three inputs large enough for several
+    encoder segments per part; its status line names the mode."""
+    build_host(bwtm)
+    sets = [oracle.generate_reads(4200 + k, 12000 + 1500 * k, 100) for k in range(3)]
+    names = []
+    for k, t in enumerate(sets):
+        names.append(str(tmp_path / ("in%d.plain" % k)))
+        write_plain(names[-1], oracle.FMI.from_text(t))
+    outs = {}
+    for label, exe, extra in (("one", "bwt_merge", ["-g", "0"]), ("partitioned", "bwt_merge_experimental", ["-g", "0,0,0,0", "-P"])):
+        out = subprocess.run([os.path.join(HOST, exe)] + extra + ["-i", "plain_default", names[0], names[1], names[2], str(tmp_path / (label + ".native"))],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        if label == "partitioned":
+            assert "(partitioned records)" in out.stderr
+        outs[label] = np.fromfile(tmp_path / (label + ".native"), dtype=np.uint8)
+    assert np.array_equal(outs["one"], outs["partitioned"])
