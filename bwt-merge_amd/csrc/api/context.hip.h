@@ -235,16 +235,20 @@ void profile_collect()
   CTX.pending.clear();
 }
 
-#define LAUNCH_CFG(name, kernel, grid, block, lds, ...) do { \
+// A HIP grid holds fewer than 2^32 threads in x, and a launch beyond that does not fail: it covers a part of the work (round 5: bwtm_extract of
+// 5 * 10^9 positions returned zeros behind the first 2^32).  The grid is checked as a 64-bit number before it is narrowed, and refused loudly.
+#define LAUNCH_CFG(name, kernel, gridx, gridy, block, lds, ...) do { \
+  const unsigned long long gx_ = (unsigned long long)(gridx); \
+  if(gx_ * (unsigned long long)(block) >= (1ull << 32)) { return fail(BWTM_EINVAL, "launch of %s: %llu workgroups of %u threads do not fit one grid", name, gx_, (unsigned)(block)); } \
   profile_begin(name); \
-  hipLaunchKernelGGL(kernel, grid, dim3((unsigned)(block)), (unsigned)(lds), CTX.stream, __VA_ARGS__); \
+  hipLaunchKernelGGL(kernel, dim3((unsigned)gx_, (unsigned)(gridy)), dim3((unsigned)(block)), (unsigned)(lds), CTX.stream, __VA_ARGS__); \
   profile_end(); \
   hipError_t le_ = hipGetLastError(); \
   if(le_ != hipSuccess) { return fail(BWTM_ENODEV, "launch of %s failed: %s", name, hipGetErrorString(le_)); } } while(0)
 
-#define LAUNCH(name, kernel, grid, block, ...) LAUNCH_CFG(name, kernel, dim3((unsigned)(grid)), block, 0, __VA_ARGS__)
-#define LAUNCH_LDS(name, kernel, grid, block, lds, ...) LAUNCH_CFG(name, kernel, dim3((unsigned)(grid)), block, lds, __VA_ARGS__)
-#define LAUNCH2D(name, kernel, gridx, gridy, block, ...) LAUNCH_CFG(name, kernel, dim3((unsigned)(gridx), (unsigned)(gridy)), block, 0, __VA_ARGS__)
+#define LAUNCH(name, kernel, grid, block, ...) LAUNCH_CFG(name, kernel, grid, 1, block, 0, __VA_ARGS__)
+#define LAUNCH_LDS(name, kernel, grid, block, lds, ...) LAUNCH_CFG(name, kernel, grid, 1, block, lds, __VA_ARGS__)
+#define LAUNCH2D(name, kernel, gridx, gridy, block, ...) LAUNCH_CFG(name, kernel, gridx, gridy, block, 0, __VA_ARGS__)
 
 //------------------------------------------------------------------------------
 // Pool.

@@ -760,9 +760,16 @@ extern "C" int bwtm_extract(const bwtm_index* x, uint64_t first, uint64_t count,
   ENTER(x->ctx);
   if(first + count > x->n) { return fail(BWTM_EINVAL, "bwtm_extract: range past the end"); }   // bwt.h:137
   if(count == 0) { return BWTM_OK; }
-  DevBuf d; TRY(d.alloc(count));
-  LAUNCH("extract", k_extract, div_up(count, BLOCK_THREADS), BLOCK_THREADS, x->view(), first, count, d.as<u8>());
-  HIP_TRY(hipMemcpyAsync(out, d.p, count, hipMemcpyDeviceToHost, CTX.stream));
-  HIP_TRY(hipStreamSynchronize(CTX.stream));
+  // one thread per position, and a HIP grid holds fewer than 2^32 threads: pieces of 2^30 positions (round 5: a single launch over 5.05 * 10^9
+  // positions returned zeros behind the first 2^32 -- tools/scale_cli.sh wrote config 2's inputs that way and merged endmarkers)
+  const u64 piece = 1ull << 30;
+  DevBuf d; TRY(d.alloc(std::min(count, piece)));
+  for(u64 done = 0; done < count; done += piece)
+  {
+    const u64 n = std::min(piece, count - done);
+    LAUNCH("extract", k_extract, div_up(n, BLOCK_THREADS), BLOCK_THREADS, x->view(), first + done, n, d.as<u8>());
+    HIP_TRY(hipMemcpyAsync(out + done, d.p, n, hipMemcpyDeviceToHost, CTX.stream));
+    HIP_TRY(hipStreamSynchronize(CTX.stream));                     // the piece's buffer is reused
+  }
   return BWTM_OK;
 }

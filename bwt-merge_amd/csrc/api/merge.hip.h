@@ -32,6 +32,13 @@ int interleave_chunks(const bwtm_index* a, const bwtm_index* b, bwtm_ra* ra, u64
 {
   if(c1 <= c0) { return BWTM_OK; }
   const u64 count = c1 - c0;
+  // one workgroup of 256 threads per chunk, fewer than 2^32 threads per grid: beyond 2^23 chunks (69 * 10^9 positions) in halves
+  if(count > (1ull << 23))
+  {
+    const u64 mid = c0 + count / 2;
+    TRY(interleave_chunks(a, b, ra, c0, mid, q_lo, q_hi, sup_out, recs_out));
+    return interleave_chunks(a, b, ra, mid, c1, q_lo, q_hi, sup_out, recs_out);
+  }
   DevBuf base_rel; TRY(base_rel.alloc(5 * count * sizeof(u32)));
   LAUNCH("interleave_base", k_interleave_base, div_up(count, BLOCK_THREADS), BLOCK_THREADS, a->view(), b->view(), ra->chunk_base.as<const u64>(), c0, c1,
     sup_out, base_rel.as<u32>(), count);

@@ -396,9 +396,14 @@ extern "C" int bwtm_slice_extract(bwtm_slice* s, uint64_t first, uint64_t count,
   const u64 lo = s->pos_first(), hi = std::min(s->n, s->rec_last << REC_SHIFT);
   if(first < lo || first + count > hi) { return fail(BWTM_EINVAL, "bwtm_slice_extract: range outside the slice"); }
   if(count == 0) { return BWTM_OK; }
-  DevBuf d; TRY(d.alloc(count));
-  LAUNCH("extract", k_extract, div_up(count, BLOCK_THREADS), BLOCK_THREADS, s->view(), first, count, d.as<u8>());
-  HIP_TRY(hipMemcpyAsync(out, d.p, count, hipMemcpyDeviceToHost, CTX.stream));
-  HIP_TRY(hipStreamSynchronize(CTX.stream));
+  const u64 piece = 1ull << 30;                                    // fewer than 2^32 threads per launch (bwtm_extract)
+  DevBuf d; TRY(d.alloc(std::min(count, piece)));
+  for(u64 done = 0; done < count; done += piece)
+  {
+    const u64 n = std::min(piece, count - done);
+    LAUNCH("extract", k_extract, div_up(n, BLOCK_THREADS), BLOCK_THREADS, s->view(), first + done, n, d.as<u8>());
+    HIP_TRY(hipMemcpyAsync(out + done, d.p, n, hipMemcpyDeviceToHost, CTX.stream));
+    HIP_TRY(hipStreamSynchronize(CTX.stream));
+  }
   return BWTM_OK;
 }

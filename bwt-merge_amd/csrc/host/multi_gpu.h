@@ -358,6 +358,10 @@ inline void mergeMultiGPU(FMI& a, FMI& b, const std::vector<int>& devices, FMI& 
           if(h != g && len > 0) { check(hipMemcpy((char*)staging[g] + off, (const char*)staging[h] + off, len, hipMemcpyDeviceToDevice), "device-to-device copy of a peer's piece"); }
         }
       }
+      // a device-to-device hipMemcpy returns before the copy has run (it is ordered on the null stream only), and the library decodes the
+      // buffer on a stream of its own: without this the first decode pass raced the copies on inputs of a few gigabytes (round 5:
+      // "native stream decodes to 1897126518 positions, header says 2020000000" with -g 0,0 at 2 x 2 Gbase; small inputs never showed it)
+      check(hipDeviceSynchronize(), "hipDeviceSynchronize");
     }
     barrier.wait();                                                         // nobody reads a peer's buffer any more
     bwtm_index* x = nullptr;

@@ -60,6 +60,14 @@ def test_coordinates_beyond_32_bits(gpu, oracle):
     assert a.bases > (1 << 32) and b.bases > (1 << 32)
     oranks, ocounts, _ = oracle.search(a, b, capacity=1 << 21, threads=8)
     A, B = upload(gpu, a), upload(gpu, b)
+    # BWT::extract of MORE than 2^32 positions in one call (one thread per position and a grid holds fewer than 2^32 threads: until round 5 the
+    # call returned zeros behind the first 2^32 -- and tools/scale_cli.sh wrote config 2's inputs through it)
+    sym = A.extract(0, a.bases)
+    for first in (0, (1 << 32) - 70000, (1 << 32) + 123457, a.bases - 100000):
+        probe = list(range(first, min(first + 100000, a.bases), 997))
+        assert [int(sym[i]) for i in probe] == [a.at(i) for i in probe], first
+    assert int(np.count_nonzero(sym[1 << 32:])) > (a.bases - (1 << 32)) // 2
+    del sym
     # the frontier search alone (one element per sequence), the node phase alone (every level of this collection has at most 4096
     # trie nodes: fmi.cpp:304-322, the reference's own form), five levels of nodes expanded into 4.3e7 elements, and the walk
     for algo, kernel, ratio, absent in ((2, "frontier_step", 0, "range_step"), (2, "range_step", -1, "frontier_step"), (2, "frontier_step", 71680, None),
