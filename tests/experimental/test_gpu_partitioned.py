@@ -266,3 +266,35 @@ def test_partitioned_merge_of_repetitive_reads(gpu, oracle, glen, coverage):
     assert np.array_equal(data, m.data)
     obe, ocum = m.samples
     assert np.array_equal(be, obe) and np.array_equal(cum, ocum[:, :-1])
+
+
+@pytest.mark.parametrize("case", ["short", "one_base", "with_n", "tiny_b", "unequal"])
+def test_partitioned_merge_of_odd_collections(gpu, oracle, case):
+    """Collections on which most parts end up with nothing: reads shorter than k, a single symbol, N's, a b of three sequences, inputs of very
+    different sizes -- all smaller than one encoder segment, so all but one part have an empty range of the output.  Windows may be a single
+    record, cuts may coincide; the merge is still the oracle's."""
+    rng = np.random.default_rng({"short": 1, "one_base": 2, "with_n": 3, "tiny_b": 4, "unequal": 5}[case])
+
+    def reads(n, lo, hi, alphabet):
+        out = []
+        for _ in range(n):
+            out.append(rng.choice(alphabet, rng.integers(lo, hi + 1)).astype(np.uint8)); out.append(np.zeros(1, dtype=np.uint8))
+        return np.concatenate(out)
+
+    if case == "short":
+        ta, tb = reads(400, 0, 3, [1, 2, 3, 4]), reads(300, 0, 4, [1, 2, 3, 4])
+    elif case == "one_base":
+        ta, tb = reads(200, 5, 40, [3]), reads(150, 1, 60, [3])
+    elif case == "with_n":
+        ta, tb = reads(300, 20, 50, [1, 2, 3, 4, 5, 5]), reads(250, 10, 70, [1, 2, 3, 4, 5])
+    elif case == "tiny_b":
+        ta, tb = reads(500, 30, 60, [1, 2, 3, 4]), reads(3, 5, 9, [1, 2, 3, 4])
+    else:
+        ta, tb = reads(40, 10, 20, [1, 2, 3, 4]), reads(900, 40, 80, [1, 2, 3, 4])
+    a, b = oracle.FMI.from_text(ta), oracle.FMI.from_text(tb)
+    for parts, k, node_ratio in ((3, 2, 8), (5, 3, 0)):
+        data, be, cum, held, bounds = partitioned_merge(gpu, a, b, parts, k, node_ratio, from_bytes=True)
+        m, _ = oracle.merge(a.clone(), b.clone(), threads=1)
+        assert np.array_equal(data, m.data), (case, parts)
+        obe, ocum = m.samples
+        assert np.array_equal(be, obe) and np.array_equal(cum, ocum[:, :-1]), (case, parts)

