@@ -7,8 +7,15 @@
     * the sliced frontier search (bwtm_fslice_*): the dense multi-GPU form of buildRA (fmi.cpp:272-334).  Exact on 1 - 8 parts against
       the oracle; its exchange needs peer-mapped buffers and a gather folded into the step kernel before it is a product path, and no
       machine with more than one GPU was available to measure it;
+    * the merge over PARTITIONED records (bwtm_x_index_upload_window / bwtm_x_index_window, bwtm_x_ra_create_range, bwtm_fslice_set_cuts,
+      bwtm_fslice_nodes_*, bwtm_fslice_gather_cut, bwtm_fslice_input_buffers): nothing replicated -- every GPU holds one window of each
+      input and of the bitvector, nodes and elements travel to the GPU that owns their position, and the product's range entry points
+      finish the merge from the windows.  Exact on 1 - 16 parts against the oracle, and against the product merge at full size
+      (DESIGN.md section 6.3); drivers: bwt-merge_amd/experimental.py (contexts of one GPU), experimental_dist.py (one process per GPU),
+      csrc/host/multi_gpu.h (bwt_merge_experimental -P).  Never run on more than one GPU;
     * the two-plane search view (bwtm_tune("search_view", 1 | 2)): a denser copy of the rank structure for the frontier search.  Exact;
-      14 % fewer HBM reads and no time saved, hence not in the product.
+      14 % fewer HBM reads and no time saved, hence not in the product;
+    * bwtm_x_device_scan: a test hook of the library's device scan.
 */
 #ifndef BWTM_EXPERIMENTAL_H
 #define BWTM_EXPERIMENTAL_H
