@@ -150,6 +150,7 @@ def merge_partitioned_dist(pkg, a, b, cuts, rank, world, dist, torch, device, ti
     bounds = [(min(nrecs, seg[g] * 512), nrecs if g == world - 1 else min(nrecs, seg[g + 1] * 512)) for g in range(world)]
     # boundary bits: row k of `mine` = this rank's bits inside rank k's first segment; after the all-gather rank k ORs its column
     mine = torch.zeros((world, 1024), dtype=torch.int64, device=device)
+    torch.cuda.synchronize(device)                                   # the zero-fill ran on torch's stream; the library's streams do not order behind it
     for k in range(rank + 1, world):
         if max(seg[k] * 65536, P[rank]) < min(P[k], P[rank + 1]):
             X.ra_read_words(ra, seg[k] * 65536, seg[k] * 65536 + 65536, mine[k].data_ptr())
@@ -161,6 +162,8 @@ def merge_partitioned_dist(pkg, a, b, cuts, rank, world, dist, torch, device, ti
     rec_first, rec_last = bounds[rank]
     ones, local, tail = ra.range_counts(rec_first, rec_last)
     before, total, super_boff, halo = combine_range_counts(ones, local, tail, bounds, rank, world, dist, torch, device)
+    if int(total) != nb:
+        raise X.BwtmError("the ranks' ranges hold %d set bits, b has %d positions" % (int(total), nb))
     ra.finalize_range(rec_first, rec_last, before, total, super_boff, halo)
     S = pkg.Slice(wa, wb, ra, rec_first, rec_last)
     _, offset, total_bytes = exchange_encoder_carries(S.lasthead(), S.size_table, rank, world, dist, torch, device)
