@@ -34,6 +34,22 @@ class HostOutput(C.Structure):
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, u64)
 
+
+class HostIndex(C.Structure):
+    """bwtm_host_index"""
+    _fields_ = [("data", C.c_void_p), ("nbytes", u64), ("blocks", u64), ("sequences", u64), ("bases", u64), ("C", u64 * (SIGMA + 1)), ("cum", C.c_void_p)]
+
+
+class IndexHeader(C.Structure):
+    """bwtm_index_header"""
+    _fields_ = [("bases", u64), ("sequences", u64), ("C", u64 * (SIGMA + 1))]
+
+
+class PartInfo(C.Structure):
+    """bwtm_part_info"""
+    _fields_ = [("steps", u64), ("node_levels", u64), ("elements", u64), ("largest", u64), ("pulled_bytes", u64), ("boundary_bytes", u64),
+                ("record_bytes", u64), ("bitvector_bytes", u64), ("ms_search", C.c_double), ("ms_search_wait", C.c_double), ("ms_finish", C.c_double)]
+
 # Every symbol include/bwtm.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("bwtm_init", C.c_int, [C.c_int]),
@@ -116,6 +132,26 @@ SYMBOLS = [
     ("bwtm_builder_finish", C.c_int, [vp, C.POINTER(vp)]),
     ("bwtm_builder_free", None, [vp]),
     ("bwtm_pool_stats", C.c_int, [vp]),
+    ("bwtm_group_create", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]),
+    ("bwtm_group_free", None, [vp]),
+    ("bwtm_group_part", C.c_int, [vp]),
+    ("bwtm_group_parts", C.c_int, [vp]),
+    ("bwtm_group_barrier", C.c_int, [vp]),
+    ("bwtm_group_allgather", C.c_int, [vp, vp, u64, vp]),
+    ("bwtm_group_abort", None, [vp]),
+    ("bwtm_partition_cuts_host", C.c_int, [C.POINTER(HostIndex), C.POINTER(HostIndex), C.c_int, C.c_int, p_u64, p_u64]),
+    ("bwtm_window_blocks", C.c_int, [C.POINTER(HostIndex), u64, u64, p_u64, p_u64, p_u64, p_u64]),
+    ("bwtm_index_upload_window", C.c_int, [vp, u64, u64, p_u64, u64, u64, p_u64, C.c_int, C.POINTER(vp)]),
+    ("bwtm_index_record_bytes", u64, [vp]),
+    ("bwtm_ra_create_range", C.c_int, [vp, vp, u64, u64, C.POINTER(vp)]),
+    ("bwtm_ra_bytes", u64, [vp]),
+    ("bwtm_part_create", C.c_int, [vp, C.POINTER(IndexHeader), C.POINTER(IndexHeader), p_u64, p_u64, C.POINTER(vp)]),
+    ("bwtm_part_free", None, [vp]),
+    ("bwtm_part_window", C.c_int, [vp, C.c_int, p_u64, p_u64]),
+    ("bwtm_part_upload", C.c_int, [vp, C.c_int, vp, u64, u64, p_u64, C.c_int]),
+    ("bwtm_part_search", C.c_int, [vp]),
+    ("bwtm_part_finish", C.c_int, [vp, C.POINTER(vp), p_u64, p_u64, p_u64]),
+    ("bwtm_part_stats", C.c_int, [vp, C.POINTER(PartInfo)]),
     ("bwtm_profile_enable", C.c_int, [C.c_int]),
     ("bwtm_profile_only", C.c_int, [C.c_char_p]),
     ("bwtm_profile_reset", C.c_int, []),
@@ -701,6 +737,127 @@ class Slice:
         out = np.zeros(count, dtype=np.uint8)
         check(lib().bwtm_slice_extract(self.h, first, count, out.ctypes.data_as(p_u8)))
         return out
+
+
+class Group:
+    """The parts of a merge over partitioned records (bwtm_group): `name` = a POSIX shared-memory name unique to the group (None for one part)."""
+
+    def __init__(self, name, part, parts):
+        out = vp()
+        check(lib().bwtm_group_create(name.encode() if name else None, int(part), int(parts), C.byref(out)))
+        self.h = out
+        self.part, self.parts = int(part), int(parts)
+
+    def free(self):
+        if self.h:
+            lib().bwtm_group_free(self.h)
+            self.h = None
+
+    def barrier(self):
+        check(lib().bwtm_group_barrier(self.h))
+
+    def allgather(self, mine):
+        """mine: a numpy array; returns [parts, ...] of the same dtype."""
+        mine = np.ascontiguousarray(mine)
+        out = np.zeros((self.parts,) + mine.shape, dtype=mine.dtype)
+        check(lib().bwtm_group_allgather(self.h, mine.ctypes.data_as(vp), mine.nbytes, out.ctypes.data_as(vp)))
+        return out
+
+    def abort(self):
+        if self.h:
+            lib().bwtm_group_abort(self.h)
+
+
+def host_index(data, cum, sequences, bases):
+    """bwtm_host_index over numpy arrays (kept alive by the returned object): data = the native bytes, cum[6][blocks + 1] = the samples."""
+    assert data.dtype == np.uint8 and data.flags["C_CONTIGUOUS"]
+    cum = np.ascontiguousarray(cum, dtype=np.uint64)
+    blocks = cum.shape[1] - 1
+    x = HostIndex()
+    x.data = data.ctypes.data; x.nbytes = data.size; x.blocks = blocks; x.sequences = int(sequences); x.bases = int(bases)
+    totals = [int(cum[c][blocks]) for c in range(SIGMA)]
+    for c in range(SIGMA + 1):
+        x.C[c] = sum(totals[:c])
+    x.cum = cum.ctypes.data
+    x._keep = (data, cum)
+    return x
+
+
+def partition_cuts_host(a, b, parts, kmer=0):
+    """(cut_a, cut_b): parts + 1 ranks each (bwtm_partition_cuts_host); a, b = host_index() objects."""
+    ca = np.zeros(parts + 1, dtype=np.uint64); cb = np.zeros(parts + 1, dtype=np.uint64)
+    check(lib().bwtm_partition_cuts_host(C.byref(a), C.byref(b), int(parts), int(kmer), ca.ctypes.data_as(p_u64), cb.ctypes.data_as(p_u64)))
+    return [int(v) for v in ca], [int(v) for v in cb]
+
+
+def window_blocks(x, pos_first, pos_last):
+    """(block_first, block_end, first_position, counts_before[6]) of the blocks that cover the records of [pos_first, pos_last] (bwtm_window_blocks)."""
+    b0, b1, fp = u64(0), u64(0), u64(0)
+    before = (u64 * 6)()
+    check(lib().bwtm_window_blocks(C.byref(x), int(pos_first), int(pos_last), C.byref(b0), C.byref(b1), C.byref(fp), before))
+    return int(b0.value), int(b1.value), int(fp.value), before
+
+
+class Part:
+    """One part of a merge over partitioned records (bwtm_part): created in the calling thread's context."""
+
+    def __init__(self, group, a, b, cut_a, cut_b):
+        """a, b: host_index() objects (or anything with bases / sequences / C)."""
+        ha, hb = IndexHeader(), IndexHeader()
+        for h, x in ((ha, a), (hb, b)):
+            h.bases = int(x.bases); h.sequences = int(x.sequences)
+            for c in range(SIGMA + 1):
+                h.C[c] = int(x.C[c])
+        ca = (u64 * len(cut_a))(*[int(v) for v in cut_a]); cb = (u64 * len(cut_b))(*[int(v) for v in cut_b])
+        out = vp()
+        check(lib().bwtm_part_create(group.h, C.byref(ha), C.byref(hb), ca, cb, C.byref(out)))
+        self.h = out
+        self.group = group
+
+    def free(self):
+        if self.h:
+            lib().bwtm_part_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def window(self, which):
+        lo, hi = u64(0), u64(0)
+        check(lib().bwtm_part_window(self.h, int(which), C.byref(lo), C.byref(hi)))
+        return int(lo.value), int(hi.value)
+
+    def share(self, which, x):
+        """(byte offset, byte count, first_position, counts_before) of this part's share of host index x's stream."""
+        lo, hi = self.window(which)
+        b0, b1, fp, before = window_blocks(x, lo, hi)
+        return b0 * 64, min(b1 * 64, int(x.nbytes)) - b0 * 64, fp, before
+
+    def upload(self, which, ptr, nbytes, first_position, counts_before, on_device=False):
+        check(lib().bwtm_part_upload(self.h, int(which), vp(ptr), int(nbytes), int(first_position), counts_before, 1 if on_device else 0))
+
+    def upload_host(self, which, x):
+        off, count, fp, before = self.share(which, x)
+        self.upload(which, x.data + off, count, fp, before, on_device=False)
+
+    def search(self):
+        check(lib().bwtm_part_search(self.h))
+
+    def finish(self):
+        """The part's encoded Slice (total_nbytes, byte_offset, next_block_start set)."""
+        out, off, total, nxt = vp(), u64(0), u64(0), u64(0)
+        check(lib().bwtm_part_finish(self.h, C.byref(out), C.byref(off), C.byref(total), C.byref(nxt)))
+        s = Slice.__new__(Slice)
+        s.h = out; s.total_nbytes = int(total.value); s.byte_offset = int(off.value); s.next_block_start = int(nxt.value)
+        return s
+
+    def stats(self):
+        info = PartInfo()
+        check(lib().bwtm_part_stats(self.h, C.byref(info)))
+        return {k: getattr(info, k) for k, _ in PartInfo._fields_}
 
 
 def merged_records(a, b):

@@ -231,7 +231,7 @@ extern "C" int bwtm_fslice_advance(bwtm_fslice* fs)
   f.seg_len_next = fs->seg_len_out.as<u64>(); f.seg_phys_next = fs->seg_phys_out;
   f.nb_max = nbl;
   f.emit16 = fs->emit16.as<unsigned short>(); f.emit_base = fs->emit_base.as<const u64>(); f.emit_cap = fs->emit_cap; f.bits32 = fs->ra->bits_as<u32>();
-  f.bound_row = fs->bound.as<u32>() + fs->in_epoch * (fs->ntiles + 1); f.step = fs->in_epoch; f.block_base = 0;
+  f.bound_row = fs->bound.as<u32>() + fs->in_epoch * (fs->ntiles + 1); f.step = fs->in_epoch; f.block_base = 0; f.src_lo = nullptr; f.src_hi = nullptr; f.nseg_in = 0;
   if(fs->wide) { LAUNCH("frontier_step", (k_frontier_step<0, true>), nbl, FR_BLOCK, fs->a->view(), fs->b->view(), f); }
   else { LAUNCH("frontier_step", (k_frontier_step<0, false>), nbl, FR_BLOCK, fs->a->view(), fs->b->view(), f); }
   fs->in_epoch++; fs->epoch_used += fs->n_in;

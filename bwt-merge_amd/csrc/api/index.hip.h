@@ -32,12 +32,13 @@ struct bwtm_index
   mutable DevBuf sview, vsup;         // the search view (built on demand by the frontier search, dropped with the records)
   mutable u64 nview = 0;
   mutable bool view_ready = false;    // set after both kernels that fill the view were queued
-  // A WINDOW of another index's records (bwtm_x_index_window; the partitioned search): `recs` holds the records
-  // [win_first, win_first + win_count) only, and view() hands the kernels a base pointer shifted back by win_first records, so that
-  // absolute record numbers address it unchanged.  Positions outside the window must never be queried: only bwtm_fslice_* take such a handle.
+#endif
+  // A WINDOW of an index's records (bwtm_index_upload_window; the merge over partitioned records): `recs` holds the
+  // records [win_first, win_first + win_count) only, and view() hands the kernels a base pointer shifted back by win_first records, so that
+  // absolute record numbers address it unchanged.  Positions outside the window must never be queried: only bwtm_part_* and the
+  // output-range entry points take such a handle.
   u64 win_first = 0, win_count = 0;
   bool windowed = false;
-#endif
 
   IndexView view() const
   {
@@ -47,18 +48,14 @@ struct bwtm_index
     for(int c = 0; c < 8; c++) { v.C[c] = C[c]; }
 #ifdef BWTM_EXPERIMENTAL
     v.view = (view_ready ? sview.as<const uint4>() : nullptr); v.vsup = (view_ready ? vsup.as<const u64>() : nullptr); v.nview = (view_ready ? nview : 0);
-    if(windowed) { v.recs = (const uint4*)((const char*)recs.p - (win_first << 6)); }        // 64 bytes per record
 #endif
+    if(windowed) { v.recs = (const uint4*)((const char*)recs.p - (win_first << 6)); }        // 64 bytes per record
     return v;
   }
 };
 
-// Entry points that query arbitrary positions refuse a window of an index (experimental build; nothing in the product build).
-#ifdef BWTM_EXPERIMENTAL
-#define WHOLE_INDEX(x, who) if((x)->windowed) { return fail(BWTM_EINVAL, who ": a window of an index (bwtm_x_index_window) only serves bwtm_fslice_*"); }
-#else
-#define WHOLE_INDEX(x, who)
-#endif
+// Entry points that query arbitrary positions refuse a window of an index.
+#define WHOLE_INDEX(x, who) if((x)->windowed) { return fail(BWTM_EINVAL, who ": a window of an index (bwtm_index_upload_window) only serves the merge over partitioned records"); }
 
 namespace
 {

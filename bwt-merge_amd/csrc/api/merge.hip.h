@@ -63,9 +63,7 @@ int interleave_impl(const bwtm_index* a, const bwtm_index* b, bwtm_ra* ra, bwtm_
 int check_interleave_args(const bwtm_index* a, const bwtm_index* b, const bwtm_ra* ra, bool allow_ranged = false)
 {
   if(!allow_ranged) { WHOLE_INDEX(a, "bwtm_interleave"); WHOLE_INDEX(b, "bwtm_interleave"); }
-#ifdef BWTM_EXPERIMENTAL
   if((a->windowed || b->windowed) && !ra->ranged) { return fail(BWTM_EINVAL, "bwtm_interleave_range: windows of indexes need a rank array finalized for the range (bwtm_ra_finalize_range)"); }
-#endif
   if(!ra->finalized) { return fail(BWTM_EINVAL, "bwtm_interleave: rank array not finalized"); }
   if(ra->ranged && !allow_ranged) { return fail(BWTM_EINVAL, "bwtm_interleave: the rank array was finalized for an output range (bwtm_interleave_range takes it)"); }
   if(ra->na != a->n || ra->nb != b->n) { return fail(BWTM_EINVAL, "bwtm_interleave: rank array was created for other inputs"); }

@@ -131,11 +131,7 @@ extern "C" int bwtm_x_index_window(const bwtm_index* whole, uint64_t pos_first, 
   return BWTM_OK;
 }
 
-extern "C" uint64_t bwtm_x_index_record_bytes(const bwtm_index* x)
-{
-  if(!x) { return 0; }
-  return (x->windowed ? x->win_count : x->nrecs) * 64;
-}
+extern "C" uint64_t bwtm_x_index_record_bytes(const bwtm_index* x) { return bwtm_index_record_bytes(x); }
 
 extern "C" int bwtm_fslice_nodes_begin(bwtm_fslice* fs, uint64_t seq_first, uint64_t count, uint64_t node_capacity)
 {
@@ -299,93 +295,12 @@ extern "C" int bwtm_x_index_upload_window(const uint8_t* data, uint64_t nbytes, 
   uint64_t bases, uint64_t sequences, const uint64_t C[7], bwtm_index** out)
 {
   ENTER(nullptr);
-  if(!out || !data || nbytes == 0 || !counts_before || !C) { return fail(BWTM_EINVAL, "bwtm_x_index_upload_window: null argument"); }
-  u64 before = 0; for(int c = 0; c < 6; c++) { before += counts_before[c]; }
-  if(before != first_position || first_position > bases) { return fail(BWTM_EINVAL, "bwtm_x_index_upload_window: the counts before the bytes add up to %llu, their first position is %llu", (unsigned long long)before, (unsigned long long)first_position); }
-  bwtm_index* x = new bwtm_index();
-  x->ctx = t_ctx; x->nbytes = nbytes;
-  auto body = [&]() -> int
-  {
-    TRY(alloc_native(x->data, nbytes));
-    // the product's upload pipeline on the share: block lengths and group counts, their scans; the stream's verdict and totals come back
-    int rc = upload_queue(x, data);
-    if(rc == BWTM_OK) { rc = upload_scan(x, 0); }
-    hipError_t e1 = hipStreamSynchronize(CTX.copy_stream), e2 = hipStreamSynchronize(CTX.stream);
-    if(rc != BWTM_OK) { return rc; }
-    if(e1 != hipSuccess || e2 != hipSuccess) { return fail(BWTM_ENODEV, "upload failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); }
-    const u32 flags = (u32)CTX.host_scratch[6];
-    x->flags.release();
-    if(flags & 1u) { return fail(BWTM_EINVAL, "not a canonical run-length stream: a full 64-byte block encodes fewer than 64 positions"); }
-    u64 held = 0; for(int c = 0; c < 6; c++) { held += CTX.host_scratch[c]; }
-    const u64 end_position = first_position + held;
-    if(end_position > bases) { return fail(BWTM_EINVAL, "bwtm_x_index_upload_window: the bytes decode to positions [%llu, %llu) of an index of %llu", (unsigned long long)first_position, (unsigned long long)end_position, (unsigned long long)bases); }
-    // absolute positions and counts: the scanned group tables start at the share's first block
-    const u64 gstride = x->ngroups + 1;
-    for(u32 c = 0; c < 7; c++)
-    {
-      const u64 v = (c < 6 ? counts_before[c] : first_position);
-      if(v != 0) { LAUNCH("add_offset", k_add_offset, div_up(gstride, BLOCK_THREADS), BLOCK_THREADS, x->gcum.as<u64>() + (u64)c * gstride, gstride, v); }
-    }
-    x->n = bases; x->m = sequences;
-    for(int c = 0; c < 7; c++) { x->C[c] = C[c]; }
-    x->C[7] = x->C[6];
-    x->nrecs = num_records(bases); x->nsup = num_supers(bases);
-    // records that begin inside the share (k_build_recs: a group owns the records that START in it; the last group owns the rest, here up to
-    // the record the share ends in, whose tail is only valid when the share holds the end of the index)
-    const u64 q0 = (first_position + REC_POS - 1) >> REC_SHIFT, q_end = (end_position >> REC_SHIFT) + 1;
-    if(q0 >= q_end) { return fail(BWTM_EINVAL, "bwtm_x_index_upload_window: the bytes hold no whole record"); }
-    x->windowed = true; x->win_first = q0; x->win_count = q_end - q0;
-    TRY(x->recs.alloc(x->win_count * 64));
-    TRY(x->sup.alloc(x->nsup * SUP_STRIDE * sizeof(u64)));
-    // super rows: k_build_sup gives a super that begins before the share the counts at the share's first position -- at or below the counts
-    // of every record of the window, which is all a row has to be (header fields are offsets from it)
-    LAUNCH("build_sup", k_build_sup, div_up(x->nsup * WAVE, BLOCK_THREADS), BLOCK_THREADS,
-      x->native_bytes(), x->nbytes, x->blen.as<const u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, end_position, x->sup.as<u64>(), x->nsup);
-    uint4* shifted = (uint4*)((char*)x->recs.p - (q0 << 6));
-    const u64 per_group = held / x->ngroups;
-    const bool long_runs = (x->nblocks > 0 && held / x->nblocks > 400);
-#define BUILD_RECS_W(W, WAVES, FILL) LAUNCH("build_recs", (k_build_recs<W, WAVES, FILL>), div_up(x->ngroups, WAVES), WAVES * WAVE, \
-    x->native_bytes(), x->nbytes, x->blen.as<const u64>(), x->block_start.as<u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, end_position, \
-    x->sup.as<const u64>(), shifted, q_end)
-    if(per_group <= 6500) { BUILD_RECS_W(8192, 4, false); }
-    else if(per_group <= 14000) { BUILD_RECS_W(16384, 4, false); }
-    else if(!long_runs) { BUILD_RECS_W(32768, 2, false); }
-    else { BUILD_RECS_W(32768, 2, true); }
-#undef BUILD_RECS_W
-    HIP_TRY(hipStreamSynchronize(CTX.stream));
-    x->blen.release(); x->block_start.release(); x->gcum.release(); x->data.release();          // a window keeps its records and super rows only
-    x->has_native = false; x->nbytes = 0; x->nblocks = 0; x->ngroups = 0;
-    // the record the share begins in and the one it ends in are incomplete unless they are the index's own first / last
-    if(end_position < bases) { x->win_count -= 1; }
-    if(x->win_count == 0) { return fail(BWTM_EINVAL, "bwtm_x_index_upload_window: the bytes hold no whole record"); }
-    return BWTM_OK;
-  };
-  int rc = body();
-  if(rc != BWTM_OK) { (void)hipStreamSynchronize(CTX.stream); delete x; return rc; }
-  *out = x;
-  return BWTM_OK;
+  return index_upload_window(data, nbytes, first_position, counts_before, bases, sequences, C, false, out);     // product code since round 6 (api/pmerge.hip.h)
 }
 
 extern "C" int bwtm_x_ra_create_range(const bwtm_index* a, const bwtm_index* b, uint64_t pos_first, uint64_t pos_last, bwtm_ra** out)
 {
-  if(!a || !b || !out || pos_first > pos_last) { return fail(BWTM_EINVAL, "bwtm_x_ra_create_range: bad argument"); }
-  if(a->ctx != b->ctx) { return fail(BWTM_EINVAL, "bwtm_x_ra_create_range: the two indexes live in different contexts"); }
-  ENTER(a->ctx);
-  bwtm_ra* ra = new bwtm_ra();
-  ra->ctx = t_ctx;
-  ra->na = a->n; ra->nb = b->n; ra->n_out = a->n + b->n;
-  ra->nrecs_out = num_records(ra->n_out);
-  ra->nchunks = div_up(ra->nrecs_out, 64);
-  const u64 tile_words = 1ull << (TILE_SHIFT - 6), nwords = ra->nchunks * CHUNK_WORDS;
-  const u64 t0 = (pos_first >> TILE_SHIFT), t1 = div_up(std::min<u64>(pos_last, ra->n_out) + 1, 1ull << TILE_SHIFT);
-  const u64 w0 = (t0 > 0 ? t0 - 1 : 0) * tile_words, w1 = std::min<u64>(nwords, (t1 + 1) * tile_words);
-  ra->windowed = true; ra->win_word_first = w0; ra->win_words = (w1 > w0 ? w1 - w0 : tile_words);
-  int rc = ra->owned_bits.alloc(ra->win_words * sizeof(u64), true);
-  if(rc == BWTM_OK) { ra->bits_ptr = (char*)ra->owned_bits.p - w0 * sizeof(u64); }
-  if(rc == BWTM_OK) { rc = ra->chunk_base.alloc((ra->nchunks + 1) * sizeof(u64), true); }
-  if(rc != BWTM_OK) { delete ra; return rc; }
-  *out = ra;
-  return BWTM_OK;
+  return bwtm_ra_create_range(a, b, pos_first, pos_last, out);                                                    // product code since round 6
 }
 
 extern "C" int bwtm_x_ra_or_range(bwtm_ra* dst, const bwtm_ra* src, uint64_t pos_first, uint64_t pos_last)
@@ -441,8 +356,4 @@ extern "C" int bwtm_x_ra_or_words(bwtm_ra* ra, uint64_t pos_first, uint64_t pos_
   return BWTM_OK;
 }
 
-extern "C" uint64_t bwtm_x_ra_bytes(const bwtm_ra* ra)
-{
-  if(!ra) { return 0; }
-  return (ra->windowed ? ra->win_words : ra->nchunks * CHUNK_WORDS) * sizeof(u64);
-}
+extern "C" uint64_t bwtm_x_ra_bytes(const bwtm_ra* ra) { return bwtm_ra_bytes(ra); }

@@ -24,20 +24,14 @@ struct bwtm_ra
   u64 range_first = 0, range_last = 0;
   DevBuf range_rel;                   // chunk counts of the range, scanned (between bwtm_ra_range_counts and bwtm_ra_finalize_range)
   DevBuf super_boff;                  // set bits before every super block of the output (ranged form only)
-#ifdef BWTM_EXPERIMENTAL
-  // A WINDOW of the bitvector (bwtm_x_ra_create_range; partitioned records): owned_bits holds the words
+  // A WINDOW of the bitvector (bwtm_ra_create_range; partitioned records): owned_bits holds the words
   // [win_word_first, win_word_first + win_words) only and bits_ptr is shifted back so that absolute word numbers address it unchanged.
   bool windowed = false;
   u64 win_word_first = 0, win_words = 0;
-#endif
 };
 
-// Entry points that walk the whole bitvector refuse a window of one (experimental build; nothing in the product build).
-#ifdef BWTM_EXPERIMENTAL
-#define WHOLE_RA(ra, who) if((ra)->windowed) { return fail(BWTM_EINVAL, who ": a window of a rank array (bwtm_x_ra_create_range) only serves bwtm_fslice_* and the output-range entry points"); }
-#else
-#define WHOLE_RA(ra, who)
-#endif
+// Entry points that walk the whole bitvector refuse a window of one.
+#define WHOLE_RA(ra, who) if((ra)->windowed) { return fail(BWTM_EINVAL, who ": a window of a rank array (bwtm_ra_create_range) only serves the merge over partitioned records and the output-range entry points"); }
 
 namespace
 {
@@ -486,7 +480,7 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
     f.seg_len_next = seg_len[1 - cur].as<u64>(); f.seg_phys_next = seg_phys[1 - cur].as<u64>();
     f.nb_max = nb_max;
     f.emit16 = emit16.as<unsigned short>(); f.emit_base = emit_base.as<const u64>(); f.emit_cap = emit_cap; f.bits32 = ra->bits_as<u32>();
-    f.bound_row = bound.as<u32>() + in_epoch * (ntiles + 1); f.step = in_epoch; f.block_base = 0;
+    f.bound_row = bound.as<u32>() + in_epoch * (ntiles + 1); f.step = in_epoch; f.block_base = 0; f.src_lo = nullptr; f.src_hi = nullptr; f.nseg_in = 0;
 #ifdef BWTM_DIAGNOSTICS
     if(g_tune.walk_emit == 1 && wide) { LAUNCH("frontier_step_noemit", (k_frontier_step<1, true>), grid, FR_BLOCK, a->view(), b->view(), f); }
     else if(g_tune.walk_emit == 1) { LAUNCH("frontier_step_noemit", (k_frontier_step<1, false>), grid, FR_BLOCK, a->view(), b->view(), f); }

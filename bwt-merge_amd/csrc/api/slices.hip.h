@@ -114,14 +114,12 @@ extern "C" int bwtm_ra_range_counts(bwtm_ra* ra, uint64_t rec_first, uint64_t re
   if(!ra || !ones) { return fail(BWTM_EINVAL, "bwtm_ra_range_counts: null argument"); }
   ENTER(ra->ctx);
   TRY(check_range(ra, rec_first, rec_last, "bwtm_ra_range_counts"));
-#ifdef BWTM_EXPERIMENTAL
   if(ra->windowed && rec_first < rec_last)
   {
     // the chunks of the range and the one before it (the halo bwtm_ra_finalize_range installs) must lie inside the window
     const u64 w0 = (rec_first >= 64 ? (rec_first >> 6) - 1 : 0) * CHUNK_WORDS, w1 = div_up(rec_last, 64) * CHUNK_WORDS;
     if(w0 < ra->win_word_first || w1 > ra->win_word_first + ra->win_words) { return fail(BWTM_EINVAL, "bwtm_ra_range_counts: the records [%llu, %llu) reach outside the rank array's window", (unsigned long long)rec_first, (unsigned long long)rec_last); }
   }
-#endif
   const u64 nsup = num_supers(ra->n_out);
   *ones = 0;
   if(super_local) { for(u64 k = 0; k < nsup; k++) { super_local[k] = 0; } }
@@ -217,15 +215,13 @@ extern "C" int bwtm_interleave_range(const bwtm_index* a, const bwtm_index* b, b
     s->nsup = num_supers(s->n);
     TRY(s->recs.alloc((rec_last - s->rec_halo + 1) * 64));
     TRY(s->sup.alloc(s->nsup * SUP_STRIDE * sizeof(u64)));
-#ifdef BWTM_EXPERIMENTAL
     if(a->windowed || b->windowed)
     {
-      // windows hold the records of this range only: the super rows the slice refers to, from inside the range (kernels/search_partition.hip.h)
+      // windows hold the records of this range only: the super rows the slice refers to, from inside the range (kernels/partition.hip.h)
       LAUNCH("interleave_sup", k_interleave_sup_window, div_up(s->nsup, BLOCK_THREADS), BLOCK_THREADS, a->view(), b->view(), ra->chunk_base.as<const u64>(),
         s->sup.as<u64>(), s->nsup, ra->super_boff.as<const u64>(), (s->rec_halo >> 6) << 6, rec_last);
     }
     else
-#endif
     LAUNCH("interleave_sup", k_interleave_sup, div_up(s->nsup, BLOCK_THREADS), BLOCK_THREADS, a->view(), b->view(),
       ra->bits_as<const u64>(), ra->chunk_base.as<const u64>(), s->n, s->sup.as<u64>(), s->nsup, (ra->ranged ? ra->super_boff.as<const u64>() : (const u64*)nullptr));
     // an empty range (more GPUs than output chunks) interleaves nothing: its halo chunk was not installed by bwtm_ra_finalize_range either

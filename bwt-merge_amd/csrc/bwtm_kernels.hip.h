@@ -15,6 +15,9 @@
                                                                     fmi.cpp:139-257, support.h:396-638
     k_lf_walk_binned, k_lf_walk_quad, k_part_*, k_tile_build
                        the same two stages in per-chain form (small shards, long sequences, > 40-bit coordinates)
+    k_cut_search_seg, k_pull_tables, k_node_cut_search, k_gather_nodes, k_frontier_step<.., PULL>
+                       the same search with the records PARTITIONED over several GPUs (one part each): the thread fan-out of
+                       fmi.cpp:351-358 as position ranges instead of sequence blocks (kernels/partition.hip.h, api/pmerge.hip.h)
     kernels/diagnostics.hip.h (only with -DBWTM_DIAGNOSTICS): timing-only and A/B variants, not in the product
     kernels/search_view.hip.h, k_frontier_step<.., VIEW>, k_frontier_gather (only with -DBWTM_EXPERIMENTAL): the two-plane search
                        view and the sliced frontier search -- exact, tested, measured, not in the product (include/bwtm_experimental.h)
@@ -78,6 +81,7 @@ __device__ inline void nt_store(u32* p, u32 v) { __builtin_nontemporal_store(v, 
 #include "kernels/search_view.hip.h"
 #endif
 #include "kernels/search_frontier.hip.h"
+#include "kernels/partition.hip.h"
 #ifdef BWTM_EXPERIMENTAL
 #include "kernels/search_partition.hip.h"
 #endif

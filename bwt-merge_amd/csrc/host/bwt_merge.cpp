@@ -26,14 +26,15 @@ static void printUsage()
   std::cerr << "  -i formats    Read the inputs in the given formats (default: native)" << std::endl;
   std::cerr << "                Multiple comma-separated formats can be provided." << std::endl;
   std::cerr << "  -o format     Write the output in the given format (default: native)" << std::endl;
-  std::cerr << "  -g N[,M,...]  Use GPU N (default: 0), or one host thread per listed GPU: the sequences of the increment are" << std::endl;
-  std::cerr << "                sharded over them and every GPU produces its range of the output" << std::endl;
+  std::cerr << "  -g N[,M,...]  Use GPU N (default: 0), or one host thread per listed GPU (at most 16).  With several GPUs the records are" << std::endl;
+  std::cerr << "                PARTITIONED: every GPU holds one window of each input and of the bitvector, transcoded from its share" << std::endl;
+  std::cerr << "                of the bytes, and produces its range of the output; the frontier's elements travel between the GPUs" << std::endl;
   std::cerr << "                (the buffer options have no effect on the device)" << std::endl;
+  std::cerr << "  -B            With several GPUs: sequence blocks instead (replicated records, every GPU searches a block of the" << std::endl;
+  std::cerr << "                increment's sequences, one reduce-scatter of the rank-array bitvector by output range)" << std::endl;
 #ifdef BWTM_EXPERIMENTAL
-  std::cerr << "  -S            With several GPUs: sliced search (every GPU advances a contiguous slice of the sorted frontier" << std::endl;
-  std::cerr << "                instead of a block of sequences; experimental build only)" << std::endl;
-  std::cerr << "  -P            With several GPUs: partitioned records (every GPU holds one window of each input and of the" << std::endl;
-  std::cerr << "                bitvector, transcoded from its share of the bytes; elements travel; experimental build only)" << std::endl;
+  std::cerr << "  -S            With several GPUs: sliced search (replicated records, every GPU advances a contiguous slice of the" << std::endl;
+  std::cerr << "                sorted frontier; experimental build only)" << std::endl;
 #endif
   std::cerr << std::endl;
   printFormats(std::cerr);
@@ -79,8 +80,11 @@ static void verifyFMI(const FMI& fmi, const std::string& name, const std::vector
   std::cout << std::endl;
 }
 
-static bool partitioned_merge = false; // -P: with several GPUs, partitioned records (nothing replicated; multi_gpu.h)
-static bool sliced_search = false;      // -S: with several GPUs, every GPU advances a slice of the sorted frontier (multi_gpu.h)
+static MultiGPUMode multi_gpu_mode = MultiGPUMode::Auto;      // several GPUs: partitioned records; -B sequence blocks, -S sliced search (multi_gpu.h)
+static const char* modeName(MultiGPUMode m)
+{
+  return (m == MultiGPUMode::SequenceBlocks ? " (sequence blocks)" : (m == MultiGPUMode::Sliced ? " (sliced search)" : " (partitioned records)"));
+}
 
 static void merge(FMI& index, FMI& increment, const MergeParameters& parameters, const std::vector<int>& devices)
 {
@@ -89,11 +93,11 @@ static void merge(FMI& index, FMI& increment, const MergeParameters& parameters,
   if(devices.size() > 1)
   {
     FMI temp; MultiGPUTimes times;
-    mergeMultiGPU(index, increment, devices, temp, &times, sliced_search, partitioned_merge);      // one host thread per GPU, result assembled on the host
+    mergeMultiGPU(index, increment, devices, temp, &times, multi_gpu_mode);      // one host thread per GPU, result assembled on the host
     index.swap(temp);
 #ifdef VERBOSE_STATUS_INFO
     // the phases of the sharded merge as GPU 0's thread saw them (stderr, like the reference's status lines): what a SCALE session reads
-    std::cerr << "mergeMultiGPU(): " << devices.size() << " GPUs" << (partitioned_merge ? " (partitioned records)" : (sliced_search ? " (sliced search)" : "")) << ": upload " << times.upload << " s, search " << times.search
+    std::cerr << "mergeMultiGPU(): " << devices.size() << " GPUs" << modeName(multi_gpu_mode) << ": upload " << times.upload << " s, search " << times.search
               << " s, exchange " << times.exchange << " s, interleave + encode " << times.interleave_encode << " s, download " << times.download
               << " s, total " << times.total << " s; exchanged " << times.exchange_bytes << " bytes per GPU; host bytes to GPU 0 " << times.host_bytes_gpu0 << std::endl;
 #endif
@@ -122,9 +126,9 @@ int main(int argc, char** argv)
   std::vector<std::string> input_formats;
   while((c = getopt(argc, argv,
 #ifdef BWTM_EXPERIMENTAL
-    "b:m:r:s:t:d:v:i:o:g:SP"
+    "b:m:r:s:t:d:v:i:o:g:BPS"
 #else
-    "b:m:r:s:t:d:v:i:o:g:"
+    "b:m:r:s:t:d:v:i:o:g:BP"
 #endif
     )) != -1)
   {
@@ -142,9 +146,10 @@ int main(int argc, char** argv)
         for(std::string token; std::getline(ss, token, ','); ) { devices.push_back(std::stoi(token)); }
       }
       break;
+    case 'B': multi_gpu_mode = MultiGPUMode::SequenceBlocks; break;
+    case 'P': multi_gpu_mode = MultiGPUMode::Partitioned; break;      // the default, without the fall-back to sequence blocks
 #ifdef BWTM_EXPERIMENTAL
-    case 'S': sliced_search = true; break;
-    case 'P': partitioned_merge = true; break;
+    case 'S': multi_gpu_mode = MultiGPUMode::Sliced; break;
 #endif
     case 'v': pattern_name = optarg; verify = true; break;
     case 'i':

@@ -44,7 +44,7 @@ int main(int argc, char** argv)
   load(a, argv[1], "plain_default"); load(b, argv[2], "plain_default");
   FMI a2 = a, b2 = b, a3 = a, b3 = b, b4 = b, b5 = b;
   FMI a6 = a, b6 = b, a7 = a, b7 = b, a8 = a, b8 = b, a9 = a, b9 = b, a10 = a, b10 = b;
-  FMI a11 = a, b11 = b, a12 = a, b12 = b, a13 = a, b13 = b;                 // (the partitioned merges of the experimental build)
+  FMI a11 = a, b11 = b, a12 = a, b12 = b, a13 = a, b13 = b;                 // (the merges over partitioned records)
   std::vector<byte_type> sa = symbolsOf(a), sb = symbolsOf(b);
   size_type na = a.size(), nb = b.size();
 
@@ -142,7 +142,7 @@ int main(int argc, char** argv)
     CHECK(again.bwt.bytes() == 0);
   }
 
-  // One host thread per GPU (multi_gpu.h).  On this box the "GPUs" are contexts of GPU 0: 1, 2, 3 and 4 threads, each
+  // One host thread per GPU (multi_gpu.h), sequence blocks.  On this box the "GPUs" are contexts of GPU 0: 1, 2, 3 and 4 threads, each
   // searching its block of b's sequences and producing its range of the output; same bytes and samples as the single call.
   {
     std::vector<std::vector<int>> device_lists = { {0}, {0, 0}, {0, 0, 0}, {0, 0, 0, 0} };
@@ -151,7 +151,7 @@ int main(int argc, char** argv)
     {
       FMI sharded; MultiGPUTimes times;
       const size_type input_bytes = as[k]->bwt.bytes() + bs[k]->bwt.bytes();
-      mergeMultiGPU(*as[k], *bs[k], device_lists[k], sharded, &times);
+      mergeMultiGPU(*as[k], *bs[k], device_lists[k], sharded, &times, MultiGPUMode::SequenceBlocks);
       CHECK(sharded.bwt.data.bytes == expected);
       CHECK(sharded.bwt.blockEnds() == merged.bwt.blockEnds());
       for(size_type c = 0; c < 6; c++) { CHECK(sharded.bwt.cumulative(c) == merged.bwt.cumulative(c)); }
@@ -167,12 +167,14 @@ int main(int argc, char** argv)
   // The same with the sliced frontier search: three contexts, each advancing a slice of the sorted frontier.
   {
     FMI sliced; MultiGPUTimes times;
-    mergeMultiGPU(a10, b10, std::vector<int>({0, 0, 0}), sliced, &times, true);
+    mergeMultiGPU(a10, b10, std::vector<int>({0, 0, 0}), sliced, &times, MultiGPUMode::Sliced);
     CHECK(sliced.bwt.data.bytes == expected);
     CHECK(sliced.bwt.blockEnds() == merged.bwt.blockEnds());
     for(size_type c = 0; c < 6; c++) { CHECK(sliced.bwt.cumulative(c) == merged.bwt.cumulative(c)); }
   }
-  // Partitioned records: contexts standing in for 1, 3 and 5 GPUs, each with windows transcoded from its share of the bytes.
+#endif
+  // Partitioned records (what several GPUs run by default): contexts standing in for 1, 3 and 5 GPUs, each with windows transcoded from its
+  // share of the bytes, the parts' step kernels reading each other's output buffers.
   {
     FMI* pa[3] = { &a11, &a12, &a13 }; FMI* pb[3] = { &b11, &b12, &b13 };
     const size_type counts[3] = { 1, 3, 5 };
@@ -180,7 +182,7 @@ int main(int argc, char** argv)
     {
       const size_type input_bytes = pa[k]->bwt.bytes() + pb[k]->bwt.bytes();
       FMI part; MultiGPUTimes times;
-      mergeMultiGPU(*pa[k], *pb[k], std::vector<int>(counts[k], 0), part, &times, false, true);
+      mergeMultiGPU(*pa[k], *pb[k], std::vector<int>(counts[k], 0), part, &times, (k == 2 ? MultiGPUMode::Auto : MultiGPUMode::Partitioned));
       CHECK(part.bwt.data.bytes == expected);
       CHECK(part.bwt.blockEnds() == merged.bwt.blockEnds());
       for(size_type c = 0; c < 6; c++) { CHECK(part.bwt.cumulative(c) == merged.bwt.cumulative(c)); }
@@ -188,7 +190,6 @@ int main(int argc, char** argv)
       CHECK(times.host_bytes_gpu0 <= input_bytes && times.total > 0);     // a part uploads the blocks of its windows, never more than the inputs
     }
   }
-#endif
 
   // Native file round trip.
   {

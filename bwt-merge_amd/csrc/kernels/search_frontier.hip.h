@@ -25,6 +25,8 @@
 // of ranks.
 
 constexpr int FR_BLOCK = 256;                  // elements (= threads) per block
+constexpr u32 PULL_SRC_SHIFT_ = 56;            // = PULL_SRC_SHIFT of kernels/partition.hip.h (included after this file)
+constexpr u64 PULL_PHYS_MASK_ = (1ull << PULL_SRC_SHIFT_) - 1;
 constexpr int FR_SEGS = 31;                    // segment-table entries staged per block (a power of two minus one: k_frontier_step searches them in five steps)
 
 struct FrontierView
@@ -46,6 +48,10 @@ struct FrontierView
   u32* bound_row;                              // this step's row of tile boundaries: [ntiles + 1], pre-set to ~0
   u64 step;
   u32 block_base;                              // first block of this launch (0 unless the step is launched in slices)
+  // PULL (the merge over partitioned records, kernels/partition.hip.h): the current frontier lies in the output buffers of up to 16 parts;
+  // seg_phys carries the part in its top byte and these device arrays (16 entries each) hold the parts' buffers as this GPU maps them
+  const uint2* const* src_lo; const unsigned short* const* src_hi;
+  u64 nseg_in;                                 // PULL: entries of the pulled table (seg_prefix / seg_phys / first_seg); the outputs' tables still have 5 * nb_max
 };
 
 __global__ void __launch_bounds__(BLOCK_THREADS) k_frontier_init(uint2* lo, unsigned short* hi, u64* seg_len, u64* seg_phys, u64 nb_max,
@@ -123,12 +129,16 @@ __device__ inline u64 ordinary_lf(const IndexView& X, u64 pos, u32& c, bool want
 
 // VIEW (instantiated only with -DBWTM_EXPERIMENTAL): the records come from the search view (160 positions per 64 bytes, bwtm_view.h); an
 // element whose view record has overflowed its exception slots reads the ordinary record of its position instead.
-template<int EMIT, bool HI, bool VIEW = false>
+// PULL: the elements are read from the parts' output buffers through a pulled segment table (k_pull_tables): one more LDS lookup per element.
+template<int EMIT, bool HI, bool VIEW = false, bool PULL = false>
 __global__ void __launch_bounds__(FR_BLOCK, (VIEW ? 6 : 8)) k_frontier_step(IndexView A, IndexView B, FrontierView f)
 {
   __shared__ u32 wave_cnt[FR_BLOCK / WAVE][6];
   __shared__ u64 s_prefix[FR_SEGS + 1], s_phys[FR_SEGS + 1];
-  const u64 nseg = 5 * f.nb_max;
+  __shared__ const uint2* s_src_lo[PULL ? 16 : 1];
+  __shared__ const unsigned short* s_src_hi[PULL ? 16 : 1];
+  const u64 nseg_out = 5 * f.nb_max;
+  const u64 nseg = (PULL ? f.nseg_in : nseg_out);                 // entries of the table the frontier is read through
   const u64 N = f.seg_prefix[nseg];
   const u32 bid = blockIdx.x + f.block_base;                      // a launch may cover a range of the step's blocks (one slice of the frontier)
   const u64 g0 = (u64)bid * FR_BLOCK;
@@ -138,7 +148,7 @@ __global__ void __launch_bounds__(FR_BLOCK, (VIEW ? 6 : 8)) k_frontier_step(Inde
   if(g0 >= N)
   {
     if(threadIdx.x < 5) { f.seg_len_next[(u64)threadIdx.x * f.nb_max + bid] = 0; f.seg_phys_next[(u64)threadIdx.x * f.nb_max + bid] = g0; }
-    if(bid == 0 && threadIdx.x == 5) { f.seg_len_next[nseg] = 0; }
+    if(bid == 0 && threadIdx.x == 5) { f.seg_len_next[nseg_out] = 0; }
     return;
   }
   // The block's elements live in a handful of segments: stage their table entries in LDS.
@@ -148,6 +158,11 @@ __global__ void __launch_bounds__(FR_BLOCK, (VIEW ? 6 : 8)) k_frontier_step(Inde
     u64 sidx = first_seg + threadIdx.x; if(sidx > nseg) { sidx = nseg; }
     s_prefix[threadIdx.x] = f.seg_prefix[sidx];
     s_phys[threadIdx.x] = f.seg_phys[sidx < nseg ? sidx : nseg - 1];
+  }
+  if(PULL && threadIdx.x >= 64 && threadIdx.x < 80)               // (another wave than the one that stages the table entries)
+  {
+    s_src_lo[threadIdx.x - 64] = f.src_lo[threadIdx.x - 64];
+    if(HI) { s_src_hi[threadIdx.x - 64] = f.src_hi[threadIdx.x - 64]; }
   }
   __syncthreads();
 
@@ -163,7 +178,7 @@ __global__ void __launch_bounds__(FR_BLOCK, (VIEW ? 6 : 8)) k_frontier_step(Inde
     u32 k = 0;
 #pragma unroll
     for(u32 step = 16; step != 0; step >>= 1) { if(s_prefix[k + step] <= g) { k += step; } }     // k + step <= 31 = FR_SEGS: inside the FR_SEGS + 1 staged entries
-    if(k < (u32)FR_SEGS) { phys = s_phys[k] + (g - s_prefix[k]); }
+    if(k < (u32)FR_SEGS) { phys = s_phys[k] + (g - s_prefix[k]); }      // (PULL: the part in the top byte survives the addition)
     else
     {
       // Rare: the element lies beyond the staged entries.  Binary search of seg_prefix (non-decreasing) for the segment
@@ -179,7 +194,14 @@ __global__ void __launch_bounds__(FR_BLOCK, (VIEW ? 6 : 8)) k_frontier_step(Inde
       const u64 sgm = lo_s;
       phys = f.seg_phys[sgm] + (g - f.seg_prefix[sgm]);
     }
-    uint2 l = f.lo[phys]; u32 h = (HI ? (u32)f.hi[phys] : 0u);
+    const uint2* lo_src = f.lo; const unsigned short* hi_src = f.hi;
+    if(PULL)
+    {
+      const u32 src = (u32)(phys >> PULL_SRC_SHIFT_);
+      phys &= PULL_PHYS_MASK_;
+      lo_src = s_src_lo[src]; if(HI) { hi_src = s_src_hi[src]; }
+    }
+    uint2 l = lo_src[phys]; u32 h = (HI ? (u32)hi_src[phys] : 0u);
     __builtin_amdgcn_sched_barrier(0);      // both loads are issued before either is used (the scheduler otherwise waits for the high bytes before it issues the other load: one more round trip per wave)
     i = (u64)l.x | ((u64)(h & 0xFF) << 32);
     r = (u64)l.y | ((u64)(h >> 8) << 32);
@@ -360,7 +382,7 @@ __global__ void __launch_bounds__(FR_BLOCK, (VIEW ? 6 : 8)) k_frontier_step(Inde
       f.seg_len_next[(u64)(kk - 1) * f.nb_max + bid] = tot;
       f.seg_phys_next[(u64)(kk - 1) * f.nb_max + bid] = g0 + base_k;
     }
-    if(bid == 0 && threadIdx.x == 5) { f.seg_len_next[nseg] = 0; }
+    if(bid == 0 && threadIdx.x == 5) { f.seg_len_next[nseg_out] = 0; }
   }
   if(mark_first) { atomicMin(&f.bound_row[tile_first], (u32)g); }
 }

@@ -76,66 +76,4 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_gather_dense(const DensePiece
   if(hi_in) { hi_in[j] = pc.hi[at]; }
 }
 
-// ---- the node phase over partitioned records.  A level's nodes (sp, count, r) live on the GPU that owns sp; with cuts at k-mer boundaries a
-// node never crosses a cut (the suffixes "x$" of a node x sort before every "x y...": a cut lies before or after all of them), so
-// k_range_step runs on a window unchanged.  Its children come out symbol-major, i.e. sorted by sp, class after class: the children of class
-// c that belong to GPU k are again a contiguous range, found here by binary search; a child that crosses a cut is reported (err).
-__global__ void __launch_bounds__(BLOCK_THREADS) k_node_cut_search(const u64* sp, const u64* cnt, const u64* class_first /* 6 */, const u64* cuts, u32 ncuts, u64* below, u32* err)
-{
-  const u32 t = threadIdx.x;
-  if(t >= 5 * ncuts) { return; }
-  const u32 c = t / ncuts, k = t - c * ncuts;
-  const u64 cut = cuts[k];
-  const u64 first = class_first[c], end = class_first[c + 1];
-  u64 lo_x = first, hi_x = end;
-  while(lo_x < hi_x)
-  {
-    const u64 mid = (lo_x + hi_x) >> 1;
-    if(sp[mid] < cut) { lo_x = mid + 1; } else { hi_x = mid; }
-  }
-  if(lo_x > first && cut != ~0ull && sp[lo_x - 1] + cnt[lo_x - 1] > cut) { atomicOr(err, 1u); }      // the node before the cut reaches across it
-  below[t] = lo_x - first;
-}
-
-struct NodePiece
-{
-  const u64* sp; const u64* r; const u64* cnt;     // the source GPU's children
-  u64 src_first, count, dst_first;
-};
-
-__global__ void __launch_bounds__(BLOCK_THREADS) k_gather_nodes(const NodePiece* pieces, u32 npieces, u64 n, u64* sp, u64* r, u64* cnt)
-{
-  const u64 j = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
-  if(j >= n) { return; }
-  u32 q = 0;
-  for(u32 k = 1; k < npieces; k++) { if(pieces[k].dst_first <= j) { q = k; } }
-  const NodePiece pc = pieces[q];
-  const u64 at = pc.src_first + (j - pc.dst_first);
-  sp[j] = pc.sp[at]; r[j] = pc.r[at]; cnt[j] = pc.cnt[at];
-}
-
-// ---- interleave of an output range from WINDOWS (bwtm_interleave_range on bwtm_x_index_window handles).  The super table of a slice only
-// serves the slice's own records, and a row only has to lie at or below the counts of every record that refers to it (header fields are
-// 25-bit offsets from it): the rows of the supers that BEGIN inside the range are the usual ones -- their positions lie inside the windows --
-// and the row of the super the range begins in, whose own beginning belongs to another GPU, is taken at the range's first chunk instead.
-// Rows of other supers stay zero: nothing of this slice refers to them.  (k_interleave_sup asks A and B at EVERY super of the output.)
-__global__ void __launch_bounds__(BLOCK_THREADS) k_interleave_sup_window(IndexView A, IndexView B, const u64* chunk_base, u64* sup, u64 nsup, const u64* super_boff,
-  u64 q_base, u64 q_end)
-{
-  const u64 s = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
-  if(s >= nsup) { return; }
-  u64 q = s << SUPER_REC_SHIFT;
-  bool have = (q >= q_base && q < q_end);
-  u64 b_off = 0;
-  if(have) { b_off = super_boff[s]; }
-  else if(s == (q_base >> SUPER_REC_SHIFT) && q_base < q_end) { q = q_base; b_off = chunk_base[q_base >> 6]; have = true; }      // q_base is the first record of a chunk
-  u64 ra[6] = {0, 0, 0, 0, 0, 0}, rb[6] = {0, 0, 0, 0, 0, 0};
-  if(have)
-  {
-    u64 a_off = (q << REC_SHIFT) - b_off;
-    if(a_off > A.n) { a_off = A.n; }
-    if(b_off > B.n) { b_off = B.n; }
-    index_ranks(A, a_off, ra); index_ranks(B, b_off, rb);
-  }
-  for(int c = 0; c < SUP_STRIDE; c++) { sup[s * SUP_STRIDE + c] = (c >= 1 && c < 6 ? ra[c] + rb[c] : 0); }
-}
+// (the node phase's routing kernels and the windows' interleave helper are product code since round 6: kernels/partition.hip.h)

@@ -41,7 +41,8 @@ enum
   BWTM_EINVAL = 1,              /* bad argument / malformed input */
   BWTM_ENODEV = 2,              /* no usable GPU, or HIP runtime failure */
   BWTM_ENOMEM = 3,              /* device or host allocation failed */
-  BWTM_EALPHABET = 4            /* fmi.cpp:338-342: cannot merge BWTs with different alphabets */
+  BWTM_EALPHABET = 4,           /* fmi.cpp:338-342: cannot merge BWTs with different alphabets */
+  BWTM_EPEER = 5                /* another part of a multi-GPU merge failed or did not arrive (bwtm_group_*, bwtm_part_*) */
 };
 
 typedef struct bwtm_context bwtm_context; /* one HIP device + the library's streams and memory pool */
@@ -314,6 +315,100 @@ int bwtm_slice_download_data(bwtm_slice* slice, uint8_t* out, uint64_t capacity)
 int bwtm_slice_download_samples(bwtm_slice* slice, uint64_t next_block_start, uint64_t* block_end, uint64_t* cum);
 /* Plain symbols of positions inside the slice. */
 int bwtm_slice_extract(bwtm_slice* slice, uint64_t first, uint64_t count, uint8_t* out);
+
+/* --- the merge over PARTITIONED records: one part per GPU, nothing replicated ---------------------------------
+   (the thread fan-out of fmi.cpp:351-358 and utils.cpp:189-218 as ranges of the merged ORDER instead of blocks of
+   b's sequences.)  A cut is a pair (cut_a[g], cut_b[g]) = (suffixes of a below w_g, suffixes of b below w_g) for a k-mer w_g; part g owns
+   a's records of [cut_a[g], cut_a[g + 1]], b's of [cut_b[g], cut_b[g + 1]) -- transcoded on its GPU from its own share of the native bytes --,
+   the frontier elements and trie nodes whose b coordinate lies in that range, and the bits and records of the output range
+   [cut_a[g] + cut_b[g], cut_a[g + 1] + cut_b[g + 1]) rounded to encoder segments.  Every rank query is local; the frontier's elements cross
+   between GPUs as loads of peer-mapped memory inside the step kernel, everything else is a few hundred bytes per LF step.
+
+   The parts of a merge (threads of one process, or one process per GPU) meet in a GROUP: a block of POSIX shared memory named by the caller
+   (a name that begins with '/', unique per group: e.g. "/bwtm-<launcher pid>-<port>"); part 0 creates it, the others attach, and the name
+   is unlinked as soon as all have.  A group serves any number of merges, one after the other.  Every part:
+
+       bwtm_group_create(name, g, parts, &group);                                   once
+       bwtm_partition_cuts_host(&a, &b, parts, 0, cut_a, cut_b);                     every part computes the same cuts (or receives them)
+       bwtm_part_create(group, &a_header, &b_header, cut_a, cut_b, &part);           binds the calling thread's context
+       for which in {0, 1}:  bwtm_part_window(part, which, &p0, &p1);  bwtm_window_blocks(&x, p0, p1, &b0, &b1, &first, before);
+                             bwtm_part_upload(part, which, x.data + 64 b0, bytes of the blocks, first, before, 0);
+       bwtm_part_search(part);                                                       collective
+       bwtm_part_finish(part, &slice, &byte_offset, &total_bytes, &next_start);      collective; then bwtm_slice_download_*(slice, ...)
+       bwtm_part_free(part);
+
+   The concatenation of the parts' slices is bit-identical to bwtm_merge() of the whole inputs.  When a part fails, the others return
+   BWTM_EPEER from their next collective step instead of waiting for it (and every wait has a deadline: BWTM_GROUP_TIMEOUT seconds, 300). */
+
+#define BWTM_MAX_PARTS 16
+typedef struct bwtm_group bwtm_group;
+typedef struct bwtm_part bwtm_part;
+
+int bwtm_group_create(const char* name, int part, int parts, bwtm_group** out);     /* collective; name may be NULL when parts == 1 */
+void bwtm_group_free(bwtm_group* group);
+int bwtm_group_part(const bwtm_group* group);
+int bwtm_group_parts(const bwtm_group* group);
+int bwtm_group_barrier(bwtm_group* group);
+/* all[h * nbytes ..] = part h's `mine` (host memory, any size; collective). */
+int bwtm_group_allgather(bwtm_group* group, const void* mine, uint64_t nbytes, void* all);
+void bwtm_group_abort(bwtm_group* group);                                           /* the caller gives up: wakes the others with BWTM_EPEER */
+
+/* A host-resident input as the reference's loaded FMI holds it: the native bytes and the samples of BWT::build (bwt.cpp:476-512) as plain
+   arrays, cum[c][k] (row-major, blocks + 1 columns) = occurrences of symbol c before block k. */
+typedef struct
+{
+  const uint8_t* data; uint64_t nbytes, blocks;
+  uint64_t sequences, bases;
+  uint64_t C[BWTM_SIGMA + 1];
+  const uint64_t* cum;                       /* [6][blocks + 1] */
+} bwtm_host_index;
+typedef struct { uint64_t bases, sequences; uint64_t C[BWTM_SIGMA + 1]; } bwtm_index_header;
+
+/* parts - 1 cuts at k-mer boundaries (kmer = 0: 4 for up to 8 parts, else 5) that balance the parts' shares of a's + b's positions:
+   insertion points by backward search on the host, sp(c w) = C[c] + rank_c(sp(w)) (utils.h:335-355, BWT::rank bwt.cpp:318-341).  cut_a,
+   cut_b: parts + 1 entries each (cut[0] = 0, cut[parts] = bases).  Pure host arithmetic; every part gets the same answer. */
+int bwtm_partition_cuts_host(const bwtm_host_index* a, const bwtm_host_index* b, int parts, int kmer, uint64_t* cut_a, uint64_t* cut_b);
+/* The 64-byte blocks [*block_first, *block_end) of x's stream whose records cover the positions [pos_first, pos_last], the position the first
+   of them begins at and the symbol counts before it (what bwtm_index_upload_window / bwtm_part_upload want).  Pure host arithmetic. */
+int bwtm_window_blocks(const bwtm_host_index* x, uint64_t pos_first, uint64_t pos_last, uint64_t* block_first, uint64_t* block_end,
+                       uint64_t* first_position, uint64_t counts_before[6]);
+
+/* A WINDOW of an index, transcoded from its own share of the native bytes: `data` = whole 64-byte blocks of the stream (host memory; device
+   memory read in place when on_device != 0: 16-byte aligned, readable 16 bytes past the end), first_position = the position the first
+   block begins at, counts_before[c] = occurrences of c before it, bases / sequences / C = the header of the WHOLE index.  The handle serves
+   the records that lie wholly inside the bytes, addressed by their absolute numbers; only bwtm_ra_create_range, bwtm_interleave_range (with a
+   rank array finalized for a range the windows cover) and the bwtm_part_* calls take it. */
+int bwtm_index_upload_window(const uint8_t* data, uint64_t nbytes, uint64_t first_position, const uint64_t counts_before[6],
+                             uint64_t bases, uint64_t sequences, const uint64_t C[BWTM_SIGMA + 1], int on_device, bwtm_index** out);
+uint64_t bwtm_index_record_bytes(const bwtm_index* index);        /* bytes of records the handle holds (a window: its share) */
+/* The rank array of one part: the bits of the output positions [pos_first, pos_last) plus one 65 536-position tile on either side. */
+int bwtm_ra_create_range(const bwtm_index* a, const bwtm_index* b, uint64_t pos_first, uint64_t pos_last, bwtm_ra** out);
+uint64_t bwtm_ra_bytes(const bwtm_ra* ra);                         /* bytes of bitvector the handle holds */
+
+typedef struct
+{
+  uint64_t steps, node_levels;               /* LF steps on elements / levels on trie nodes */
+  uint64_t elements, largest;                /* elements this part advanced in all steps / in its largest step */
+  uint64_t pulled_bytes;                     /* bytes of elements and table entries its step kernels read from the parts' output buffers */
+  uint64_t boundary_bytes;                   /* bytes of boundary bits per pair of neighbouring parts */
+  uint64_t record_bytes, bitvector_bytes;    /* what the part holds */
+  double ms_search, ms_search_wait, ms_finish;   /* wall time of the two collective calls; of the search, the time spent waiting for peers */
+} bwtm_part_info;
+
+int bwtm_part_create(bwtm_group* group, const bwtm_index_header* a, const bwtm_index_header* b,
+                     const uint64_t* cut_a, const uint64_t* cut_b, bwtm_part** out);
+void bwtm_part_free(bwtm_part* part);
+/* The positions [*pos_first, *pos_last] of input `which` (0 = a, 1 = b) this part's window must cover: its range and two encoder segments on either side. */
+int bwtm_part_window(const bwtm_part* part, int which, uint64_t* pos_first, uint64_t* pos_last);
+int bwtm_part_upload(bwtm_part* part, int which, const uint8_t* data, uint64_t nbytes, uint64_t first_position,
+                     const uint64_t counts_before[6], int on_device);
+/* buildRA (fmi.cpp:272-334) for the part's range: node levels and LF steps in lock step with the other parts. */
+int bwtm_part_search(bwtm_part* part);
+/* The second half: boundary bits, range counts, bwtm_ra_finalize_range, bwtm_interleave_range, the encoder's carries, bwtm_slice_encode.
+   *slice = the part's encoded slice (the caller frees it), *byte_offset = where its bytes begin in the merged stream, *total_bytes = the
+   stream's size, *next_block_start = what bwtm_slice_download_samples wants.  The part's windows and rank array are released. */
+int bwtm_part_finish(bwtm_part* part, bwtm_slice** slice, uint64_t* byte_offset, uint64_t* total_bytes, uint64_t* next_block_start);
+int bwtm_part_stats(const bwtm_part* part, bwtm_part_info* info);
 
 /* --- ingest: reads -> index ---------------------------------------------------
    The reference merges BWTs that other tools built (RopeBWT / SGA, README.md:5,20; PlainData::read, formats.cpp:133-161,

@@ -123,16 +123,20 @@ def test_cli_one_thread_per_gpu(bwtm, oracle, tmp_path):
         write_plain(names[-1], oracle.FMI.from_text(t))
     exe = os.path.join(HOST, "bwt_merge")
     outs = {}
-    # "rounds": the sharded upload in three rounds of pieces (what inputs of 128 MiB per GPU and more take by themselves)
-    for label, g, env in (("one", "0", {}), ("three", "0,0,0", {}), ("four", "0,0,0,0", {}), ("rounds", "0,0,0", {"BWTM_SHARDED_UPLOAD_ROUNDS": "3"})):
-        out = subprocess.run([exe, "-g", g, "-i", "plain_default", names[0], names[1], names[2], str(tmp_path / (label + ".native"))],
+    # several GPUs: partitioned records by default, sequence blocks with -B; "rounds": the sharded upload of the sequence-block path in three
+    # rounds of pieces (what inputs of 128 MiB per GPU and more take by themselves)
+    for label, g, extra, env in (("one", "0", [], {}), ("three", "0,0,0", [], {}), ("four", "0,0,0,0", [], {}), ("five_strict", "0,0,0,0,0", ["-P"], {}),
+                                 ("blocks3", "0,0,0", ["-B"], {}), ("blocks4", "0,0,0,0", ["-B"], {}), ("rounds", "0,0,0", ["-B"], {"BWTM_SHARDED_UPLOAD_ROUNDS": "3"})):
+        out = subprocess.run([exe, "-g", g] + extra + ["-i", "plain_default", names[0], names[1], names[2], str(tmp_path / (label + ".native"))],
                              capture_output=True, text=True, env=dict(os.environ, **env))
         assert out.returncode == 0, out.stdout + out.stderr
         assert out.stdout.count("BWTs merged in ") == 2
         if g != "0":
-            assert out.stderr.count("mergeMultiGPU(): %d GPUs: upload " % len(g.split(","))) == 2, out.stderr[-1500:]     # the phases of both sharded merges
+            mode = "sequence blocks" if "-B" in extra else "partitioned records"
+            assert out.stderr.count("mergeMultiGPU(): %d GPUs (%s): upload " % (len(g.split(",")), mode)) == 2, out.stderr[-1500:]     # the phases of both merges
         outs[label] = np.fromfile(tmp_path / (label + ".native"), dtype=np.uint8)
-    assert np.array_equal(outs["one"], outs["three"]) and np.array_equal(outs["one"], outs["four"]) and np.array_equal(outs["one"], outs["rounds"])
+    for label in outs:
+        assert np.array_equal(outs["one"], outs[label]), label
     direct = oracle.FMI.from_text(np.concatenate(sets))
     assert np.array_equal(outs["three"][32:32 + direct.nbytes], direct.data)           # header (24 B) + byte count (8 B), then BWT::data
 
