@@ -24,6 +24,7 @@ import json
 import os
 import sys
 import time
+import types
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -70,6 +71,13 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (process group, caller-owned bitvector, reduce-scatter by output range, output slices) even with one rank: "
                          "a smoke test of that path on a 1-GPU box")
+    ap.add_argument("--search", choices=("auto", "blocks", "partitioned"), default="auto",
+                    help="several ranks: `partitioned` = the merge over partitioned records (one part per rank: windows from byte shares, the frontier's "
+                         "elements read from the peers' buffers, no collective library; DESIGN.md section 6.3), `blocks` = sequence blocks of input2 per rank, "
+                         "replicated records, RCCL reduce-scatter of the bitvector; auto = partitioned for two ranks and more, blocks for --force-dist on one")
+    ap.add_argument("--same-device", action="store_true",
+                    help="all ranks use GPU 0 (a one-GPU box): the ranks are still processes of their own that map each other's buffers through HIP IPC; "
+                         "the process group is gloo (RCCL refuses two ranks on one device); --search partitioned only")
     ap.add_argument("--target", choices=("auto", "on", "off"), default="auto",
                     help="after the configured workload, measure the north star's target size (two sets of --target-reads reads on ONE GPU) and add it to "
                          "the line as `target`; auto = when this is the default single-GPU config-2 run and the device has the memory for it")
@@ -86,7 +94,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: this process starts the N ranks itself (it has not touched the GPU) and
         # relays rank 0's JSON line.
-        sys.exit(launch_ranks(args.gpus))
+        sys.exit(launch_ranks(args.gpus, args.same_device))
 
     # stdout carries the ONE JSON line and nothing else: native libraries (RCCL prints a version banner through C stdio) are sent
     # to stderr by pointing file descriptor 1 there; the line itself goes to the saved descriptor.
@@ -105,16 +113,25 @@ def main():
     pkg = _pkg.load()
     from bwt_merge_amd import synth
 
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     pkg.init(local_rank)
     dist = None
     sharded = world > 1 or args.force_dist
+    args.partitioned = sharded and (args.search == "partitioned" or (args.search == "auto" and world > 1))
+    if args.same_device and world > 1 and not args.partitioned:
+        raise SystemExit("--same-device needs --search partitioned (RCCL refuses two ranks on one device)")
     if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.same_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
+    args.coll_dev = (torch.device("cpu") if args.same_device else dev)          # where the bench's own small collectives (timing, flags) live
 
     for kv in args.tune:
         key, _, value = kv.partition("=")
@@ -149,6 +166,13 @@ def main():
     if rank == 0:
         out["process_seconds"] = round(time.time() - T_START, 1)       # this process from its start to this line (the driver's clock sees launch + this)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+        # the numbers a reader of a truncated log needs, as the LAST line on stderr (the JSON line above is ~16 KB)
+        tg = out.get("target") or {}
+        summary = {"value": out.get("value"), "ms_per_step": out.get("ms_per_step"), "host_to_host_value": out.get("host_to_host_value"), "n_gpus": out.get("n_gpus"),
+                   "search": (out.get("config") or {}).get("search"), "roofline_frac": (out.get("roofline") or {}).get("frac"), "verified": out.get("verified"),
+                   "target_value": tg.get("value"), "target_ms_per_step": tg.get("ms_per_step"), "target_host_to_host_value": tg.get("host_to_host_value"), "target_verified": tg.get("verified")}
+        sys.stderr.flush()
+        os.write(2, ("[bench] summary " + json.dumps(summary) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -212,26 +236,62 @@ def measure(env, args):
     reads_per_set = [args.reads_a or args.reads] + [args.reads] * (nsets - 1)
     seeds = [1001 + k for k in range(nsets)]
     host_in, dev_in, meta = [], [], []
-    for k, seed in enumerate(seeds):
-        def progress(done, total, k=k):
-            if rank == 0 and (done == total or (done // args.leaf_reads) % 64 == 0):
-                log("input%d: %d / %d reads (%.0f s)" % (k + 1, done, total, time.time() - t_gen))
-        ix = synth.build_index(pkg, seed, reads_per_set[k], args.readlen, leaf_reads=args.leaf_reads, device=dev, progress=progress,
-                               workload=args.workload, native=not args.torch_leaves, **wargs)
-        ix.encode()
-        hb = pkg.HostBuffer(ix.nbytes)
-        ix.download_into(hb.array)
-        meta.append({"sequences": ix.sequences, "bases": ix.bases, "nbytes": ix.nbytes, "C": ix.C})
-        ix.free()
-        host_in.append(hb)
+
+    def build_inputs():
+        for k, seed in enumerate(seeds):
+            def progress(done, total, k=k):
+                if rank == 0 and (done == total or (done // args.leaf_reads) % 64 == 0):
+                    log("input%d: %d / %d reads (%.0f s)" % (k + 1, done, total, time.time() - t_gen))
+            ix = synth.build_index(pkg, seed, reads_per_set[k], args.readlen, leaf_reads=args.leaf_reads, device=dev, progress=progress,
+                                   workload=args.workload, native=not args.torch_leaves, **wargs)
+            ix.encode()
+            hb = pkg.HostBuffer(ix.nbytes)
+            ix.download_into(hb.array)
+            meta.append({"sequences": ix.sequences, "bases": ix.bases, "nbytes": ix.nbytes, "C": ix.C})
+            if args.partitioned:
+                meta[-1]["cum"] = ix.samples()[1]                  # the samples of BWT::build: what the reference's loaded FMI holds next to the bytes
+            ix.free()
+            host_in.append(hb)
+        torch.cuda.empty_cache()
+        if args.same_device:
+            pkg.trim()
+
+    if args.same_device and world > 1:
+        for r in range(world):                                  # ranks that share one GPU build their inputs one after the other
+            if r == rank:
+                build_inputs()
+            dist.barrier()
+    else:
+        build_inputs()
     torch.cuda.empty_cache()
     if not args.keep_pool:
         pkg.trim()
-    for hb in host_in:
-        t = torch.empty(hb.nbytes + 16, dtype=torch.uint8, device=dev)       # 16 readable bytes after the stream (borrowed form)
-        t[: hb.nbytes].copy_(torch.from_numpy(hb.array))
-        t[hb.nbytes:].zero_()
-        dev_in.append(t)
+    part_env = None
+    if args.partitioned:
+        # One part per rank.  The group lives as long as the process; the HBM-resident inputs of a part are its byte SHARES (the 64-byte blocks
+        # that cover its windows): no rank holds a whole input on its device.  The cuts are computed again inside every timed step.
+        from bwt_merge_amd import partitioned as bwtm_parts
+        if nsets != 2:
+            raise SystemExit("--search partitioned measures single merges (--chain 2)")
+        gname = ("/bwtm-bench-" + os.environ.get("BWTM_GROUP_TAG", str(os.getpid()))) if world > 1 else None
+        group = pkg.Group(gname, rank, world)
+        hidx = [pkg.host_index(host_in[k].array, meta[k]["cum"], meta[k]["sequences"], meta[k]["bases"]) for k in range(2)]
+        cuts0 = pkg.partition_cuts_host(hidx[0], hidx[1], world)
+        probe = pkg.Part(group, hidx[0], hidx[1], cuts0[0], cuts0[1])
+        share_meta = [probe.share(k, hidx[k]) for k in range(2)]
+        probe.free()
+        for k, (off, count, fp, before) in enumerate(share_meta):
+            t = torch.empty(count + 16, dtype=torch.uint8, device=dev)
+            t[:count].copy_(torch.from_numpy(host_in[k].array[off: off + count]))
+            t[count:].zero_()
+            dev_in.append(t)
+        part_env = types.SimpleNamespace(mod=bwtm_parts, group=group, hidx=hidx, cuts0=cuts0, share_meta=share_meta, stats=[], cuts_ms=[], transcode_ms=[])
+    else:
+        for hb in host_in:
+            t = torch.empty(hb.nbytes + 16, dtype=torch.uint8, device=dev)       # 16 readable bytes after the stream (borrowed form)
+            t[: hb.nbytes].copy_(torch.from_numpy(hb.array))
+            t[hb.nbytes:].zero_()
+            dev_in.append(t)
     torch.cuda.synchronize()
     n_a, n_b = meta[0]["bases"], meta[1]["bases"]
     m_a, m_b = meta[0]["sequences"], meta[1]["sequences"]
@@ -263,7 +323,29 @@ def measure(env, args):
     shard_times = {}                                 # phases of the sharded merges of this rank (N > 1 or --force-dist)
 
     # ---------------------------------------------------------------- one step
+    def step_partitioned(keep=False):
+        # the whole merge as this rank's part: cuts (host rank queries on the inputs' samples), windows transcoded from the resident byte shares,
+        # the search in lock step with the other ranks, the second half
+        tc = time.perf_counter()
+        cuts = pkg.partition_cuts_host(part_env.hidx[0], part_env.hidx[1], world)
+        part_env.cuts_ms.append((time.perf_counter() - tc) * 1e3)
+        if cuts != part_env.cuts0:
+            raise RuntimeError("the cuts changed between two steps")
+        shares = []
+        for k in range(2):
+            off, count, fp, before = part_env.share_meta[k]
+            shares.append((dev_in[k].data_ptr(), count, fp, before))
+        S, st = part_env.mod.merge_part(part_env.group, part_env.hidx[0], part_env.hidx[1], cuts=cuts, shares=shares)
+        pkg.synchronize()
+        part_env.stats.append(st)
+        if keep:
+            return S
+        S.free()
+        return None
+
     def step(keep=False):
+        if args.partitioned:
+            return step_partitioned(keep)
         A, B = load_inputs()
         if not sharded:
             for k in range(2, nsets):            # a chain: the running result is a device rank structure, the next increment is loaded
@@ -283,6 +365,8 @@ def measure(env, args):
         step()
     pkg.device_bytes_peak(reset=True)
     shard_times.clear()
+    if part_env is not None:
+        part_env.stats.clear(); part_env.cuts_ms.clear()
     # Inside the timed region only the dominant kernel's launches are bracketed by HIP events (two event records per launch cost
     # microseconds each on the stream, and a search is ~330 launches); the per-kernel table comes from one more, untimed step.
     pkg.profile_only(None if args.profile_all else "frontier_step,lf_walk")
@@ -301,6 +385,17 @@ def measure(env, args):
         # rank 0's view, per merge of the timed region; the maximum over ranks of the whole step is `ms_per_step`
         shard_phases = {k: round(shard_times[k] / shard_times["merges"], 2) for k in ("ms_search", "ms_exchange", "ms_interleave_encode")}
         shard_phases["exchange_bytes_per_gpu"] = int(shard_times["exchange_bytes_per_gpu"])
+    part_phases = None
+    timed_stats = list(part_env.stats) if part_env is not None else []
+    if timed_stats:
+        n = len(timed_stats)
+        part_phases = {"ms_cuts_on_the_host": round(sum(part_env.cuts_ms) / max(1, len(part_env.cuts_ms)), 3),
+                       "ms_search": round(sum(x["ms_search"] for x in timed_stats) / n, 2), "ms_search_waiting_for_peers": round(sum(x["ms_search_wait"] for x in timed_stats) / n, 2),
+                       "ms_finish": round(sum(x["ms_finish"] for x in timed_stats) / n, 2),
+                       "lf_steps": int(timed_stats[-1]["steps"]), "node_levels": int(timed_stats[-1]["node_levels"]),
+                       "elements_advanced": int(timed_stats[-1]["elements"]), "largest_frontier": int(timed_stats[-1]["largest"]),
+                       "bytes_read_from_the_parts_buffers_per_merge": int(timed_stats[-1]["pulled_bytes"]), "boundary_bytes_per_pair": int(timed_stats[-1]["boundary_bytes"]),
+                       "record_bytes_held": int(timed_stats[-1]["record_bytes"]), "bitvector_bytes_held": int(timed_stats[-1]["bitvector_bytes"])}
     prof_all, prof_all_steps = prof, max(1, args.steps)
     if not args.profile_all:
         if last is not None and (n_a + n_b) > 4e10:
@@ -315,7 +410,7 @@ def measure(env, args):
     pkg.profile_enable(False)
     peak_device = pkg.device_bytes_peak() + sum(t.numel() for t in dev_in)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=args.coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     sec_per_step = elapsed / max(1, args.steps)
@@ -334,6 +429,9 @@ def measure(env, args):
     node_levels = (prof_all.get("range_step", (0.0, 0))[1] / prof_all_steps / max(1, nsets - 1)) if dom == "frontier_step" else 0
     if nsets == 2 and dom == "frontier_step":
         units_per_search = max(0.0, units_per_search - node_levels * (seq_last - seq_first + 1))
+    if timed_stats:
+        units_per_search = float(timed_stats[-1]["elements"])           # what THIS rank's step kernels advanced (its share of every step)
+        node_levels = float(timed_stats[-1]["node_levels"])
     launches_per_search = dom_launches / searches if dom_launches else 0
     avg_launch_s = (dom_ms / 1e3 / dom_launches) if dom_launches else float("nan")
     units_per_launch = units_per_search / launches_per_search if launches_per_search else 0
@@ -391,10 +489,10 @@ def measure(env, args):
     # whole-job algorithmic bytes W = 176 n_B + |A| + |B| + 2 |Out|
     out_bytes = last.total_nbytes if last is not None else 0
     W = 176 * searched_bases + sum(mt["nbytes"] for mt in meta) + 2 * out_bytes
-    job = {"algorithmic_bytes": W, "achieved_GBs": round(W / sec_per_step / 1e9, 1), "frac": round(W / sec_per_step / 1e9 / HBM_PEAK_GBS, 4),
+    job = {"algorithmic_bytes": W, "algorithmic_GBs": round(W / sec_per_step / 1e9, 1), "ratio_of_survey_W_rate_to_peak": round(W / sec_per_step / 1e9 / HBM_PEAK_GBS, 4),
            "note": "SURVEY 8(d)'s W charges every LF step its own two 64-byte blocks; the sorted frontier shares records between neighbouring elements, so the "
-                   "bytes really moved are ~0.73 W for the search (roofline.traffic_over_algorithmic) and this fraction can pass 1.0: it is the contract's "
-                   "algorithmic figure, not a bandwidth measurement -- roofline.frac is"}
+                   "bytes really moved are ~0.73 W for the search (roofline.traffic_over_algorithmic) and this ratio can pass 1.0: it is the contract's "
+                   "algorithmic figure, not a bandwidth measurement and not an upper bound for this algorithm -- roofline.frac is the measured one"}
 
     # ---------------------------------------------------------------- verification at full size
     verified, checks = None, {}
@@ -403,8 +501,20 @@ def measure(env, args):
         log("full-size verification: %s %s" % (verified, checks))
     if sharded and last is not None and not args.no_verify:
         # every rank: its slice of the sharded result == the same byte range of the result it computes alone
-        ok = verify_slice(pkg, np, last, load_inputs)
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+        if args.partitioned:
+            # (from the host copies: a part's resident inputs are its byte shares; ranks that share one GPU take turns)
+            def load_full():
+                return tuple(pkg.Index.upload(host_in[k].array, meta[k]["sequences"], meta[k]["bases"]) for k in range(2))
+            ok = True
+            for r in range(world if args.same_device else 1):
+                if not args.same_device or r == rank:
+                    ok = verify_slice(pkg, np, last, load_full)
+                    pkg.trim()
+                if args.same_device:
+                    dist.barrier()
+        else:
+            ok = verify_slice(pkg, np, last, load_inputs)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=args.coll_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         verified = bool(flag.item() == 1)
         checks = {"every_slice_equals_the_single_gpu_result": verified, "slices": world}
@@ -430,7 +540,9 @@ def measure(env, args):
     torch.cuda.empty_cache()
     if rank == 0 and not sharded and not args.no_host and nsets == 2:
         host = host_to_host(pkg, np, torch, dev, host_in, meta, args)
-    if sharded and not args.no_host and nsets == 2:
+    if sharded and not args.no_host and nsets == 2 and args.partitioned:
+        host = host_to_host_partitioned(pkg, np, torch, args, host_in, meta, rank, world, dist, part_env)      # collective
+    elif sharded and not args.no_host and nsets == 2:
         host = host_to_host_sharded(pkg, np, torch, dev, host_in, meta, args, rank, world, dist)       # collective: every rank takes part
     if rank == 0 and not sharded and not args.no_host and nsets > 2:
         host = host_chain(pkg, np, torch, host_in, meta, args, chain_tail)
@@ -443,9 +555,12 @@ def measure(env, args):
 
     rccl_ranks = None
     if dist is not None:
-        one_t = torch.ones(1, dtype=torch.int64, device=dev)
+        one_t = torch.ones(1, dtype=torch.int64, device=args.coll_dev)
         dist.all_reduce(one_t, op=dist.ReduceOp.SUM)                       # counted by the collective itself, not read from the environment
         rccl_ranks = int(one_t.item())
+    if part_env is not None:
+        part_env.group.barrier()
+        part_env.group.free()
     for hb in host_in:
         hb.free()
     host_in.clear()
@@ -455,8 +570,9 @@ def measure(env, args):
     wname = {"iid": "sigma=6", "genome": "reads from a shared random genome, %dx coverage, %d%% substitutions" % (args.coverage, args.error_percent),
              "mixed": "sigma=6, 100 / 150 bp mixed"}[args.workload]
     return {
-        "metric": "merged Gbases/sec (input1+input2), bit-exact native BWT",
-        "value": round(value, 4), "value_basis": "hbm_resident", "host_to_host_value": (host or {}).get("value"), "unit": "Gbases/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
+        "metric": "merged Gbases/sec (input1+input2), bit-exact native BWT; value = inputs and result resident in HBM, host_to_host_value = SURVEY 8(d)'s T (page-locked host to page-locked host)",
+        "value": round(value, 4), "value_basis": "hbm_resident", "host_to_host_value": (host or {}).get("value"), "unit": "Gbases/s", "n_gpus": world,
+        "rccl_ranks": (None if args.same_device else rccl_ranks), "process_group": (None if dist is None else ("gloo" if args.same_device else "nccl")), "ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(sec_per_step * 1e3, 2), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "%s Gbase synthetic %d bp read sets (%s)%s, native format, inputs resident in HBM" %
@@ -464,9 +580,13 @@ def measure(env, args):
                     ", chained merge in command-line order (value = bases through all merges / time)" if nsets > 2 else ""),
                    "reads_per_set": args.reads, "reads_input1": reads_per_set[0], "read_length": args.readlen,
                    "bases": [mt["bases"] for mt in meta], "native_bytes": [mt["nbytes"] for mt in meta] + [out_bytes],
-                   "parallelism": "sequence blocks of input2 sharded over %d GPU(s)%s" %
-                   (world, ", RCCL reduce-scatter of the rank-array bitvector by output range, result sharded by output range" if sharded else "")},
-        "sharded_phases_rank0": shard_phases,
+                   "parallelism": (("partitioned records: one part per rank (%d), windows transcoded from the rank's byte shares, the frontier's elements read from the "
+                                    "peers' output buffers inside the step kernel (%s), no collective library; result sharded by output range" %
+                                    (world, "HIP IPC between the ranks' processes, all on GPU 0" if args.same_device else "peer-mapped memory over xGMI")) if args.partitioned else
+                                   "sequence blocks of input2 sharded over %d GPU(s)%s" %
+                                   (world, ", RCCL reduce-scatter of the rank-array bitvector by output range, result sharded by output range" if sharded else "")),
+                   "search": ("partitioned" if args.partitioned else ("blocks" if sharded else "single")), "same_device": bool(args.same_device)},
+        "sharded_phases_rank0": shard_phases, "partitioned_phases_rank0": part_phases,
         "roofline": roofline, "job_roofline": job, "kernel_ms_per_step": kernel_ms,
         "host_to_host": host, "peak_device_bytes": peak_device,
         "cpu_baseline": cpu, "verified": verified, "verification": checks,
@@ -535,7 +655,7 @@ def stored_traffic(dom, args, world, nsets, launches_per_search, units_per_searc
     return None, why
 
 
-def launch_ranks(world):
+def launch_ranks(world, same_device=False):
     """One fresh child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, the same command line),
     started before this process has made any GPU call -- a process that has initialised the GPU must never be replaced or
     forked on this pool.  Rank 0's stdout (the JSON line) is passed through; the exit code is non-zero when any rank fails."""
@@ -544,8 +664,9 @@ def launch_ranks(world):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if same_device else r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   BWTM_GROUP_TAG="%d-%d" % (os.getpid(), port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=(None if r == 0 else subprocess.DEVNULL)))
     rc = 0
@@ -769,6 +890,45 @@ def host_to_host_sharded(pkg, np, torch, dev, host_in, meta, args, rank, world, 
     return {"value": round(merged / 1e9 / sec, 4), "unit": "Gbases/s", "ms_per_step": round(sec * 1e3, 2), "ms_each": [round(x * 1e3, 1) for x in times],
             "phases_ms": phases, "includes": "sharded H2D of both native inputs (1 / N per link) + all-gather, transcode, sharded search, reduce-scatter, "
             "interleave + encode of the rank's output slice, D2H of the slice; without the samples",
+            "bytes": {"h2d_this_rank": int(from_host), "h2d_all_inputs": meta[0]["nbytes"] + meta[1]["nbytes"], "d2h_all_ranks": int(total)}}
+
+
+def host_to_host_partitioned(pkg, np, torch, args, host_in, meta, rank, world, dist, part_env):
+    """SURVEY 8(d)'s T over partitioned records: page-locked inputs -> this rank's byte range of the native result in page-locked memory.  Every
+    rank uploads only the 64-byte blocks that cover its windows (its PCIe link carries 1 / N of the inputs and two margins), transcodes them, searches
+    in lock step with the others, encodes its range of the output and downloads it.  Data only, like host_to_host_sharded."""
+    torch.cuda.empty_cache(); pkg.trim()
+    out_buf, times, phases, from_host, total = None, [], None, 0, 0
+    for it in range(2 + max(1, args.host_steps)):
+        pkg.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        cuts = pkg.partition_cuts_host(part_env.hidx[0], part_env.hidx[1], world)
+        S, st = part_env.mod.merge_part(part_env.group, part_env.hidx[0], part_env.hidx[1], cuts=cuts)
+        t1 = time.perf_counter()
+        if out_buf is None or out_buf.nbytes < S.nbytes:
+            if out_buf is not None:
+                out_buf.free()
+            out_buf = pkg.HostBuffer(S.nbytes + (1 << 20))
+        S.data_into(out_buf.array)
+        total = S.total_nbytes
+        S.free()
+        pkg.synchronize(); dist.barrier()
+        t2 = time.perf_counter()
+        t = torch.tensor([t2 - t0, t1 - t0, t2 - t1], dtype=torch.float64, device=args.coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if it >= 2:
+            times.append(float(t[0].item()))
+            phases = {"ms_cuts_upload_transcode_search_encode": round(float(t[1].item()) * 1e3, 2), "ms_download": round(float(t[2].item()) * 1e3, 2)}
+        from_host = sum(part_env.share_meta[k][1] for k in range(2))
+        if rank == 0:
+            log("host to host over partitioned records on %d ranks, round %d: %.1f ms" % (world, it, float(t[0].item()) * 1e3))
+    if out_buf is not None:
+        out_buf.free()
+    merged = meta[0]["bases"] + meta[1]["bases"]
+    sec = sum(times) / len(times)
+    return {"value": round(merged / 1e9 / sec, 4), "unit": "Gbases/s", "ms_per_step": round(sec * 1e3, 2), "ms_each": [round(x * 1e3, 1) for x in times],
+            "phases_ms": phases, "includes": "cuts on the host, H2D of the rank's byte shares of both inputs, transcode of its windows, the partitioned search, "
+            "interleave + encode of the rank's output range, D2H of the slice; without the samples",
             "bytes": {"h2d_this_rank": int(from_host), "h2d_all_inputs": meta[0]["nbytes"] + meta[1]["nbytes"], "d2h_all_ranks": int(total)}}
 
 

@@ -46,6 +46,7 @@ struct GroupShared
   std::atomic<u32> attached;
   std::atomic<u32> abort_flag;
   std::atomic<u64> seq[PART_MAX];                  // barriers passed by every part
+  std::atomic<u64> ticket;                         // BWTM_GROUP_SERIAL: compute sections run one part at a time, in the order (section, part)
   GroupArena arena[PART_MAX];
   alignas(64) u8 blob[2][PART_MAX][GROUP_BLOB];
 };
@@ -73,6 +74,9 @@ struct bwtm_group
   // this part's arena (hipMalloc: the pool's mapped blocks cannot be exported), kept across merges
   void* arena = nullptr; u64 arena_bytes = 0; int arena_device = -1;
   double wait_seconds = 0;                         // time spent waiting for peers (statistics)
+  // BWTM_GROUP_SERIAL=1 (measurements on ONE GPU whose contexts stand in for GPUs): every compute section of a part -- the kernels between two
+  // exchanges -- runs alone on the device, so that a part's kernel times are what its own GPU would need (tools/parts_scale.py)
+  bool serial = false; u64 sections = 0;
 };
 
 namespace
@@ -130,6 +134,31 @@ int group_allgather(bwtm_group* g, const void* mine, u64 nbytes, void* all)
 }
 
 void group_abort(bwtm_group* g) { if(g && g->sh) { g->sh->abort_flag.store(1); } }
+
+// A compute section of a part: in serial mode it begins when all parts' sections before it (in the order (section, part)) have finished on
+// the device, and its end drains the part's stream.  Every part must pass through the same sequence of sections.
+struct Turn
+{
+  bwtm_group* g; int rc = BWTM_OK; bool held = false;
+  explicit Turn(bwtm_group* g_) : g(g_)
+  {
+    if(!g->serial || g->parts == 1) { return; }
+    const u64 mine = g->sections * (u64)g->parts + (u64)g->part;
+    g->sections++;
+    const double t0 = group_now();
+    u32 spins = 0;
+    while(g->sh->ticket.load(std::memory_order_acquire) != mine)
+    {
+      if(g->sh->abort_flag.load(std::memory_order_relaxed) != 0) { rc = fail(BWTM_EPEER, "another part of the group has failed"); return; }
+      if(++spins > 2000) { sched_yield(); if((spins & 1023) == 0 && group_now() - t0 > group_timeout()) { g->sh->abort_flag.store(1); rc = fail(BWTM_EPEER, "part %d waited %.0f s for its turn", g->part, group_now() - t0); return; } }
+      else { __builtin_ia32_pause(); }
+    }
+    held = true;
+  }
+  ~Turn() { if(held) { (void)hipStreamSynchronize(CTX.stream); g->sh->ticket.fetch_add(1, std::memory_order_release); } }
+  Turn(const Turn&) = delete; Turn& operator=(const Turn&) = delete;
+};
+#define TURN(group) Turn turn_(group); if(turn_.rc != BWTM_OK) { return turn_.rc; }
 
 // This part's exported arena: at least `bytes`, zeroed where `zero_bytes` says (from its start); re-published when it had to grow.
 int group_arena(bwtm_group* g, u64 bytes, void** out)
@@ -262,6 +291,7 @@ extern "C" int bwtm_group_create(const char* name, int part, int parts, bwtm_gro
     if(g->sh->parts != (u32)parts) { munmap(m, sizeof(GroupShared)); delete g; return fail(BWTM_EINVAL, "bwtm_group_create: %s was created for %u parts, not %d", name, g->sh->parts, parts); }
   }
   g->sh->attached.fetch_add(1);
+  { const char* v = std::getenv("BWTM_GROUP_SERIAL"); g->serial = (v && v[0] == '1'); }
   int rc = group_barrier(g);                                         // everybody has the block mapped ...
   if(part == 0) { (void)shm_unlink(name); }                           // ... so its name can go: the memory lives as long as it is mapped
   if(rc != BWTM_OK) { munmap(m, sizeof(GroupShared)); delete g; return rc; }

@@ -124,11 +124,11 @@ int ra_create_range(const bwtm_index* a, const bwtm_index* b, u64 pos_first, u64
 int frontier_table_scan(const u64* seg_len, u64 nseg, u64* seg_prefix, u32* first_seg, u64* emit_base, u64 step, DevBuf& tiles, u32 tag)
 {
   const u64 scan_tiles = div_up(nseg + 1, (u64)SCAN_TILE);
-  if(scan_tiles <= FRONTIER_SCAN1_TILES)
+  if(scan_tiles <= FRONTIER_SCAN1_TILES && g_tune.frontier_unfused == 0)
   {
     LAUNCH("frontier_scan", k_frontier_scan1, scan_tiles, BLOCK_THREADS, seg_len, tiles.as<unsigned long long>(), tag, nseg, seg_prefix, first_seg, emit_base, step, (u64*)nullptr);
   }
-  else if(scan_tiles <= FRONTIER_SCAN_TILES)
+  else if(scan_tiles <= FRONTIER_SCAN_TILES && g_tune.frontier_unfused != 1)
   {
     LAUNCH("scan_reduce", k_scan_reduce<0>, scan_tiles, BLOCK_THREADS, seg_len, tiles.as<u64>(), nseg + 1, (u64)0, scan_tiles);
     LAUNCH("frontier_scan", k_frontier_scan, scan_tiles, BLOCK_THREADS, seg_len, tiles.as<const u64>(), nseg, seg_prefix, first_seg, emit_base, step, (u64*)nullptr);
@@ -352,6 +352,7 @@ extern "C" int bwtm_part_upload(bwtm_part* P, int which, const uint8_t* data, ui
   ENTER(P->ctx);
   if(P->win[which]) { bwtm_index_free(P->win[which]); P->win[which] = nullptr; }
   const bool is_a = (which == 0);
+  TURN(P->grp);
   TRY(index_upload_window(data, nbytes, first_position, counts_before, is_a ? P->na : P->nb, is_a ? P->ma : P->mb, is_a ? P->Ca : P->Cb, on_device != 0, &P->win[which]));
   // the window must hold the records of the part's range and its margins
   u64 lo, hi; (void)bwtm_part_window(P, which, &lo, &hi);
@@ -485,6 +486,8 @@ int search_setup(PartSearch& S, bool node_phase)
 int publish_outputs(PartSearch& S, int par, u64 nb, u64 error, StepInfo* all)
 {
   const u64 nseg = 5 * nb;
+  {
+  TURN(S.G);
   TRY(frontier_table_scan(S.mine<const u64>(S.lay.seg_len[par]), nseg, S.out_prefix.as<u64>(), S.out_first_seg.as<u32>(), S.dummy_emit.as<u64>(), 0, S.tiles_out, S.tag_out));
   S.tag_out = (S.tag_out == 0x7FFFFFFFu ? 1 : S.tag_out + 1);
   LAUNCH("cut_search", k_cut_search_seg, 5 * (u64)(S.parts - 1) + 1, BLOCK_THREADS, S.mine<const uint2>(S.lay.lo[par]), (S.wide ? S.mine<const unsigned short>(S.lay.hi[par]) : nullptr),
@@ -492,6 +495,7 @@ int publish_outputs(PartSearch& S, int par, u64 nb, u64 error, StepInfo* all)
     S.cut_dev.as<CutEntry>());
   HIP_TRY(hipMemcpyAsync(S.cut_host, S.cut_dev.p, 5 * (PART_MAX + 1) * sizeof(CutEntry), hipMemcpyDeviceToHost, CTX.stream));
   HIP_TRY(hipStreamSynchronize(CTX.stream));                         // this part's step is complete: its outputs may be read, its inputs overwritten
+  }
   StepInfo mine;
   mine.nb = nb; mine.error = error;
   std::memcpy(mine.cut, S.cut_host, sizeof(mine.cut));
@@ -557,6 +561,8 @@ int node_phase(PartSearch& S, u64 root_first, u64 root_count, u64 limit, u64& nb
     const int par = (int)(lvl & 1);
     u64* csp = S.mine<u64>(S.lay.node_sp[par]); u64* cr = S.mine<u64>(S.lay.node_r[par]); u64* ccnt = S.mine<u64>(S.lay.node_cnt[par]);
     NodeInfo mine = {};
+    {
+    TURN(S.G);
     if(N > 0)
     {
       const u64 grid = div_up(N, BLOCK_THREADS);
@@ -592,6 +598,7 @@ int node_phase(PartSearch& S, u64 root_first, u64 root_count, u64 limit, u64& nb
       }
     }
     else { HIP_TRY(hipStreamSynchronize(CTX.stream)); }
+    }
     TRY(group_allgather(S.G, &mine, sizeof(NodeInfo), infos.data()));
     for(int h = 0; h < S.parts; h++) { if(infos[h].error != 0) { return (h == S.g ? (mine.error == 1 ? BWTM_ENOMEM : BWTM_EINVAL) : fail(BWTM_EPEER, "part %d stopped the node phase", h)); } }
     // this part's nodes of the next level: from every part's children, class after class
@@ -611,6 +618,7 @@ int node_phase(PartSearch& S, u64 root_first, u64 root_count, u64 limit, u64& nb
     }
     if(n > ncap) { return fail(BWTM_ENOMEM, "bwtm_part_search: %llu nodes fall into part %d's range, capacity %llu", (unsigned long long)n, S.g, (unsigned long long)ncap); }
     N = n;
+    TURN(S.G);
     if(n > 0)
     {
       HIP_TRY(hipMemcpyAsync(gather_pieces.p, host_pieces, (u64)np * sizeof(NodePiece), hipMemcpyHostToDevice, CTX.stream));
@@ -624,6 +632,7 @@ int node_phase(PartSearch& S, u64 root_first, u64 root_count, u64 limit, u64& nb
   nb_out = 1;
   if(done) { return BWTM_OK; }
   // expand: the part's nodes -> its elements, as the outputs of a step (contiguous, class 0)
+  TURN(S.G);
   u64 alive = 0;
   if(N > 0)
   {
@@ -673,6 +682,7 @@ int part_search(PartSearch& S)
     if(count > S.cap) { return fail(BWTM_ENOMEM, "bwtm_part_search: %llu roots fall into part %d's range, capacity %llu", (unsigned long long)count, S.g, (unsigned long long)S.cap); }
     nb_out = std::max<u64>(1, div_up(count, (u64)FR_BLOCK));
     const u64 items = std::max<u64>(nb_out * FR_BLOCK, 5 * nb_out + 1);
+    TURN(S.G);
     LAUNCH("frontier_init", k_frontier_init, div_up(items, BLOCK_THREADS), BLOCK_THREADS, S.mine<uint2>(S.lay.lo[0]), (S.wide ? S.mine<unsigned short>(S.lay.hi[0]) : nullptr),
       S.mine<u64>(S.lay.seg_len[0]), S.mine<u64>(S.lay.seg_phys[0]), nb_out, root_first, count, P->ma);
   }
@@ -704,9 +714,19 @@ int part_search(PartSearch& S)
       TRY(S.seg_len_in.alloc((S.seg_in_cap + 1) * 8)); TRY(S.seg_phys_in.alloc((S.seg_in_cap + 1) * 8)); TRY(S.seg_prefix_in.alloc((S.seg_in_cap + 1) * 8));
       TRY(S.tiles_in.alloc(div_up(S.seg_in_cap + 1, (u64)SCAN_TILE) * 8, true));
     }
+    TURN(S.G);
     HIP_TRY(hipMemcpyAsync(S.plan_dev[par].p, plan, sizeof(PullPlan), hipMemcpyHostToDevice, CTX.stream));
-    LAUNCH("pull_tables", k_pull_tables, div_up(nseg_in + 1, BLOCK_THREADS), BLOCK_THREADS, S.plan_dev[par].as<const PullPlan>(), S.seg_len_in.as<u64>(), S.seg_phys_in.as<u64>());
-    TRY(frontier_table_scan(S.seg_len_in.as<const u64>(), nseg_in, S.seg_prefix_in.as<u64>(), S.first_seg_in.as<u32>(), S.emit_base.as<u64>(), S.in_epoch, S.tiles_in, S.tag_in));
+    if(div_up(nseg_in + 1, (u64)SCAN_TILE) <= FRONTIER_SCAN1_TILES && g_tune.frontier_unfused == 0)
+    {
+      // the pulled table and its scan in one launch
+      LAUNCH("pull_scan", k_pull_scan1, div_up(nseg_in + 1, (u64)SCAN_TILE), BLOCK_THREADS, S.plan_dev[par].as<const PullPlan>(), S.tiles_in.as<unsigned long long>(), S.tag_in,
+        S.seg_phys_in.as<u64>(), S.seg_prefix_in.as<u64>(), S.first_seg_in.as<u32>(), S.emit_base.as<u64>(), S.in_epoch);
+    }
+    else
+    {
+      LAUNCH("pull_tables", k_pull_tables, div_up(nseg_in + 1, BLOCK_THREADS), BLOCK_THREADS, S.plan_dev[par].as<const PullPlan>(), S.seg_len_in.as<u64>(), S.seg_phys_in.as<u64>());
+      TRY(frontier_table_scan(S.seg_len_in.as<const u64>(), nseg_in, S.seg_prefix_in.as<u64>(), S.first_seg_in.as<u32>(), S.emit_base.as<u64>(), S.in_epoch, S.tiles_in, S.tag_in));
+    }
     S.tag_in = (S.tag_in == 0x7FFFFFFFu ? 1 : S.tag_in + 1);
     const u64 grid = std::max<u64>(1, div_up(n_in, (u64)FR_BLOCK));
     FrontierView f;
@@ -727,6 +747,7 @@ int part_search(PartSearch& S)
     P->info.pulled_bytes += n_in * (S.wide ? 10 : 8) + nseg_in * 16;
     if(S.in_epoch == S.EPOCH || S.epoch_used + S.cap > S.emit_cap) { TRY(part_flush(S)); }
   }
+  TURN(S.G);
   TRY(frontier_flush(S.ra, S.emit16, S.emit_cap, S.emit_base, S.bound, S.ntiles, S.in_epoch));
   HIP_TRY(hipStreamSynchronize(CTX.stream));
   return BWTM_OK;
@@ -785,6 +806,8 @@ int part_finish(bwtm_part* P, bwtm_slice** out, u64* byte_offset, u64* total_byt
       return lo < hi;
     };
     const u64 nwords = ra->nchunks * CHUNK_WORDS, seg_words = BOUNDARY_BYTES / 8;
+    {
+    TURN(G);
     for(int k = g + 1; k < parts; k++)
     {
       u64* row = (u64*)((char*)arena + mine_lay.boundary + (u64)k * BOUNDARY_BYTES);
@@ -795,7 +818,9 @@ int part_finish(bwtm_part* P, bwtm_slice** out, u64* byte_offset, u64* total_byt
       if(h1 > h0) { HIP_TRY(hipMemcpyAsync(row + (h0 - w0), ra->bits_as<const u64>() + h0, (h1 - h0) * 8, hipMemcpyDeviceToDevice, CTX.stream)); }
     }
     HIP_TRY(hipStreamSynchronize(CTX.stream));
+    }
     TRY(group_barrier(G));
+    TURN(G);
     for(int h = 0; h < g; h++)
     {
       if(!touches(h, g)) { continue; }
@@ -811,7 +836,7 @@ int part_finish(bwtm_part* P, bwtm_slice** out, u64* byte_offset, u64* total_byt
   // 2. the small exchange of the ranges: set bits of every range, local offsets of the supers that start in it, its last chunk of bits
   const u64 nsup = num_supers(ra->n_out);
   std::vector<u64> mine(1 + CHUNK_WORDS + nsup, 0), everyone((u64)parts * (1 + CHUNK_WORDS + nsup), 0);
-  TRY(bwtm_ra_range_counts(ra, rec_first[g], rec_last[g], &mine[0], mine.data() + 1 + CHUNK_WORDS, mine.data() + 1));
+  { TURN(G); TRY(bwtm_ra_range_counts(ra, rec_first[g], rec_last[g], &mine[0], mine.data() + 1 + CHUNK_WORDS, mine.data() + 1)); }
   TRY(group_allgather(G, mine.data(), mine.size() * 8, everyone.data()));
   const u64 stride = mine.size();
   u64 before = 0, total = 0;
@@ -830,15 +855,19 @@ int part_finish(bwtm_part* P, bwtm_slice** out, u64* byte_offset, u64* total_byt
   }
   const u64* halo = nullptr;
   for(int h = g; h-- > 0; ) { if(rec_last[h] > rec_first[h]) { halo = everyone.data() + h * stride + 1; break; } }
-  TRY(bwtm_ra_finalize_range(ra, rec_first[g], rec_last[g], before, total, super_boff.data(), halo));
   // 3. this part's range of the output; the encoder's two carries (api/slices.hip.h)
   bwtm_slice* slice = nullptr;
-  TRY(bwtm_interleave_range(P->win[0], P->win[1], ra, rec_first[g], rec_last[g], &slice));
-  bwtm_ra_free(P->ra); P->ra = nullptr;
-  for(int k = 0; k < 2; k++) { bwtm_index_free(P->win[k]); P->win[k] = nullptr; }
-  auto fail_slice = [&](int rc) { bwtm_slice_free(slice); return rc; };
   u64 head = 0;
-  int rc = bwtm_slice_lasthead(slice, &head);
+  int rc = BWTM_OK;
+  {
+    TURN(G);
+    TRY(bwtm_ra_finalize_range(ra, rec_first[g], rec_last[g], before, total, super_boff.data(), halo));
+    TRY(bwtm_interleave_range(P->win[0], P->win[1], ra, rec_first[g], rec_last[g], &slice));
+    bwtm_ra_free(P->ra); P->ra = nullptr;
+    for(int k = 0; k < 2; k++) { bwtm_index_free(P->win[k]); P->win[k] = nullptr; }
+    rc = bwtm_slice_lasthead(slice, &head);
+  }
+  auto fail_slice = [&](int rc2) { bwtm_slice_free(slice); return rc2; };
   if(rc != BWTM_OK) { return fail_slice(rc); }
   std::vector<u64> heads(parts, 0);
   rc = group_allgather(G, &head, 8, heads.data());
@@ -846,12 +875,16 @@ int part_finish(bwtm_part* P, bwtm_slice** out, u64* byte_offset, u64* total_byt
   u64 head_before = 0;
   for(int h = 0; h < g; h++) { head_before = std::max(head_before, heads[h]); }
   u64 table[64]; std::vector<u64> tables((u64)parts * 64, 0), offsets(parts + 1, 0);
-  rc = bwtm_slice_size_table(slice, head_before, table);
+  { Turn turn_(G); rc = (turn_.rc != BWTM_OK ? turn_.rc : bwtm_slice_size_table(slice, head_before, table)); }
   if(rc == BWTM_OK) { rc = group_allgather(G, table, sizeof(table), tables.data()); }
   if(rc == BWTM_OK) { rc = bwtm_fold_offsets(tables.data(), parts, offsets.data()); }
-  if(rc == BWTM_OK) { rc = bwtm_slice_encode(slice, offsets[g]); }
   u64 first_start = ~0ull;
-  if(rc == BWTM_OK) { rc = bwtm_slice_first_block_start(slice, &first_start); }
+  if(rc == BWTM_OK)
+  {
+    Turn turn_(G);
+    rc = (turn_.rc != BWTM_OK ? turn_.rc : bwtm_slice_encode(slice, offsets[g]));
+    if(rc == BWTM_OK) { rc = bwtm_slice_first_block_start(slice, &first_start); }
+  }
   if(rc != BWTM_OK) { return fail_slice(rc); }
   std::vector<u64> starts(parts, ~0ull);
   rc = group_allgather(G, &first_start, 8, starts.data());

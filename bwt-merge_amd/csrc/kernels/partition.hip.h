@@ -141,6 +141,78 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_pull_tables(const PullPlan* p
   seg_phys[idx] = at | ((u64)pc.src << PULL_SRC_SHIFT);
 }
 
+// k_pull_tables and the scan of the pulled table (k_frontier_scan1) in ONE launch: every workgroup pulls the 2048 entries of its tile, publishes
+// the tile's total as a tagged word and waits for the tiles before it, as k_frontier_scan1 does (at most FRONTIER_SCAN1_TILES tiles, all resident).
+__global__ void __launch_bounds__(BLOCK_THREADS) k_pull_scan1(const PullPlan* plan, unsigned long long* tile_total, u32 tag, u64* seg_phys, u64* seg_prefix, u32* first_seg,
+  u64* emit_base, u64 step)
+{
+  __shared__ u32 s_first[5 * PART_MAX];
+  __shared__ u64 lds[BLOCK_THREADS / WAVE];
+  const u32 np = plan->npieces;
+  const u64 nseg = plan->nseg, n = nseg + 1;                          // the entry after the last segment holds 0 and receives N_t
+  if(threadIdx.x < np) { s_first[threadIdx.x] = plan->piece[threadIdx.x].dst_first; }
+  __syncthreads();
+  const u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+  u64 item[SCAN_ITEMS], at[SCAN_ITEMS];
+  u64 acc = 0;
+  // the thread's eight consecutive entries: the run of the first one by binary search, the following ones by stepping
+  u32 q = 0;
+  if(base < nseg) { for(u32 st = 64; st != 0; st >>= 1) { if(q + st < np && s_first[q + st] <= base) { q += st; } } }
+  PullPiece pc = plan->piece[q];
+#pragma unroll
+  for(int k = 0; k < SCAN_ITEMS; k++)
+  {
+    const u64 idx = base + k;
+    item[k] = 0; at[k] = 0;
+    if(idx < nseg)
+    {
+      while(q + 1 < np && s_first[q + 1] <= idx) { q++; pc = plan->piece[q]; }
+      const u32 j = (u32)idx - pc.dst_first;
+      const u64 e = pc.src_first + j;
+      u64 len = plan->seg_len[pc.src][e], a = plan->seg_phys[pc.src][e];
+      if(j + 1 == pc.count && pc.last_len != PULL_ALL && len > pc.last_len) { len = pc.last_len; }
+      if(j == 0) { const u64 skip = (pc.clip_first < len ? pc.clip_first : len); len -= skip; a += skip; }
+      item[k] = len; at[k] = a | ((u64)pc.src << PULL_SRC_SHIFT);
+    }
+    acc += item[k];
+  }
+  const u64 incl = wave_incl_sum(acc);
+  const u64 wave_total = shfl_u64(incl, WAVE - 1);
+  u64 excl = shfl_up_u64(incl, 1);
+  if(lane_id() == 0) { excl = 0; }
+  if(lane_id() == 0) { lds[threadIdx.x >> 6] = wave_total; }
+  __syncthreads();
+  u64 before_waves = 0, tile_sum = 0;
+  for(int k = 0; k < BLOCK_THREADS / WAVE; k++) { if(k < (int)(threadIdx.x >> 6)) { before_waves += lds[k]; } tile_sum += lds[k]; }
+  if(threadIdx.x == 0) { __hip_atomic_store(&tile_total[blockIdx.x], ((unsigned long long)tag << 32) | (unsigned long long)tile_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __syncthreads();                                                     // lds is reused below
+  u64 c = 0;
+  for(u64 k = threadIdx.x; k < blockIdx.x; k += BLOCK_THREADS)
+  {
+    unsigned long long w;
+    do { w = __hip_atomic_load(&tile_total[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while((u32)(w >> 32) != tag);
+    c += (u32)w;
+  }
+  const u64 carry = block_reduce<0>(c, lds);
+  u64 run = carry + before_waves + excl;
+  for(int k = 0; k < SCAN_ITEMS; k++)
+  {
+    const u64 idx = base + k;
+    if(idx < n)
+    {
+      seg_prefix[idx] = run;
+      if(idx < nseg)
+      {
+        seg_phys[idx] = at[k];
+        const u64 b = (run + FR_BLOCK - 1) / FR_BLOCK;
+        if(b * FR_BLOCK < run + item[k]) { first_seg[b] = (u32)idx; }
+      }
+      else { seg_phys[idx] = 0; emit_base[step + 1] = emit_base[step] + run; }
+    }
+    run += item[k];
+  }
+}
+
 // ---- the node phase over partitioned records.  A level's nodes (sp, count, r) live on the GPU that owns sp; with cuts at k-mer boundaries a
 // node never crosses a cut (the suffixes "x$" of a node x sort before every "x y...": a cut lies before or after all of them), so
 // k_range_step runs on a window unchanged.  Its children come out symbol-major, i.e. sorted by sp, class after class: the children of class

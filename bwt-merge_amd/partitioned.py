@@ -58,7 +58,7 @@ def merge_part(group, a, b, cuts=None, kmer=0, shares=None, profile=None):
 
 def merge_parts(pkg, a, b, parts, device=0, kmer=0, cuts=None, profile=False, collect=None):
     """The whole merge with `parts` threads of this process, one context of `device` each.  Returns a dict: slices (in order; their contexts
-    stay alive until release() is called), stats, cuts, and with profile = True the kernel milliseconds of every part by phase.
+    stay alive until release() is called), stats, cuts, and with profile = True the kernel milliseconds of every part by phase and kernel (phases[g][phase][kernel]).
     collect(g, slice) (optional) runs in part g's thread after its merge (download its bytes / samples there)."""
     if cuts is None:
         cuts = capi.partition_cuts_host(a, b, parts, kmer)
@@ -74,7 +74,7 @@ def merge_parts(pkg, a, b, parts, device=0, kmer=0, cuts=None, profile=False, co
 
             def prof(phase):
                 pkg.synchronize()
-                phases[g][phase] = sum(v[0] for v in pkg.profile_read().values())
+                phases[g][phase] = {name: v[0] for name, v in pkg.profile_read().items()}      # kernel -> ms of this phase
                 pkg.profile_reset()
             if profile:
                 pkg.profile_only(None); pkg.profile_reset(); pkg.profile_enable(True)

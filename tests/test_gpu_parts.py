@@ -77,12 +77,13 @@ def test_parts_with_mixed_read_lengths(gpu, oracle):
     ta = oracle.generate_reads(9400, 2500, 90)
     tb = np.concatenate([oracle.generate_reads(9500 + j, 400, int(n)) for j, n in enumerate([1, 17, 60, 100, 139, 33])])
     a, b = oracle.FMI.from_text(ta), oracle.FMI.from_text(tb)
-    for parts, kmer, rr in ((3, 3, 0), (5, 4, 8), (8, 4, 3)):
-        gpu.tune("range_ratio", rr)
+    # (unfused = 2: the pulled table by k_pull_tables and the two-launch scan instead of k_pull_scan1; 1: the generic scan + k_frontier_prep)
+    for parts, kmer, rr, unfused in ((3, 3, 0, 0), (5, 4, 8, 0), (8, 4, 3, 0), (4, 3, 8, 2), (3, 2, 0, 1)):
+        gpu.tune("range_ratio", rr); gpu.tune("frontier_unfused", unfused)
         try:
             data, be, cum, stats, _ = merge_parts(gpu, a, b, parts, kmer)
         finally:
-            gpu.tune("range_ratio", 8)
+            gpu.tune("range_ratio", 8); gpu.tune("frontier_unfused", 0)
         check_against_oracle(oracle, a, b, data, be, cum)
         assert all(s["steps"] + s["node_levels"] == 140 for s in stats)
 
