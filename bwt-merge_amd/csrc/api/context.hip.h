@@ -65,6 +65,10 @@ struct bwtm_context
   // small page-locked scratch for results read back by the host (a pageable destination would make
   // hipMemcpyAsync stage and block)
   u64* host_scratch = nullptr;             // 128 u64: [0, 32) call results, [32, 64) upload / encode / slices, [64, 96) the search's size ring
+  // The one-launch scans (k_frontier_scan1, k_pull_scan1) let a tile wait for the tiles before it: all their workgroups must be resident at the
+  // same time.  The limits come from THIS device (CUs x workgroups of the kernel per CU, capped at FRONTIER_SCAN1_TILES); larger tables take the
+  // two-launch form.  (A device that is shared with other processes delays such a kernel, it cannot deadlock it: the others' kernels end.)
+  u64 scan1_tiles = 0, pull_scan1_tiles = 0;
 };
 
 namespace
@@ -130,6 +134,15 @@ int context_setup(bwtm_context* c, int device)
   HIP_TRY(hipHostMalloc((void**)&c->host_scratch, 128 * sizeof(u64), hipHostMallocDefault));
   vmm_setup(c);
   // Kernels that take more than the default 64 KiB of dynamic LDS (a per-device attribute).
+  {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    int per_cu_scan = 0, per_cu_pull = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_scan, (const void*)k_frontier_scan1, BLOCK_THREADS, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_pull, (const void*)k_pull_scan1, BLOCK_THREADS, 0));
+    c->scan1_tiles = std::min<u64>(FRONTIER_SCAN1_TILES, (u64)std::max(per_cu_scan, 0) * (u64)std::max(prop.multiProcessorCount, 0));
+    c->pull_scan1_tiles = std::min<u64>(FRONTIER_SCAN1_TILES, (u64)std::max(per_cu_pull, 0) * (u64)std::max(prop.multiProcessorCount, 0));
+  }
   HIP_TRY(hipFuncSetAttribute((const void*)k_part_scatter_sorted, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   HIP_TRY(hipFuncSetAttribute((const void*)k_lf_walk_binned<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024));
 #ifdef BWTM_DIAGNOSTICS

@@ -124,7 +124,7 @@ int ra_create_range(const bwtm_index* a, const bwtm_index* b, u64 pos_first, u64
 int frontier_table_scan(const u64* seg_len, u64 nseg, u64* seg_prefix, u32* first_seg, u64* emit_base, u64 step, DevBuf& tiles, u32 tag)
 {
   const u64 scan_tiles = div_up(nseg + 1, (u64)SCAN_TILE);
-  if(scan_tiles <= FRONTIER_SCAN1_TILES && g_tune.frontier_unfused == 0)
+  if(scan_tiles <= CTX.scan1_tiles && g_tune.frontier_unfused == 0)
   {
     LAUNCH("frontier_scan", k_frontier_scan1, scan_tiles, BLOCK_THREADS, seg_len, tiles.as<unsigned long long>(), tag, nseg, seg_prefix, first_seg, emit_base, step, (u64*)nullptr);
   }
@@ -137,7 +137,7 @@ int frontier_table_scan(const u64* seg_len, u64 nseg, u64* seg_prefix, u32* firs
   else
   {
     TRY(device_scan<0>(seg_len, seg_prefix, nseg + 1));
-    LAUNCH("frontier_prep", k_frontier_prep, div_up(nseg, BLOCK_THREADS), BLOCK_THREADS, (const u64*)seg_prefix, nseg, first_seg, emit_base, step);
+    LAUNCH("frontier_prep", k_frontier_prep, std::max<u64>(1, div_up(nseg, BLOCK_THREADS)), BLOCK_THREADS, (const u64*)seg_prefix, nseg, first_seg, emit_base, step);
   }
   return BWTM_OK;
 }
@@ -383,7 +383,7 @@ struct PartSearch
   DevBuf seg_len_in, seg_phys_in, seg_prefix_in, first_seg_in, tiles_in; u64 seg_in_cap = 0;
   DevBuf out_prefix, out_first_seg, tiles_out, dummy_emit;
   DevBuf cuts_dev, cut_dev, srcs, plan_dev[2];
-  DevBuf emit16, emit_base, bound; u64 emit_cap = 0, EPOCH = 1, in_epoch = 0, epoch_used = 0, ntiles = 0;
+  DevBuf emit16, emit_base, bound; u64 emit_cap = 0, EPOCH = 1, in_epoch = 0, epoch_used = 0, ntiles = 0, tile_first = 0;      // (the tiles of the part's window of the bitvector)
   // page-locked staging
   PullPlan* plan_host[2] = {nullptr, nullptr}; CutEntry* cut_host = nullptr; u64* small_host = nullptr;
   u32 tag_in = 1, tag_out = 1;
@@ -468,7 +468,9 @@ int search_setup(PartSearch& S, bool node_phase)
   HIP_TRY(hipMemcpyAsync(S.srcs.p, sp, 4 * PART_MAX * sizeof(void*), hipMemcpyHostToDevice, CTX.stream));
   HIP_TRY(hipStreamSynchronize(CTX.stream));
   // dense emits of an epoch of steps, as in search_frontier()
-  S.ntiles = div_up(S.ra->n_out + 1, 1ull << TILE_SHIFT);
+  // the tile bookkeeping of the emits covers the part's own window of the bitvector, not the whole output
+  S.tile_first = S.ra->win_word_first >> (TILE_SHIFT - 6);
+  S.ntiles = div_up(S.ra->win_words, 1ull << (TILE_SHIFT - 6));
   const u64 per_seq = P->nb / (m > 0 ? m : 1) + 1;
   S.emit_cap = std::min<u64>((u64)(g_tune.emit_budget > 0 ? g_tune.emit_budget : (16ll << 30)) / sizeof(unsigned short), 2 * S.cap * per_seq + (1ull << 20));
   if(S.emit_cap < S.cap) { S.emit_cap = S.cap; }
@@ -527,7 +529,7 @@ void plan_input(const StepInfo* all, int g, int parts, PullPlan* plan, u64& n_in
 
 int part_flush(PartSearch& S)
 {
-  TRY(frontier_flush(S.ra, S.emit16, S.emit_cap, S.emit_base, S.bound, S.ntiles, S.in_epoch));
+  TRY(frontier_flush(S.ra, S.emit16, S.emit_cap, S.emit_base, S.bound, S.ntiles, S.in_epoch, S.tile_first));
   HIP_TRY(hipMemsetAsync(S.bound.p, 0xFF, S.EPOCH * (S.ntiles + 1) * sizeof(u32), CTX.stream));
   HIP_TRY(hipMemsetAsync(S.emit_base.p, 0, (S.EPOCH + 1) * sizeof(u64), CTX.stream));
   S.in_epoch = 0; S.epoch_used = 0;
@@ -716,7 +718,7 @@ int part_search(PartSearch& S)
     }
     TURN(S.G);
     HIP_TRY(hipMemcpyAsync(S.plan_dev[par].p, plan, sizeof(PullPlan), hipMemcpyHostToDevice, CTX.stream));
-    if(div_up(nseg_in + 1, (u64)SCAN_TILE) <= FRONTIER_SCAN1_TILES && g_tune.frontier_unfused == 0)
+    if(div_up(nseg_in + 1, (u64)SCAN_TILE) <= CTX.pull_scan1_tiles && g_tune.frontier_unfused == 0)
     {
       // the pulled table and its scan in one launch
       LAUNCH("pull_scan", k_pull_scan1, div_up(nseg_in + 1, (u64)SCAN_TILE), BLOCK_THREADS, S.plan_dev[par].as<const PullPlan>(), S.tiles_in.as<unsigned long long>(), S.tag_in,
@@ -736,7 +738,7 @@ int part_search(PartSearch& S)
     f.seg_len_next = S.mine<u64>(S.lay.seg_len[1 - par]); f.seg_phys_next = S.mine<u64>(S.lay.seg_phys[1 - par]);
     f.nb_max = grid;
     f.emit16 = S.emit16.as<unsigned short>(); f.emit_base = S.emit_base.as<const u64>(); f.emit_cap = S.emit_cap; f.bits32 = S.ra->bits_as<u32>();
-    f.bound_row = S.bound.as<u32>() + S.in_epoch * (S.ntiles + 1); f.step = S.in_epoch; f.block_base = 0;
+    f.bound_row = S.bound.as<u32>() + S.in_epoch * (S.ntiles + 1) - S.tile_first; f.step = S.in_epoch; f.block_base = 0;      // indexed by absolute tile numbers
     f.src_lo = S.srcs.as<const uint2* const>() + (2 * par + 0) * PART_MAX; f.src_hi = S.srcs.as<const unsigned short* const>() + (2 * par + 1) * PART_MAX;
     f.nseg_in = nseg_in;
     if(S.wide) { LAUNCH("frontier_step", (k_frontier_step<0, true, false, true>), grid, FR_BLOCK, S.A->view(), S.B->view(), f); }
@@ -748,7 +750,7 @@ int part_search(PartSearch& S)
     if(S.in_epoch == S.EPOCH || S.epoch_used + S.cap > S.emit_cap) { TRY(part_flush(S)); }
   }
   TURN(S.G);
-  TRY(frontier_flush(S.ra, S.emit16, S.emit_cap, S.emit_base, S.bound, S.ntiles, S.in_epoch));
+  TRY(frontier_flush(S.ra, S.emit16, S.emit_cap, S.emit_base, S.bound, S.ntiles, S.in_epoch, S.tile_first));
   HIP_TRY(hipStreamSynchronize(CTX.stream));
   return BWTM_OK;
 }

@@ -225,7 +225,8 @@ int search_partitioned(const bwtm_index* a, const bwtm_index* b, u64 seq_first, 
 
 // Level-synchronous search (k_frontier_*): one launch per LF step over the sorted frontier; the emits of the steps of an
 // EPOCH are written densely and turned into bitvector tiles when the epoch ends.
-int frontier_flush(bwtm_ra* ra, DevBuf& emit16, u64 emit_cap, DevBuf& emit_base, DevBuf& bound, u64 ntiles, u64 nsteps)
+// tile_first: the rows of `bound` describe the tiles [tile_first, tile_first + ntiles) only (a part's window of the bitvector, api/pmerge.hip.h).
+int frontier_flush(bwtm_ra* ra, DevBuf& emit16, u64 emit_cap, DevBuf& emit_base, DevBuf& bound, u64 ntiles, u64 nsteps, u64 tile_first = 0)
 {
   if(nsteps == 0) { return BWTM_OK; }
   const u64 nsegs = div_up(ntiles, BOUND_SEG);
@@ -233,7 +234,7 @@ int frontier_flush(bwtm_ra* ra, DevBuf& emit16, u64 emit_cap, DevBuf& emit_base,
   LAUNCH2D("bound_seg_min", k_bound_seg_min, nsegs, nsteps, BLOCK_THREADS, bound.as<const u32>(), ntiles, nsegs, segmin.as<u32>());
   LAUNCH2D("bound_suffix_min", k_bound_suffix_min, nsegs, nsteps, BLOCK_THREADS, bound.as<u32>(), ntiles, nsegs, segmin.as<const u32>(), emit_base.as<const u64>());
   LAUNCH("tile_build", k_tile_build_frontier, ntiles, BLOCK_THREADS, emit16.as<const unsigned short>(), emit_base.as<const u64>(), emit_cap, bound.as<const u32>(),
-    ntiles, nsteps, ra->bits_as<u64>(), ra->nchunks * CHUNK_WORDS);
+    ntiles, nsteps, ra->bits_as<u64>() + (tile_first << (TILE_SHIFT - 6)), ra->nchunks * CHUNK_WORDS - (tile_first << (TILE_SHIFT - 6)));
   return BWTM_OK;
 }
 
@@ -438,7 +439,7 @@ int search_frontier(const bwtm_index* a, const bwtm_index* b, u64 seq_first, u64
     // One launch when every tile's workgroup is resident at the same time whatever the order of dispatch (1024 workgroups of 256 threads:
     // four per CU, the kernel allows seven): a tile that waits for another can then never wait for one that has not started.  Larger tables
     // (above 5 x 10^7 sequences per call: the target size has 4769 tiles) take the two-launch form, 4 us more per step of 10 ms.
-    if(scan_tiles <= FRONTIER_SCAN1_TILES && g_tune.frontier_unfused == 0)
+    if(scan_tiles <= CTX.scan1_tiles && g_tune.frontier_unfused == 0)
     {
       // scan of the segment lengths + per-step bookkeeping in one launch: the tiles exchange their totals through tagged words
       LAUNCH("frontier_scan", k_frontier_scan1, scan_tiles, BLOCK_THREADS, seg_len[cur].as<const u64>(), scan_partial.as<unsigned long long>(), (u32)((t & 0x7FFFFFFFull) + 1), nseg,

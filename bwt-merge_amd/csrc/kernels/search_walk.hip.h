@@ -223,8 +223,10 @@ __device__ __attribute__((noinline)) void sink_flush_bin(const EmitSink sink, u3
 
 // LDS_SUP: both super tables are staged in dynamic LDS (5 u64 per super block: symbols 1..5),
 // which removes two of the four distinct-line gathers per step (measured: 259 -> 172 ms).
+// (Without the tables in LDS -- indexes beyond ~3 x 10^10 positions walked per chain -- the kernel carries eight more 64-bit super-table values per
+// lane: at four waves per SIMD it spilled ten registers to scratch (round 5, tests/_build/bwtm_api.s); three waves per SIMD hold them.)
 template<bool LDS_SUP>
-__global__ void __launch_bounds__(WB_THREADS, 4) k_lf_walk_binned(IndexView A, IndexView B, u64 seq_first, u64 seq_count, EmitSink sink, u32 nsup_a, u32 nsup_b)
+__global__ void __launch_bounds__(WB_THREADS, (LDS_SUP ? 4 : 3)) k_lf_walk_binned(IndexView A, IndexView B, u64 seq_first, u64 seq_count, EmitSink sink, u32 nsup_a, u32 nsup_b)
 {
   extern __shared__ u64 sup_lds[];            // LDS_SUP: [5 * nsup_a] for A, then [5 * nsup_b] for B, C already added
   __shared__ u64 sC[16];

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "bwt-merge_amd", "csrc", "bwtm_api.hip")
 OUT = os.path.join(ROOT, "tests", "_build", "bwtm_api.s")
 HOT = ("k_frontier_step", "k_frontier_scan", "k_tile_build_frontier", "k_build_recs", "k_block_len", "k_interleave", "k_enc_emit", "k_enc_size",
-       "k_enc_lasthead", "k_block_cum", "k_ingest_scatter", "k_ingest_hist", "k_ingest_keys")
+       "k_enc_lasthead", "k_block_cum", "k_ingest_scatter", "k_ingest_hist", "k_ingest_keys", "k_lf_walk_binned", "k_pull_scan1", "k_cut_search_seg")
 
 
 @pytest.fixture(scope="module")
