@@ -223,8 +223,9 @@ int transcode(bwtm_index* x)
 #define BUILD_RECS(W, WAVES, FILL) LAUNCH("build_recs", (k_build_recs<W, WAVES, FILL>), div_up(x->ngroups, WAVES), WAVES * WAVE, \
     x->native_bytes(), x->nbytes, x->blen.as<const u64>(), x->block_start.as<u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, x->n, \
     x->sup.as<const u64>(), x->recs.as<uint4>(), x->nrecs)
-  if(per_group <= 6500) { BUILD_RECS(8192, 4, false); }
-  else if(per_group <= 14000) { BUILD_RECS(16384, 4, false); }
+  const u64 window = (g_tune.recs_window != 0 ? (u64)g_tune.recs_window : (per_group <= 6500 ? 8192 : (per_group <= 14000 ? 16384 : 32768)));
+  if(window == 8192) { BUILD_RECS(8192, 4, false); }
+  else if(window == 16384) { BUILD_RECS(16384, 4, false); }
   else if(!long_runs) { BUILD_RECS(32768, 2, false); }
   else { BUILD_RECS(32768, 2, true); }
 #undef BUILD_RECS

@@ -1,7 +1,7 @@
 #!/bin/bash
-# What a SCALE session on a multi-GPU node runs to decide between the two multi-GPU searches: the C++ tool on the
-# same two inputs with 1, 2, 4, 8 GPUs: with sequence blocks (product: bwt_merge -g ...), with the sliced frontier search and with partitioned
-# records (experimental build: bwt_merge_experimental -g ... -S / -P; DESIGN.md sections 6.2, 6.3).  Every run prints the phases of mergeMultiGPU() on stderr (upload / search /
+# What a SCALE session on a multi-GPU node runs to compare the multi-GPU designs: the C++ tool on the
+# same two inputs with 1, 2, 4, 8 GPUs: with partitioned records (product default: bwt_merge -g ... -P), with sequence blocks (product: -B) and with the
+# sliced frontier search (experimental build: bwt_merge_experimental -g ... -S).  Every run prints the phases of mergeMultiGPU() on stderr (upload / search /
 # exchange / interleave + encode / download, exchanged bytes per GPU; built with -DVERBOSE_STATUS_INFO like the reference); this script
 # collects those lines into gpurun_out/scale_cli.txt.  The inputs are two synthetic read sets written as native files by the tool itself.
 # Usage: bash tools/scale_cli.sh [reads per set = 50000000] [max gpus = 8]
@@ -32,9 +32,10 @@ for g in 1 2 4 8; do
   if [ -z "$BWTM_SCALE_SAME_DEVICE" ] && [ $g -gt $ngpu ]; then break; fi
   if [ -n "$BWTM_SCALE_SAME_DEVICE" ]; then list=$(printf '0,%.0s' $(seq $g)); list=${list%,}; else list=$(seq -s, 0 $((g-1))); fi
   for mode in blocks sliced partitioned; do
-    exe=$H/bwt_merge; extra=""
-    if [ $mode = sliced ]; then if [ $g -lt 2 ]; then continue; fi; exe=$H/bwt_merge_experimental; extra="-S"; fi
-    if [ $mode = partitioned ]; then if [ $g -lt 2 ]; then continue; fi; exe=$H/bwt_merge_experimental; extra="-P"; fi
+    exe=$H/bwt_merge; extra="-B"
+    if [ $g -lt 2 ]; then extra=""; if [ $mode != blocks ]; then continue; fi; fi
+    if [ $mode = sliced ]; then exe=$H/bwt_merge_experimental; extra="-S"; fi
+    if [ $mode = partitioned ]; then extra="-P"; fi
     for round in 1 2; do                                   # the first run of a device list pays ncclCommInitAll and the pools' first allocations
       echo "== $g GPU(s), $mode, run $round" | tee -a $R/gpurun_out/scale_cli.txt
       $exe -g $list $extra -i native $W/in0.native $W/in1.native $W/out.native 2>&1 | grep -E "mergeMultiGPU|BWTs merged|Total time|rror" | tee -a $R/gpurun_out/scale_cli.txt || true
