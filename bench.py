@@ -361,6 +361,35 @@ def measure(env, args):
         M.free()
         return None
 
+    if args.partitioned and world > 1:
+        # The first partitioned merge of the run.  It has never met two physical GPUs: when it fails on ANY rank -- the
+        # parts' buffers cannot be mapped between the devices, a part runs out of room -- every rank gets an error from the same collective step,
+        # and the run goes on with sequence blocks instead of dying without a line; `config.search` and `partitioned_fallback` say so.
+        failed, why = 0, None
+        try:
+            step()
+        except pkg.BwtmError as e:
+            failed, why = 1, str(e)
+        flag = torch.tensor([failed], dtype=torch.int64, device=args.coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) != 0:
+            if args.same_device:
+                raise SystemExit("the partitioned merge failed (%s) and --same-device has no other path" % why)
+            log("rank %d: the merge over partitioned records failed (%s); this run goes on with sequence blocks" % (rank, why or "on another rank"))
+            args.partitioned_fallback = why or "failed on another rank"
+            args.partitioned = False
+            try:
+                part_env.group.free()
+            except Exception:                                     # noqa: BLE001
+                pass
+            part_env = None
+            dev_in.clear(); torch.cuda.empty_cache(); pkg.trim()
+            for hb in host_in:
+                t = torch.empty(hb.nbytes + 16, dtype=torch.uint8, device=dev)
+                t[: hb.nbytes].copy_(torch.from_numpy(hb.array))
+                t[hb.nbytes:].zero_()
+                dev_in.append(t)
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     pkg.device_bytes_peak(reset=True)
@@ -585,7 +614,8 @@ def measure(env, args):
                                     (world, "HIP IPC between the ranks' processes, all on GPU 0" if args.same_device else "peer-mapped memory over xGMI")) if args.partitioned else
                                    "sequence blocks of input2 sharded over %d GPU(s)%s" %
                                    (world, ", RCCL reduce-scatter of the rank-array bitvector by output range, result sharded by output range" if sharded else "")),
-                   "search": ("partitioned" if args.partitioned else ("blocks" if sharded else "single")), "same_device": bool(args.same_device)},
+                   "search": ("partitioned" if args.partitioned else ("blocks" if sharded else "single")), "same_device": bool(args.same_device),
+                   "partitioned_fallback": getattr(args, "partitioned_fallback", None)},
         "sharded_phases_rank0": shard_phases, "partitioned_phases_rank0": part_phases,
         "roofline": roofline, "job_roofline": job, "kernel_ms_per_step": kernel_ms,
         "host_to_host": host, "peak_device_bytes": peak_device,

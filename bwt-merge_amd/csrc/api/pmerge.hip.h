@@ -831,7 +831,7 @@ int part_finish(bwtm_part* P, bwtm_slice** out, u64* byte_offset, u64* total_byt
       const u64* row = (const u64*)((const char*)pa + lay_all[h].boundary + (u64)g * BOUNDARY_BYTES);
       const u64 w0 = (P->out_seg(g) << 16) >> 6, w1 = std::min<u64>(nwords, w0 + seg_words);
       const u64 h0 = std::max<u64>(w0, ra->win_word_first), h1 = std::min<u64>(w1, ra->win_word_first + ra->win_words);
-      if(h1 > h0) { LAUNCH("bits_or", k_bits_or, div_up(h1 - h0, BLOCK_THREADS), BLOCK_THREADS, ra->bits_as<u64>() + h0, row + (h0 - w0), h1 - h0); }
+      if(h1 > h0) { LAUNCH("bits_or", k_bits_or_peer, div_up(h1 - h0, BLOCK_THREADS), BLOCK_THREADS, ra->bits_as<u64>() + h0, row + (h0 - w0), h1 - h0); }
     }
     HIP_TRY(hipStreamSynchronize(CTX.stream));
     P->info.boundary_bytes = BOUNDARY_BYTES;

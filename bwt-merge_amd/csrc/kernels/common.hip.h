@@ -93,6 +93,17 @@ __device__ inline u64 wave_sum_mostly_small(u64 v)
 __device__ inline u64 wave_max(u64 v)   { return shfl_u64(wave_incl_max(v), WAVE - 1); }
 
 //------------------------------------------------------------------------------
+// Loads of memory that a kernel of ANOTHER GPU wrote before the last exchange (the parts' exported buffers of the merge over partitioned
+// records: output coordinates, segment tables, node lists, boundary bits).  System scope: no cache of this GPU may answer with what the
+// address held two steps ago (the buffers are reused every second step), whatever the runtime invalidates at a kernel's start.
+// (The pointers come out of LDS-staged tables as generic ones: the casts say "global", so the loads are global_load ... sc0 sc1, not flat_load.)
+typedef __attribute__((address_space(1))) const u64 peer_u64;
+typedef __attribute__((address_space(1))) const unsigned short peer_u16;
+__device__ inline u64 peer_load(const u64* p) { return __hip_atomic_load((peer_u64*)(uintptr_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ inline uint2 peer_load(const uint2* p) { const u64 v = peer_load((const u64*)p); return make_uint2((u32)v, (u32)(v >> 32)); }
+__device__ inline unsigned short peer_load(const unsigned short* p) { return __hip_atomic_load((peer_u16*)(uintptr_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+//------------------------------------------------------------------------------
 // Record access.
 
 __device__ inline void load_record(const uint4* recs, u64 q, u32 w[16])

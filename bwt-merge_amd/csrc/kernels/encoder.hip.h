@@ -186,9 +186,15 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_lasthead(const uint4* rec
 // Per-lane event statistics of a tile: number of events and the LONG events among them (heads that end a
 // run of >= 42: no other head among the 41 positions before them; at most two per tile).  `before` =
 // (position of the last head before this tile) + 1.
-__device__ inline void tile_event_stats(const TileInfo& ti, u64 tile_base, u64 before, u32& nev, u64& long_mask)
+// dep_len (round 6): != 0 when the tile's FIRST head ends a run of >= 83 = 2 * 42 - 1, its length.  Only such runs have a size that depends on the
+// byte offset: a run of 42 .. 82 is two bytes wherever it starts (head + one extension byte, or -- when the head is the last byte of its
+// block -- a run of 41 and a run of 1 .. 41, support.h:267-279), so the ordered walk over the long events (for_each_dep_event) only has to
+// visit the others; a later head of a tile is never one of them (the head before it lies in the same 64 positions).
+constexpr u64 DEP_RUN = 2 * MAX_RUN - 1;
+
+__device__ inline void tile_event_stats(const TileInfo& ti, u64 tile_base, u64 before, u32& nev, u64& long_mask, u64& dep_len)
 {
-  nev = (u32)__builtin_popcountll(ti.E); long_mask = 0;
+  nev = (u32)__builtin_popcountll(ti.E); long_mask = 0; dep_len = 0;
   const u64 H = ti.H;
   if(H == 0) { return; }
   // covered = OR of H << k for k = 1..41: positions that have a head among the 41 positions before them
@@ -200,42 +206,20 @@ __device__ inline void tile_event_stats(const TileInfo& ti, u64 tile_base, u64 b
   const u64 later = H & (H - 1);                   // heads other than the first one of the tile
   long_mask = later & ~covered;
   const u64 pos = tile_base + (u32)__builtin_ctzll(H);   // first head: its run started before the tile
-  if(pos > 0 && pos + 1 - before >= MAX_RUN) { long_mask |= H & (0 - H); }
+  if(pos > 0 && pos + 1 - before >= MAX_RUN) { long_mask |= H & (0 - H); if(pos + 1 - before >= DEP_RUN) { dep_len = pos + 1 - before; } }
 }
 
-// The long events of a chunk in position order.  f(t, g, len): tile (lane) t, number of events of the
-// chunk before this one, run length; all arguments are wave-uniform.  Every lane first works out its own
-// (at most two) long events in parallel; the ordered walk then only broadcasts them.
+// The offset-dependent long events of a chunk in position order: f(t, bytes, len) with t = tile (lane), bytes = bytes the chunk emits before the
+// event when every such event before it is counted as ONE byte (pre_excl: the lane's exclusive prefix of its events + its two-byte long events),
+// len = run length; all arguments wave-uniform.
 template<class F>
-__device__ inline void for_each_long_event(const TileInfo& ti, u64 first_tile, u64 before, u64 long_mask, u32 ev_excl, F&& f)
+__device__ inline void for_each_dep_event(u64 dep_len, u32 pre_excl, F&& f)
 {
-  u32 g0 = 0, g1 = 0; u64 len0 = 0, len1 = 0;
-  if(long_mask != 0)
-  {
-    const u64 tb = (first_tile + lane_id()) << 6;
-    u64 lm = long_mask;
-#pragma unroll
-    for(int k = 0; k < 2; k++)
-    {
-      if(lm != 0)
-      {
-        const u32 b = (u32)__builtin_ctzll(lm); lm &= lm - 1;
-        const u64 below = (1ull << b) - 1;
-        const u64 hb = ti.H & below;
-        const u64 prev1 = (hb != 0 ? tb + (63 - (u64)__builtin_clzll(hb)) + 1 : before);     // (previous head) + 1
-        const u32 g = ev_excl + (u32)__builtin_popcountll(ti.E & below);
-        const u64 len = tb + b + 1 - prev1;
-        if(k == 0) { g0 = g; len0 = len; } else { g1 = g; len1 = len; }
-      }
-    }
-  }
-  u64 pending = __ballot(long_mask != 0);
+  u64 pending = __ballot(dep_len != 0);
   while(pending)
   {
     const int t = (int)__builtin_ctzll(pending); pending &= pending - 1;
-    f((u32)t, (u32)__shfl((int)g0, t, WAVE), shfl_u64(len0, t));
-    const u64 second = shfl_u64(len1, t);
-    if(second != 0) { f((u32)t, (u32)__shfl((int)g1, t, WAVE), second); }
+    f((u32)t, (u32)__shfl((int)pre_excl, t, WAVE), shfl_u64(dep_len, t));
   }
 }
 
@@ -263,19 +247,22 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_enc_size(const uint4* recs, u
     u64 before = shfl_up_u64(incl, 1);
     if(lane_id() == 0) { before = NONE; }
     if(last > before) { before = last; }
-    u32 nev; u64 long_mask;
-    tile_event_stats(ti, T << 6, before, nev, long_mask);
-    const u64 ev_incl = (u64)wave_incl_sum32(nev);
-    const u32 chunk_events = (u32)shfl_u64(ev_incl, WAVE - 1);
-    // Events shorter than 42 are one byte under every hypothesis; only the long ones are resolved in order.
+    u32 nev; u64 long_mask, dep_len;
+    tile_event_stats(ti, T << 6, before, nev, long_mask, dep_len);
+    // Events shorter than 42 are one byte under every hypothesis and runs of 42 .. 82 two; only the longer ones are resolved in order
+    // (round 6: on reads of a genome the ordered walk visited every run of >= 42, a tenth of the events, with three shuffles each).
+    const u32 two = (u32)__builtin_popcountll(long_mask) - (dep_len != 0 ? 1u : 0u);
+    const u32 pre = nev + two;
+    const u32 pre_incl = wave_incl_sum32(pre);
+    const u32 chunk_bytes = (u32)__builtin_amdgcn_readlane((int)pre_incl, WAVE - 1);
     u32 last_g = 0;
-    for_each_long_event(ti, ft, before, long_mask, (u32)(ev_incl - nev), [&](u32, u32 g, u64 len)
+    for_each_dep_event(dep_len, pre_incl - pre, [&](u32, u32 g, u64 len)
     {
       acc += g - last_g;
       acc += long_run_bytes((u64)o + acc, len);
       last_g = g + 1;
     });
-    acc += chunk_events - last_g;
+    acc += chunk_bytes - last_g;
     u64 m = shfl_u64(incl, WAVE - 1);
     if(m > last) { last = m; }
   }
@@ -525,8 +512,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 4) k_enc_emit(const uint4* recs
     u64 before = shfl_up_u64(incl, 1);
     if(lane_id() == 0) { before = NONE; }
     if(last > before) { before = last; }
-    u32 nev; u64 long_mask;
-    tile_event_stats(ti, T << 6, before, nev, long_mask);
+    u32 nev; u64 long_mask, dep_len;
+    tile_event_stats(ti, T << 6, before, nev, long_mask, dep_len);
     u64 ev_incl = (u64)wave_incl_sum32(nev);
     u64 chunk_events = shfl_u64(ev_incl, WAVE - 1);
     bool slow = (__ballot(long_mask != 0) != 0);
@@ -613,13 +600,21 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 4) k_enc_emit(const uint4* recs
       const u32 a = (u32)(off & 15);
       const u64 origin = off - a;                                      // stream offset of lds[0]
       const u32 ev_excl = (u32)(ev_incl - nev);
-      u32 extra = 0, shift = 0;                                      // extra bytes of all long events / of those in earlier tiles
-      for_each_long_event(ti, ft, before, long_mask, ev_excl, [&](u32 t, u32 g, u64 len)
+      // extra bytes of all long events / of those in earlier tiles: one per run of 42 .. 82 (a wave scan), and what the ordered walk over the
+      // longer runs adds (round 6; see tile_event_stats)
+      const u32 two = (u32)__builtin_popcountll(long_mask) - (dep_len != 0 ? 1u : 0u);
+      const u32 two_incl = wave_incl_sum32(two);
+      u32 extra = (u32)__builtin_amdgcn_readlane((int)two_incl, WAVE - 1), shift = two_incl - two;
       {
-        const u32 sz = (u32)long_run_bytes(off + g + extra, len);
-        if(lane_id() > t) { shift += sz - 1; }
-        extra += sz - 1;
-      });
+        u32 dep_extra = 0;
+        for_each_dep_event(dep_len, ev_excl + shift, [&](u32 t, u32 g, u64 len)
+        {
+          const u32 sz = (u32)long_run_bytes(off + g + dep_extra, len);
+          if(lane_id() > t) { shift += sz - 1; }
+          dep_extra += sz - 1;
+        });
+        extra += dep_extra;
+      }
       if(ti.H != 0)
       {
         const u64 tb = T << 6;
@@ -634,7 +629,27 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 4) k_enc_emit(const uint4* recs
         {
           const u32 b = (u32)__builtin_ctzll(h); h &= h - 1;
           const u64 pos = tb + b, len = pos + 1 - prev1;
-          if((long_mask >> b) & 1)
+          if(((long_mask >> b) & 1) && len < DEP_RUN)
+          {
+            // a run of 42 .. 82: head (basic length 42) + one extension byte, or -- when the head is the last byte of its block -- a run of 41
+            // and a run of length - 41 that opens the next block (support.h:267-279; long_run_write_cb for these lengths, written out)
+            const u64 at = origin + idx;
+            const bool edge = ((at & (RLE_BLOCK - 1)) == RLE_BLOCK - 1);
+            if((at & (RLE_BLOCK - 1)) == 0)
+            {
+              block_start[at >> 6] = prev1 - 1;
+              if(CUM) { store_cum_at(at >> 6, prev1 - 1, b, run_sym); }
+            }
+            lds[idx] = (u8)(run_sym + 6 * (edge ? MAX_RUN - 2 : MAX_RUN - 1));
+            lds[idx + 1] = (u8)(edge ? run_sym + 6 * (len - MAX_RUN) : len - MAX_RUN);
+            if(edge)
+            {
+              block_start[(at + 1) >> 6] = prev1 - 1 + (MAX_RUN - 1);
+              if(CUM) { store_cum_at((at + 1) >> 6, prev1 - 1 + (MAX_RUN - 1), b, run_sym); }
+            }
+            idx += 2;
+          }
+          else if((long_mask >> b) & 1)
           {
             idx += (u32)long_run_write_cb(lds, origin + idx, run_sym, len, prev1 - 1, origin, [&](u64 blk, u64 p)
             {

@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_pull_tables(const PullPlan* p
   const PullPiece pc = plan->piece[q];
   const u32 j = (u32)idx - pc.dst_first;
   const u64 e = pc.src_first + j;
-  u64 len = plan->seg_len[pc.src][e], at = plan->seg_phys[pc.src][e];
+  u64 len = peer_load(&plan->seg_len[pc.src][e]), at = peer_load(&plan->seg_phys[pc.src][e]);
   if(j + 1 == pc.count && pc.last_len != PULL_ALL && len > pc.last_len) { len = pc.last_len; }
   if(j == 0) { const u64 skip = (pc.clip_first < len ? pc.clip_first : len); len -= skip; at += skip; }
   seg_len[idx] = len;
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_pull_scan1(const PullPlan* pl
       while(q + 1 < np && s_first[q + 1] <= idx) { q++; pc = plan->piece[q]; }
       const u32 j = (u32)idx - pc.dst_first;
       const u64 e = pc.src_first + j;
-      u64 len = plan->seg_len[pc.src][e], a = plan->seg_phys[pc.src][e];
+      u64 len = peer_load(&plan->seg_len[pc.src][e]), a = peer_load(&plan->seg_phys[pc.src][e]);
       if(j + 1 == pc.count && pc.last_len != PULL_ALL && len > pc.last_len) { len = pc.last_len; }
       if(j == 0) { const u64 skip = (pc.clip_first < len ? pc.clip_first : len); len -= skip; a += skip; }
       item[k] = len; at[k] = a | ((u64)pc.src << PULL_SRC_SHIFT);
@@ -248,7 +248,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_gather_nodes(const NodePiece*
   for(u32 k = 1; k < npieces; k++) { if(pieces[k].dst_first <= j) { q = k; } }
   const NodePiece pc = pieces[q];
   const u64 at = pc.src_first + (j - pc.dst_first);
-  sp[j] = pc.sp[at]; r[j] = pc.r[at]; cnt[j] = pc.cnt[at];
+  sp[j] = peer_load(&pc.sp[at]); r[j] = peer_load(&pc.r[at]); cnt[j] = peer_load(&pc.cnt[at]);
+}
+
+// dst |= the boundary row of another part (8 KiB in its exported buffers).
+__global__ void __launch_bounds__(BLOCK_THREADS) k_bits_or_peer(u64* dst, const u64* src, u64 nwords)
+{
+  const u64 w = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if(w < nwords) { const u64 v = peer_load(&src[w]); if(v != 0) { dst[w] |= v; } }
 }
 
 // ---- interleave of an output range from WINDOWS (bwtm_interleave_range on bwtm_x_index_window handles).  The super table of a slice only

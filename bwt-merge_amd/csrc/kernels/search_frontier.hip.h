@@ -201,7 +201,9 @@ __global__ void __launch_bounds__(FR_BLOCK, (VIEW ? 6 : 8)) k_frontier_step(Inde
       phys &= PULL_PHYS_MASK_;
       lo_src = s_src_lo[src]; if(HI) { hi_src = s_src_hi[src]; }
     }
-    uint2 l = lo_src[phys]; u32 h = (HI ? (u32)hi_src[phys] : 0u);
+    uint2 l; u32 h = 0;
+    if(PULL) { l = peer_load(&lo_src[phys]); if(HI) { h = (u32)peer_load(&hi_src[phys]); } }      // another GPU's kernel wrote them before the step's exchange
+    else { l = lo_src[phys]; if(HI) { h = (u32)hi_src[phys]; } }
     __builtin_amdgcn_sched_barrier(0);      // both loads are issued before either is used (the scheduler otherwise waits for the high bytes before it issues the other load: one more round trip per wave)
     i = (u64)l.x | ((u64)(h & 0xFF) << 32);
     r = (u64)l.y | ((u64)(h >> 8) << 32);

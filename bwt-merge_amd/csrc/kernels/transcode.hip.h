@@ -301,6 +301,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_build_sup(const u8* data, u64
 // by all 64 lanes after the decode pass.  It costs ~1 ms on read-like streams, hence a template flag.
 constexpr u32 BR_FILLS = 256;
 
+// (Round 6 measured a RUN-parallel deposit for the streams of longer runs -- every lane stores the window-relative end of each byte's run, then
+// the group's 64 x 64 bytes are dealt out round-robin and every run ORs its own edge words into the planes: no accumulators, no divergent
+// flushes.  It lost: 14.8 vs 12.1 ms at 300 x genome reads, 13.6 vs 8.2 at 30 x; four times the LDS atomics at 1.5 waves per SIMD.  So did
+// smaller windows with more waves: 16 384 / 8 192 positions 17.2 / 21.0 vs 12.1 ms.  DESIGN_HISTORY.md, round 6.)
 template<u32 BR_WINDOW, int WAVES, bool FILL>
 __global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64 nbytes, const u64* blen, u64* block_start,
   const u64* gcum, u64 gstride, u64 nblocks, u64 ngroups, u64 n, const u64* sup, uint4* recs, u64 nrecs)

@@ -64,6 +64,9 @@ def test_stored_traffic_entries_describe_this_code(bwtm):
     stale = [e["config"] for e in stored["entries"] if e["code_hash"] != bench.search_code_hash()]
     for e in stored["entries"]:
         assert e["hbm_bytes_per_launch"] > 0 and e["launches_per_search"] > 0 and e["lf_steps_per_search"] > 0
+    if stale and os.environ.get("BWTM_REQUIRE_FRESH_PMC"):
+        # the end-of-round run (tools/final_round.sh sets the flag after it has re-collected the passes): a stale profile may not ship
+        raise AssertionError("PMC passes for %s predate the last edit of the search kernels' sources" % stale)
     if stale:
         # not a failure of the code: bench.py then reports the design-floor fraction and says why (traffic_profile_check); the multi-minute PMC
         # passes (tools/pmc_step_kernel.sh) are re-collected at the end of a round, not after every edit of a kernel source
@@ -87,6 +90,31 @@ def test_bench_distributed_path_on_one_rank(bwtm):
     assert ph["ms_search"] > 0 and ph["ms_exchange"] > 0 and ph["ms_interleave_encode"] > 0 and ph["exchange_bytes_per_gpu"] == 0
     h = d["host_to_host"]                     # the N-GPU host-to-host leg (sharded upload + all-gather, slice download) on its one rank
     assert h["value"] > 0 and h["bytes"]["h2d_this_rank"] == h["bytes"]["h2d_all_inputs"] and h["bytes"]["d2h_all_ranks"] == d["config"]["native_bytes"][2]
+
+
+def test_bench_partitioned_on_one_rank(bwtm):
+    """The merge over partitioned records as the bench runs it, on its one rank: a group of one, the part's windows transcoded from its resident
+    byte share, pulled tables, the second half; the slice equals the single-GPU stream."""
+    d = run_bench([sys.executable, "bench.py", "--force-dist", "--search", "partitioned", "--reads", "3000000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert d["verified"] is True and d["config"]["search"] == "partitioned" and d["value"] > 0 and d["rccl_ranks"] == 1
+    ph = d["partitioned_phases_rank0"]
+    assert ph["lf_steps"] + ph["node_levels"] == 101 and ph["ms_search"] > 0 and ph["ms_finish"] > 0 and ph["elements_advanced"] > 0
+    assert ph["record_bytes_held"] == 64 * (2 * (3000000 * 101 // 128 + 1)) and ph["boundary_bytes_per_pair"] == 0
+    h = d["host_to_host"]
+    assert h["value"] > 0 and h["bytes"]["h2d_this_rank"] == h["bytes"]["h2d_all_inputs"] and h["bytes"]["d2h_all_ranks"] == d["config"]["native_bytes"][2]
+
+
+def test_bench_partitioned_between_processes_on_one_gpu(bwtm):
+    """Three RANKS (processes started by bench.py itself) that share GPU 0: every rank is one part, maps the other ranks' exported buffers through
+    HIP IPC handles and reads its share of every step's elements out of them; every rank's slice equals the same bytes of the single-GPU
+    stream.  The process group is gloo (RCCL refuses several ranks on one device): the data path needs no collective library."""
+    d = run_bench([sys.executable, "bench.py", "--gpus", "3", "--same-device", "--search", "partitioned", "--reads", "1500000", "--steps", "2", "--warmup", "1",
+                   "--no-cpu-baseline"])
+    assert d["n_gpus"] == 3 and d["ranks"] == 3 and d["process_group"] == "gloo" and d["rccl_ranks"] is None
+    assert d["verified"] is True and d["verification"]["slices"] == 3 and d["config"]["same_device"] is True
+    ph = d["partitioned_phases_rank0"]
+    assert ph["boundary_bytes_per_pair"] == 8192 and 0 < ph["record_bytes_held"] < 64 * (2 * (1500000 * 101 // 128 + 1))
+    assert d["host_to_host"]["bytes"]["h2d_this_rank"] < d["host_to_host"]["bytes"]["h2d_all_inputs"]
 
 
 def test_bench_chained_merge_of_four_sets(bwtm):
@@ -113,7 +141,9 @@ def test_bench_two_gpus_self_launched(bwtm):
         pytest.skip("needs two GPUs")
     d = run_bench([sys.executable, "bench.py", "--gpus", "2", "--reads", "4000000", "--steps", "2", "--warmup", "1"])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["verified"] is True and d["value"] > 0
-    assert d["verification"]["slices"] == 2 and d["cpu_baseline"] is None and d["host_to_host"] is None
+    assert d["verification"]["slices"] == 2 and d["cpu_baseline"] is None and d["config"]["search"] == "partitioned"
+    d = run_bench([sys.executable, "bench.py", "--gpus", "2", "--search", "blocks", "--reads", "4000000", "--steps", "2", "--warmup", "1", "--no-host"])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["verified"] is True and d["config"]["search"] == "blocks"
 
 
 def test_bench_self_launch_reports_a_failing_rank(bwtm):

@@ -55,9 +55,13 @@ def check_index(ix, sym, rng, nq=4000):
 
 def test_upload_builds_exact_rank_structure(gpu, oracle):
     rng = np.random.default_rng(1)
-    # run-length mixes chosen so that all three LDS window sizes of the transcode are used (positions per 62-block group)
-    for lengths in ([1, 1, 1, 2, 3], [2, 3, 4], [1, 2, 41, 42, 43, 169, 170, 5000], [16425, 16426, 100000, 1, 7]):
+    # run-length mixes chosen so that all three LDS window sizes of the transcode are used (positions per 62-block group); the last three
+    # are streams of the long-window kind: runs around the one-byte limit (9 .. 41), long-event mixes, and a few giant runs between short ones
+    for lengths in ([1, 1, 1, 2, 3], [2, 3, 4], [1, 2, 41, 42, 43, 169, 170, 5000], [16425, 16426, 100000, 1, 7], [9, 12, 17, 23, 31, 32, 33, 41],
+                    [5, 20, 42, 60, 83, 90, 168, 169, 170, 400], [3, 8, 40000, 14, 70000, 21], [2, 3, 4, 5, 6, 8, 10]):
         sym = run_symbols(rng, 3000 if max(lengths) > 4 else 60000, lengths)
+        if max(lengths) in (41, 400, 10):
+            sym = run_symbols(rng, 40000, lengths)                  # several groups, windows and records per group
         f = oracle.FMI.from_symbols(sym)
         ix = gpu.Index.upload(f.data, f.sequences, f.bases)
         assert (ix.sequences, ix.nbytes, ix.blocks) == (f.sequences, f.nbytes, f.blocks)
@@ -236,7 +240,7 @@ def test_empty_increment_and_empty_base(gpu, oracle):
     assert np.array_equal(gpu.merge(E, A).data(), a.data)
 
 
-@pytest.mark.parametrize("case", ["mixed", "boundaries", "sparse_long", "giant", "tiny", "alternating"])
+@pytest.mark.parametrize("case", ["mixed", "boundaries", "sparse_long", "genome_like", "giant", "tiny", "alternating"])
 def test_encoder_block_rule(gpu, oracle, case):
     """Run::write's offset-dependent forms (support.h:256-282), including runs that end in
     chunks far from where they start, against the oracle's encoder."""
@@ -252,6 +256,12 @@ def test_encoder_block_rule(gpu, oracle, case):
         # (offsets of the short events shifted by the extra bytes of the long ones before them)
         syms = [run_symbols(rng, 400000, [1] * 30 + [2] * 10 + [3, 7, 42, 45, 100, 171, 200, 3000]),
                 run_symbols(rng, 100000, [1] * 6 + [41, 42, 50, 64, 65, 127, 128, 129])]
+    elif case == "genome_like":
+        # the run lengths of reads of a genome at high coverage: most chunks hold runs of 42 .. 82 (two bytes at every offset: a wave scan gives
+        # their shifts), a few of 83 and more (the ordered walk), one-byte runs around them -- at every offset mod 64, in both encoder kernels
+        syms = [run_symbols(rng, 300000, [3, 5, 9, 14, 20, 30, 41, 42, 50, 64, 82, 83, 84, 100, 169, 170, 300]),
+                run_symbols(rng, 200000, [41, 42, 43, 81, 82, 83, 84, 1, 2]),
+                run_symbols(rng, 150000, [12] * 8 + [20] * 8 + [45, 60, 82] * 2 + [83, 126, 211, 5000])]
     elif case == "giant":
         syms = [np.full(5_000_000, 3, dtype=np.uint8),
                 np.concatenate([np.full(70000, 1, np.uint8), np.full(1, 2, np.uint8), np.full(4096 * 64 * 16 + 5, 4, np.uint8)])]
