@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=50_000_000)
+    ap.add_argument("--reads-a", type=int, default=0, help="reads of input1 when it differs from input2 (BASELINE config 4's shape: a large input1, a small input2)")
     ap.add_argument("--readlen", type=int, default=100)
     ap.add_argument("--parts", default="2,4,8")
     ap.add_argument("--kmer", type=int, default=0)
@@ -42,9 +43,9 @@ def main():
     dev = torch.device("cuda", 0)
     t0 = time.time()
     hosts = []
-    for seed in (1001, 1002):
+    for seed, nreads in ((1001, args.reads_a or args.reads), (1002, args.reads)):
         wargs = ({"coverage": args.coverage, "error_percent": 1} if args.workload == "genome" else {})
-        ix = synth.build_index(pkg, seed, args.reads, args.readlen, device=dev, workload=args.workload, **wargs)
+        ix = synth.build_index(pkg, seed, nreads, args.readlen, device=dev, workload=args.workload, **wargs)
         ix.encode()
         data = pkg.HostBuffer(ix.nbytes)
         ix.download_into(data.array)
@@ -53,8 +54,8 @@ def main():
         ix.free()
     torch.cuda.empty_cache(); pkg.trim()
     a, b = hosts
-    print("inputs: 2 x %d reads of %d bp (%.2f + %.2f Gbase, %.2f + %.2f GB native) in %.0f s" %
-          (args.reads, args.readlen, a.bases / 1e9, b.bases / 1e9, a.data.size / 1e9, b.data.size / 1e9, time.time() - t0), flush=True)
+    print("inputs: %d + %d reads of %d bp (%.2f + %.2f Gbase, %.2f + %.2f GB native) in %.0f s" %
+          (args.reads_a or args.reads, args.reads, args.readlen, a.bases / 1e9, b.bases / 1e9, a.data.size / 1e9, b.data.size / 1e9, time.time() - t0), flush=True)
     pkg.tune("emit_budget", args.emit_budget)
 
     # the product merge on the one GPU: the reference bytes, and its kernels by phase
