@@ -383,10 +383,11 @@ struct PartSearch
   // local
   DevBuf seg_len_in, seg_phys_in, seg_prefix_in, first_seg_in, tiles_in; u64 seg_in_cap = 0;
   DevBuf out_prefix, out_first_seg, tiles_out, dummy_emit;
-  DevBuf cuts_dev, cut_dev, srcs, plan_dev[2];
+  DevBuf cuts_dev, srcs, plan_dev[2];
   DevBuf emit16, emit_base, bound; u64 emit_cap = 0, EPOCH = 1, in_epoch = 0, epoch_used = 0, ntiles = 0, tile_first = 0;      // (the tiles of the part's window of the bitvector)
   // page-locked staging
   PullPlan* plan_host[2] = {nullptr, nullptr}; CutEntry* cut_host = nullptr; u64* small_host = nullptr;
+  CutEntry* cut_mapped = nullptr;                  // cut_host as the device addresses it
   u32 tag_in = 1, tag_out = 1;
   ~PartSearch()
   {
@@ -448,10 +449,15 @@ int search_setup(PartSearch& S, bool node_phase)
   TRY(S.out_prefix.alloc((5 * S.nbl_cap + 1) * 8)); TRY(S.out_first_seg.alloc((S.nbl_cap + 2) * sizeof(u32)));
   TRY(S.tiles_out.alloc(std::max<u64>(div_up(5 * S.nbl_cap + 1, (u64)SCAN_TILE), 1) * 8, true));
   TRY(S.dummy_emit.alloc(2 * 8, true));
-  TRY(S.cuts_dev.alloc((S.parts + 1) * 8)); TRY(S.cut_dev.alloc(5 * (PART_MAX + 1) * sizeof(CutEntry), true));
+  TRY(S.cuts_dev.alloc((S.parts + 1) * 8));
   TRY(S.srcs.alloc(4 * PART_MAX * sizeof(void*)));
   for(int k = 0; k < 2; k++) { TRY(S.plan_dev[k].alloc(sizeof(PullPlan))); HIP_TRY(hipHostMalloc((void**)&S.plan_host[k], sizeof(PullPlan), hipHostMallocDefault)); }
+  // The cut search stores its triples straight into page-locked host memory (2 KB of posted writes): a copy command behind the kernel costs more
+  // idle device than the transfer (the search's frontier size travels the same way, api/search.hip.h).  The plan goes the other way as a copy:
+  // every workgroup of the pull kernels reads it, and 500 workgroups fetching it over PCIe take longer than one command.
   HIP_TRY(hipHostMalloc((void**)&S.cut_host, 5 * (PART_MAX + 1) * sizeof(CutEntry), hipHostMallocDefault));
+  std::memset(S.cut_host, 0, 5 * (PART_MAX + 1) * sizeof(CutEntry));
+  HIP_TRY(hipHostGetDevicePointer((void**)&S.cut_mapped, S.cut_host, 0));
   HIP_TRY(hipHostMalloc((void**)&S.small_host, 256 * sizeof(u64), hipHostMallocDefault));
   // the cuts and the parts' buffers, as this GPU addresses them: [parity][lo | hi][part]
   for(int k = 0; k <= S.parts; k++) { S.small_host[k] = (k == S.parts ? ~0ull : P->cut_b[k]); }
@@ -495,8 +501,7 @@ int publish_outputs(PartSearch& S, int par, u64 nb, u64 error, StepInfo* all)
   S.tag_out = (S.tag_out == 0x7FFFFFFFu ? 1 : S.tag_out + 1);
   LAUNCH("cut_search", k_cut_search_seg, 5 * (u64)(S.parts - 1) + 1, BLOCK_THREADS, S.mine<const uint2>(S.lay.lo[par]), (S.wide ? S.mine<const unsigned short>(S.lay.hi[par]) : nullptr),
     S.out_prefix.as<const u64>(), S.mine<const u64>(S.lay.seg_phys[par]), S.out_first_seg.as<const u32>(), nb, S.cuts_dev.as<const u64>(), (u32)S.parts, (u32)(PART_MAX + 1),
-    S.cut_dev.as<CutEntry>());
-  HIP_TRY(hipMemcpyAsync(S.cut_host, S.cut_dev.p, 5 * (PART_MAX + 1) * sizeof(CutEntry), hipMemcpyDeviceToHost, CTX.stream));
+    S.cut_mapped);
   HIP_TRY(hipStreamSynchronize(CTX.stream));                         // this part's step is complete: its outputs may be read, its inputs overwritten
   }
   StepInfo mine;

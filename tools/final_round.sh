@@ -10,7 +10,7 @@ bash tools/pmc_step_kernel.sh ${tag}_pmc_step_target 500000000 --tune emit_budge
 python tools/make_traffic_json.py gpurun_out/${tag}_pmc_step_target/pmc.txt "profiles/${tag}_pmc_step_kernel_target.txt (tools/pmc_step_kernel.sh --tune emit_budget=8589934592)" 500000000 100 44500000000 emit_budget=8589934592
 cp profiles/search_kernel_traffic.json $out/search_kernel_traffic.json          # copy back into profiles/ with the two pmc.txt files
 cd $R
-python -m pytest tests -m gpu -q 2>&1 | tail -4 > $out/gpu_tests.txt; cat $out/gpu_tests.txt
+BWTM_REQUIRE_FRESH_PMC=1 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $out/gpu_tests.txt; cat $out/gpu_tests.txt          # (the PMC passes above are this tree's: a stale profile fails here)
 bash tools/profile_round.sh $tag/prof > $out/profile_round.log 2>&1
 bash tools/pmc_passes.sh $tag/pmc_all sq > /dev/null 2>&1
 cd /tmp; rm -rf /tmp/prof_t
@@ -24,7 +24,11 @@ python bench.py --reads-a 200000000 --reads 50000000 --no-cpu-baseline --target 
 python bench.py --chain 4 --workload mixed --reads 24000000 --no-cpu-baseline --target off --steps 3 > $out/bench_config5_shape.json 2> $out/bench_config5_shape.log
 python bench.py --workload genome --coverage 30 --no-cpu-baseline --target off --no-host --steps 3 > $out/bench_genome30.json 2> $out/bench_genome30.log
 python bench.py --workload genome --coverage 300 --no-cpu-baseline --target off --no-host --steps 3 > $out/bench_genome300.json 2> $out/bench_genome300.log
-for f in bench_default bench_config4_shape bench_config5_shape bench_genome30 bench_genome300; do python3 -c "
+# the merge over partitioned records: contexts of the one GPU standing in for GPUs (per-part kernel times, bytes == the single-GPU stream), one rank, and ranks that share the GPU
+python tools/parts_scale.py --parts 2,4,8 > $out/parts_scale_config2.txt 2>&1; tail -5 $out/parts_scale_config2.txt
+python bench.py --force-dist --search partitioned --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_partitioned_1rank_config2.json 2> $out/bench_partitioned_1rank_config2.log
+python bench.py --gpus 4 --same-device --search partitioned --reads 12000000 --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_partitioned_4proc_same_device_12M.json 2> $out/bench_partitioned_4proc_same_device_12M.log
+for f in bench_default bench_config4_shape bench_config5_shape bench_genome30 bench_genome300 bench_partitioned_1rank_config2 bench_partitioned_4proc_same_device_12M; do python3 -c "
 import json,sys
 try:
     d=json.loads(open('$out/$f.json').read().strip().splitlines()[-1]); t=d.get('target') or {}
