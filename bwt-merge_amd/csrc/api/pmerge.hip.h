@@ -422,6 +422,7 @@ int search_setup(PartSearch& S, bool node_phase)
   // A part holds ~m / parts elements (the cuts balance positions): twice that and some slack, at most everything.  Without the node phase the
   // search begins with ALL roots on the part that owns the "$" suffixes (k-mer cuts: the first).
   S.cap = (S.parts == 1 || !node_phase ? m + 1 : std::min<u64>(m + 1, 2 * (m / S.parts) + 65536));
+  if(g_tune.part_capacity > 0 && (u64)g_tune.part_capacity < S.cap) { S.cap = (u64)g_tune.part_capacity; }      // tests: a part that runs out of room
   if(S.cap >= (1ull << 32)) { return fail(BWTM_EINVAL, "bwtm_part_search: %llu elements per part do not fit the 32-bit indexes of a step", (unsigned long long)S.cap); }
   S.nbl_cap = div_up(S.cap, (u64)FR_BLOCK); S.fcap = S.nbl_cap * FR_BLOCK;
   const u64 limit = (g_tune.range_ratio > 0 ? std::max<u64>(1, std::min<u64>(m / (u64)g_tune.range_ratio, 1ull << 24)) : 0);

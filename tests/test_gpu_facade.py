@@ -137,6 +137,13 @@ def test_cli_one_thread_per_gpu(bwtm, oracle, tmp_path):
         outs[label] = np.fromfile(tmp_path / (label + ".native"), dtype=np.uint8)
     for label in outs:
         assert np.array_equal(outs["one"], outs[label]), label
+    # a part that runs out of room: the default mode repeats the merge with sequence blocks (and says so), -P fails
+    small = dict(os.environ, BWTM_TUNE="part_capacity=500")
+    out = subprocess.run([exe, "-g", "0,0,0", "-i", "plain_default", names[0], names[1], names[2], str(tmp_path / "fallback.native")], capture_output=True, text=True, env=small)
+    assert out.returncode == 0 and out.stderr.count("repeating it with sequence blocks") >= 1, out.stderr[-1500:]
+    assert np.array_equal(outs["one"], np.fromfile(tmp_path / "fallback.native", dtype=np.uint8))
+    out = subprocess.run([exe, "-g", "0,0,0", "-P", "-i", "plain_default", names[0], names[1], names[2], str(tmp_path / "strict.native")], capture_output=True, text=True, env=small)
+    assert out.returncode != 0 and "the merge over partitioned records failed" in out.stderr
     direct = oracle.FMI.from_text(np.concatenate(sets))
     assert np.array_equal(outs["three"][32:32 + direct.nbytes], direct.data)           # header (24 B) + byte count (8 B), then BWT::data
 

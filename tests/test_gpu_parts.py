@@ -200,6 +200,25 @@ def test_a_group_serves_a_chain_of_merges(gpu, oracle):
         check_against_oracle(oracle, sets[k], sets[k + 1], data, be, cum)
 
 
+def test_a_part_that_runs_out_of_room_stops_every_part(gpu, oracle):
+    """Cuts that balance positions do not bound the elements a part holds in a step.  With a capacity of 2000 elements per part (the knob
+    `part_capacity`) some part overflows -- at the expansion of the node levels or in an element step -- says so in the step's exchange, and
+    every part returns from the same collective call: the one that overflowed with BWTM_ENOMEM, the others with BWTM_EPEER; nobody waits."""
+    from bwt_merge_amd import partitioned
+    a = oracle.FMI.from_text(oracle.generate_reads(9801, 24000, 100)); b = oracle.FMI.from_text(oracle.generate_reads(9802, 19000, 100))
+    ha, hb = host(gpu, a), host(gpu, b)
+    for rr in (8, 0):
+        gpu.tune("part_capacity", 2000 if rr else 5000); gpu.tune("range_ratio", rr)      # (from the roots on, part 0 begins with all 19 000 of them)
+        try:
+            with pytest.raises(gpu.BwtmError) as e:
+                partitioned.merge_parts(gpu, ha, hb, 4, kmer=3)
+            assert "bwtm error 3" in str(e.value) and "capacity" in str(e.value), str(e.value)
+        finally:
+            gpu.tune("part_capacity", 0); gpu.tune("range_ratio", 8)
+    data, be, cum, _, _ = merge_parts(gpu, a, b, 4, 3)                   # and the group-less state is clean: the next merge is the oracle's
+    check_against_oracle(oracle, a, b, data, be, cum)
+
+
 def test_part_errors_reach_every_part(gpu, oracle):
     """A part that cannot go on (here: cuts that are not k-mer boundaries, so a trie node crosses one) stops the others with BWTM_EPEER instead
     of leaving them in a barrier; handles of windows are refused by the entry points that walk whole indexes."""
