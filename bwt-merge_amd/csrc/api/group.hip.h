@@ -73,6 +73,9 @@ struct bwtm_group
   Peer peer[PART_MAX];
   // this part's arena (hipMalloc: the pool's mapped blocks cannot be exported), kept across merges
   void* arena = nullptr; u64 arena_bytes = 0; int arena_device = -1;
+  // page-locked staging of this part's searches (the step's plan and cut tables, small vectors): allocated once, not per merge
+  // (a hipHostMalloc takes a fraction of a millisecond; a merge of 1 / 8 of config 2 takes twenty)
+  char* pinned = nullptr;
   double wait_seconds = 0;                         // time spent waiting for peers (statistics)
   // BWTM_GROUP_SERIAL=1 (measurements on ONE GPU whose contexts stand in for GPUs): every compute section of a part -- the kernels between two
   // exchanges -- runs alone on the device, so that a part's kernel times are what its own GPU would need (tools/parts_scale.py)
@@ -159,6 +162,15 @@ struct Turn
   Turn(const Turn&) = delete; Turn& operator=(const Turn&) = delete;
 };
 #define TURN(group) Turn turn_(group); if(turn_.rc != BWTM_OK) { return turn_.rc; }
+
+constexpr u64 GROUP_PINNED_BYTES = 32768;
+
+int group_pinned(bwtm_group* g, char** out)
+{
+  if(!g->pinned) { HIP_TRY(hipHostMalloc((void**)&g->pinned, GROUP_PINNED_BYTES, hipHostMallocDefault)); }
+  *out = g->pinned;
+  return BWTM_OK;
+}
 
 // This part's exported arena: at least `bytes`, zeroed where `zero_bytes` says (from its start); re-published when it had to grow.
 int group_arena(bwtm_group* g, u64 bytes, void** out)
@@ -303,6 +315,7 @@ extern "C" void bwtm_group_free(bwtm_group* g)
 {
   if(!g) { return; }
   for(int h = 0; h < g->parts; h++) { if(g->peer[h].opened) { (void)hipIpcCloseMemHandle(g->peer[h].ptr); } }
+  if(g->pinned) { (void)hipHostFree(g->pinned); }
   if(g->arena) { int dev = 0; (void)hipGetDevice(&dev); (void)hipSetDevice(g->arena_device); (void)hipFree(g->arena); (void)hipSetDevice(dev); }
   if(g->sh) { if(g->mapped) { munmap(g->sh, sizeof(GroupShared)); } else { std::free(g->sh); } }
   delete g;

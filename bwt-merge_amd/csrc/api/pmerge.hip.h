@@ -388,13 +388,10 @@ struct PartSearch
   // page-locked staging
   PullPlan* plan_host[2] = {nullptr, nullptr}; CutEntry* cut_host = nullptr; u64* small_host = nullptr;
   CutEntry* cut_mapped = nullptr;                  // cut_host as the device addresses it
+  NodePiece* node_pieces_host = nullptr;           // (all five: pieces of the group's page-locked block)
+  u64 step_limit = 0;                              // elements a step may hold (= cap unless a test lowers it)
+  std::string own_error;                           // what this part said when it ran out of room (it learns of its own stop from the exchange like everybody)
   u32 tag_in = 1, tag_out = 1;
-  ~PartSearch()
-  {
-    for(int k = 0; k < 2; k++) { if(plan_host[k]) { (void)hipHostFree(plan_host[k]); } }
-    if(cut_host) { (void)hipHostFree(cut_host); }
-    if(small_host) { (void)hipHostFree(small_host); }
-  }
   template<class T> T* mine(u64 off) const { return (T*)(arena + off); }
   template<class T> T* theirs(int h, u64 off) const { return (T*)(peer[h] + off); }
 };
@@ -423,6 +420,7 @@ int search_setup(PartSearch& S, bool node_phase)
   // search begins with ALL roots on the part that owns the "$" suffixes (k-mer cuts: the first).
   S.cap = (S.parts == 1 || !node_phase ? m + 1 : std::min<u64>(m + 1, 2 * (m / S.parts) + 65536));
   if(g_tune.part_capacity > 0 && (u64)g_tune.part_capacity < S.cap) { S.cap = (u64)g_tune.part_capacity; }      // tests: a part that runs out of room
+  S.step_limit = (g_tune.part_capacity < 0 ? std::min<u64>(S.cap, (u64)(-g_tune.part_capacity)) : S.cap);
   if(S.cap >= (1ull << 32)) { return fail(BWTM_EINVAL, "bwtm_part_search: %llu elements per part do not fit the 32-bit indexes of a step", (unsigned long long)S.cap); }
   S.nbl_cap = div_up(S.cap, (u64)FR_BLOCK); S.fcap = S.nbl_cap * FR_BLOCK;
   const u64 limit = (g_tune.range_ratio > 0 ? std::max<u64>(1, std::min<u64>(m / (u64)g_tune.range_ratio, 1ull << 24)) : 0);
@@ -452,14 +450,16 @@ int search_setup(PartSearch& S, bool node_phase)
   TRY(S.dummy_emit.alloc(2 * 8, true));
   TRY(S.cuts_dev.alloc((S.parts + 1) * 8));
   TRY(S.srcs.alloc(4 * PART_MAX * sizeof(void*)));
-  for(int k = 0; k < 2; k++) { TRY(S.plan_dev[k].alloc(sizeof(PullPlan))); HIP_TRY(hipHostMalloc((void**)&S.plan_host[k], sizeof(PullPlan), hipHostMallocDefault)); }
+  static_assert(sizeof(PullPlan) <= 4096 && 5 * (PART_MAX + 1) * sizeof(CutEntry) <= 4096 && 5 * PART_MAX * sizeof(NodePiece) <= 4096 && GROUP_PINNED_BYTES >= 5 * 4096 + 2048, "the group's page-locked block");
+  char* pinned = nullptr;
+  TRY(group_pinned(S.G, &pinned));
+  for(int k = 0; k < 2; k++) { TRY(S.plan_dev[k].alloc(sizeof(PullPlan))); S.plan_host[k] = (PullPlan*)(pinned + 4096 * k); }
+  S.cut_host = (CutEntry*)(pinned + 8192); S.small_host = (u64*)(pinned + 12288); S.node_pieces_host = (NodePiece*)(pinned + 16384);
   // The cut search stores its triples straight into page-locked host memory (2 KB of posted writes): a copy command behind the kernel costs more
   // idle device than the transfer (the search's frontier size travels the same way, api/search.hip.h).  The plan goes the other way as a copy:
   // every workgroup of the pull kernels reads it, and 500 workgroups fetching it over PCIe take longer than one command.
-  HIP_TRY(hipHostMalloc((void**)&S.cut_host, 5 * (PART_MAX + 1) * sizeof(CutEntry), hipHostMallocDefault));
   std::memset(S.cut_host, 0, 5 * (PART_MAX + 1) * sizeof(CutEntry));
   HIP_TRY(hipHostGetDevicePointer((void**)&S.cut_mapped, S.cut_host, 0));
-  HIP_TRY(hipHostMalloc((void**)&S.small_host, 256 * sizeof(u64), hipHostMallocDefault));
   // the cuts and the parts' buffers, as this GPU addresses them: [parity][lo | hi][part]
   for(int k = 0; k <= S.parts; k++) { S.small_host[k] = (k == S.parts ? ~0ull : P->cut_b[k]); }
   HIP_TRY(hipMemcpyAsync(S.cuts_dev.p, S.small_host, (S.parts + 1) * 8, hipMemcpyHostToDevice, CTX.stream));
@@ -509,7 +509,8 @@ int publish_outputs(PartSearch& S, int par, u64 nb, u64 error, StepInfo* all)
   mine.nb = nb; mine.error = error;
   std::memcpy(mine.cut, S.cut_host, sizeof(mine.cut));
   TRY(group_allgather(S.G, &mine, sizeof(StepInfo), all));
-  for(int h = 0; h < S.parts; h++) { if(all[h].error != 0) { return fail(BWTM_EPEER, "part %d stopped the search (error %llu)%s", h, (unsigned long long)all[h].error, h == S.g ? ": see its own message" : ""); } }
+  if(all[S.g].error != 0) { return fail(BWTM_ENOMEM, "%s", S.own_error.c_str()); }
+  for(int h = 0; h < S.parts; h++) { if(all[h].error != 0) { return fail(BWTM_EPEER, "part %d ran out of room and stopped the search", h); } }
   return BWTM_OK;
 }
 
@@ -557,9 +558,7 @@ int node_phase(PartSearch& S, u64 root_first, u64 root_count, u64 limit, u64& nb
   TRY(pieces.alloc((u64)piece_cap * sizeof(RangePiece))); TRY(npieces.alloc(sizeof(u32), true));
   TRY(class_first.alloc(6 * 8)); TRY(below.alloc(5ull * (S.parts + 1) * 8, true)); TRY(err.alloc(sizeof(u32), true));
   TRY(gather_pieces.alloc(5ull * PART_MAX * sizeof(NodePiece)));
-  NodePiece* host_pieces = nullptr;
-  HIP_TRY(hipHostMalloc((void**)&host_pieces, 5ull * PART_MAX * sizeof(NodePiece), hipHostMallocDefault));
-  struct Free { NodePiece* p; ~Free() { (void)hipHostFree(p); } } free_pieces{host_pieces};
+  NodePiece* host_pieces = S.node_pieces_host;
   const u32 ncuts = (u32)S.parts + 1;
   u64 N = 0;
   if(root_count > 0) { LAUNCH("range_init", k_range_init, 1, BLOCK_THREADS, sp.as<u64>(), r.as<u64>(), cnt.as<u64>(), root_first, root_count, P->ma); N = 1; }
@@ -711,10 +710,11 @@ int part_search(PartSearch& S)
       const int src = ((int)h < S.parts ? (int)h : S.g);
       plan->seg_len[h] = S.theirs<const u64>(src, S.peer_lay[src].seg_len[par]); plan->seg_phys[h] = S.theirs<const u64>(src, S.peer_lay[src].seg_phys[par]);
     }
-    if(n_in > S.cap)
+    if(n_in > S.step_limit)
     {
       // everybody learns it at the next exchange and stops there; this part idles through the step
-      (void)fail(BWTM_ENOMEM, "bwtm_part_search: %llu elements fall into part %d's range in step %llu, capacity %llu", (unsigned long long)n_in, S.g, (unsigned long long)t, (unsigned long long)S.cap);
+      (void)fail(BWTM_ENOMEM, "bwtm_part_search: %llu elements fall into part %d's range in step %llu, capacity %llu", (unsigned long long)n_in, S.g, (unsigned long long)t, (unsigned long long)S.step_limit);
+      S.own_error = g_error;
       pending_error = 3; n_in = 0; nseg_in = 0; plan->npieces = 0; plan->nseg = 0;
     }
     if(nseg_in > S.seg_in_cap)

@@ -338,7 +338,10 @@ int bwtm_slice_extract(bwtm_slice* slice, uint64_t first, uint64_t count, uint8_
        bwtm_part_free(part);
 
    The concatenation of the parts' slices is bit-identical to bwtm_merge() of the whole inputs.  When a part fails, the others return
-   BWTM_EPEER from their next collective step instead of waiting for it (and every wait has a deadline: BWTM_GROUP_TIMEOUT seconds, 300). */
+   BWTM_EPEER from their next collective step instead of waiting for it (and every wait has a deadline: BWTM_GROUP_TIMEOUT seconds, 300).
+   A part that runs out of room -- the cuts balance positions, which does not bound the elements of a skewed collection -- returns BWTM_ENOMEM and
+   the others BWTM_EPEER, all from the same step: the caller repeats the merge another way (csrc/host/multi_gpu.h: sequence blocks).  A group
+   that has seen a failure stays failed: free it and create another. */
 
 #define BWTM_MAX_PARTS 16
 typedef struct bwtm_group bwtm_group;

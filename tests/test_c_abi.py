@@ -76,3 +76,13 @@ def test_struct_layouts_of_the_binding_match_the_headers(bwtm, tmp_path):
     assert max_parts == experimental.MAX_PARTS
     assert ctypes.sizeof(V) == size
     assert V.totals.offset == off_totals and V.below.offset == off_below and V.class_first.offset == off_class_first
+    # the structs of the merge over partitioned records (round 6)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "bwtm.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %d\\n", sizeof(bwtm_host_index), offsetof(bwtm_host_index, cum), offsetof(bwtm_host_index, C),\n'
+                   '  sizeof(bwtm_index_header), sizeof(bwtm_part_info), offsetof(bwtm_part_info, ms_search), offsetof(bwtm_part_info, record_bytes), BWTM_MAX_PARTS); return 0; }\n')
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    size_hi, off_cum, off_C, size_hdr, size_info, off_ms, off_rec, max_parts = (int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split())
+    assert ctypes.sizeof(capi.HostIndex) == size_hi and capi.HostIndex.cum.offset == off_cum and capi.HostIndex.C.offset == off_C
+    assert ctypes.sizeof(capi.IndexHeader) == size_hdr
+    assert ctypes.sizeof(capi.PartInfo) == size_info and capi.PartInfo.ms_search.offset == off_ms and capi.PartInfo.record_bytes.offset == off_rec
+    assert max_parts == 16

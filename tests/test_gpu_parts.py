@@ -207,8 +207,10 @@ def test_a_part_that_runs_out_of_room_stops_every_part(gpu, oracle):
     from bwt_merge_amd import partitioned
     a = oracle.FMI.from_text(oracle.generate_reads(9801, 24000, 100)); b = oracle.FMI.from_text(oracle.generate_reads(9802, 19000, 100))
     ha, hb = host(gpu, a), host(gpu, b)
-    for rr in (8, 0):
-        gpu.tune("part_capacity", 2000 if rr else 5000); gpu.tune("range_ratio", rr)      # (from the roots on, part 0 begins with all 19 000 of them)
+    # at the expansion of the node levels / at the roots (part 0 begins with all 19 000 of them) / in an element step (a negative value holds only
+    # the steps to it: the part says so in the step's exchange and idles through the step, every part stops at the next exchange)
+    for rr, capacity in ((8, 2000), (0, 5000), (8, -3000), (0, -6000)):
+        gpu.tune("part_capacity", capacity); gpu.tune("range_ratio", rr)
         try:
             with pytest.raises(gpu.BwtmError) as e:
                 partitioned.merge_parts(gpu, ha, hb, 4, kmer=3)
