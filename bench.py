@@ -273,7 +273,13 @@ def measure(env, args):
         from bwt_merge_amd import partitioned as bwtm_parts
         if nsets != 2:
             raise SystemExit("--search partitioned measures single merges (--chain 2)")
-        gname = ("/bwtm-bench-" + os.environ.get("BWTM_GROUP_TAG", str(os.getpid()))) if world > 1 else None
+        gname = None
+        if world > 1:
+            # one shared-memory name for all ranks, whoever launched them (bench.py itself, torch.distributed.run): rank 0 makes it up and the
+            # process group carries it to the others (a name derived from the environment could meet a leftover of an earlier run)
+            obj = ["/bwtm-bench-%d-%x" % (os.getpid(), int(time.time() * 1e6) & 0xFFFFFFFFFF) if rank == 0 else None]
+            dist.broadcast_object_list(obj, src=0, device=(args.coll_dev if args.same_device else dev))
+            gname = obj[0]
         group = pkg.Group(gname, rank, world)
         hidx = [pkg.host_index(host_in[k].array, meta[k]["cum"], meta[k]["sequences"], meta[k]["bases"]) for k in range(2)]
         cuts0 = pkg.partition_cuts_host(hidx[0], hidx[1], world)
@@ -695,8 +701,7 @@ def launch_ranks(world, same_device=False):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if same_device else r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
-                   BWTM_GROUP_TAG="%d-%d" % (os.getpid(), port))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=(None if r == 0 else subprocess.DEVNULL)))
     rc = 0

@@ -123,6 +123,17 @@ def test_bench_partitioned_between_processes_on_one_gpu(bwtm):
     assert d["host_to_host"]["bytes"]["h2d_this_rank"] < d["host_to_host"]["bytes"]["h2d_all_inputs"]
 
 
+def test_bench_partitioned_under_the_drivers_launcher_on_one_gpu(bwtm):
+    """The same with the ranks started the way the driver starts them (python -m torch.distributed.run ... bench.py --gpus N): nothing of bench.py's
+    own launcher is in the environment, and the ranks still meet in one group (rank 0 makes the shared-memory name up, the process group carries it)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29519",
+           "bench.py", "--gpus", "2", "--same-device", "--search", "partitioned", "--reads", "1500000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-host"]
+    d = run_bench(cmd)
+    if d["verified"] is not True:
+        d = run_bench(cmd)                                              # (processes that share a GPU: see the test above)
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["verified"] is True and d["config"]["search"] == "partitioned" and d["config"]["partitioned_fallback"] is None
+
+
 def test_bench_chained_merge_of_four_sets(bwtm):
     """BASELINE config 5's shape: four sets of mixed 100 / 150 bp reads merged in command-line order, intermediate results
     device-resident; reads extracted from the final index equal the four generators'."""
