@@ -207,6 +207,26 @@ int upload_validate(bwtm_index* x, u64 sequences, u64 bases, const u64* C, u32 s
   return BWTM_OK;
 }
 
+// The records of an index (or of a window of it: `held` positions from the share's first one up to n_end, records addressed through a shifted
+// pointer) from its native bytes, block lengths and scanned group tables.  One wave per group; the LDS window is sized to the positions a group
+// covers on average (iid reads: ~5300).  BWTM_TUNE=recs_window=... picks the window.
+int build_records(bwtm_index* x, u64 held, u64 n_end, uint4* recs, u64 nrecs)
+{
+  const u64 gstride = x->ngroups + 1;
+  const u64 per_group = held / x->ngroups;
+  const bool long_runs = (x->nblocks > 0 && held / x->nblocks > 400);        // > ~6 positions per byte: cooperative fill of long runs pays
+#define BUILD_RECS(W, WAVES, FILL) LAUNCH("build_recs", (k_build_recs<W, WAVES, FILL>), div_up(x->ngroups, WAVES), WAVES * WAVE, \
+    x->native_bytes(), x->nbytes, x->blen.as<const u64>(), x->block_start.as<u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, n_end, \
+    x->sup.as<const u64>(), recs, nrecs)
+  const u64 window = (g_tune.recs_window != 0 ? (u64)g_tune.recs_window : (per_group <= 6500 ? 8192 : (per_group <= 14000 ? 16384 : 32768)));
+  if(window == 8192) { BUILD_RECS(8192, 4, false); }
+  else if(window == 16384) { BUILD_RECS(16384, 4, false); }
+  else if(!long_runs) { BUILD_RECS(32768, 2, false); }
+  else { BUILD_RECS(32768, 2, true); }
+#undef BUILD_RECS
+  return BWTM_OK;
+}
+
 // Step 4.  Records + super table from the native stream (needs x->n; C is not used by the kernels).
 int transcode(bwtm_index* x)
 {
@@ -217,18 +237,7 @@ int transcode(bwtm_index* x)
   LAUNCH("build_sup", k_build_sup, div_up(x->nsup * WAVE, BLOCK_THREADS), BLOCK_THREADS,   // one wave per super
     x->native_bytes(), x->nbytes, x->blen.as<const u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, x->n,
     x->sup.as<u64>(), x->nsup);
-  // one wave per group; LDS window sized to the positions a group covers on average (iid reads: ~5300)
-  const u64 per_group = x->n / x->ngroups;
-  const bool long_runs = (x->nblocks > 0 && x->n / x->nblocks > 400);        // > ~6 positions per byte: cooperative fill of long runs pays
-#define BUILD_RECS(W, WAVES, FILL) LAUNCH("build_recs", (k_build_recs<W, WAVES, FILL>), div_up(x->ngroups, WAVES), WAVES * WAVE, \
-    x->native_bytes(), x->nbytes, x->blen.as<const u64>(), x->block_start.as<u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, x->n, \
-    x->sup.as<const u64>(), x->recs.as<uint4>(), x->nrecs)
-  const u64 window = (g_tune.recs_window != 0 ? (u64)g_tune.recs_window : (per_group <= 6500 ? 8192 : (per_group <= 14000 ? 16384 : 32768)));
-  if(window == 8192) { BUILD_RECS(8192, 4, false); }
-  else if(window == 16384) { BUILD_RECS(16384, 4, false); }
-  else if(!long_runs) { BUILD_RECS(32768, 2, false); }
-  else { BUILD_RECS(32768, 2, true); }
-#undef BUILD_RECS
+  TRY(build_records(x, x->n, x->n, x->recs.as<uint4>(), x->nrecs));
   x->blen.release();                                             // (stream ordered) the block starts are in block_start now
   return BWTM_OK;
 }

@@ -74,17 +74,7 @@ int index_upload_window(const u8* data, u64 nbytes, u64 first_position, const u6
     LAUNCH("build_sup", k_build_sup, div_up(x->nsup * WAVE, BLOCK_THREADS), BLOCK_THREADS,
       x->native_bytes(), x->nbytes, x->blen.as<const u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, end_position, x->sup.as<u64>(), x->nsup);
     uint4* shifted = (uint4*)((char*)x->recs.p - (q0 << 6));
-    const u64 per_group = held / x->ngroups;
-    const bool long_runs = (x->nblocks > 0 && held / x->nblocks > 400);
-#define BUILD_RECS_W(W, WAVES, FILL) LAUNCH("build_recs", (k_build_recs<W, WAVES, FILL>), div_up(x->ngroups, WAVES), WAVES * WAVE, \
-    x->native_bytes(), x->nbytes, x->blen.as<const u64>(), x->block_start.as<u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, end_position, \
-    x->sup.as<const u64>(), shifted, q_end)
-    const u64 window = (g_tune.recs_window != 0 ? (u64)g_tune.recs_window : (per_group <= 6500 ? 8192 : (per_group <= 14000 ? 16384 : 32768)));
-    if(window == 8192) { BUILD_RECS_W(8192, 4, false); }
-    else if(window == 16384) { BUILD_RECS_W(16384, 4, false); }
-    else if(!long_runs) { BUILD_RECS_W(32768, 2, false); }
-    else { BUILD_RECS_W(32768, 2, true); }
-#undef BUILD_RECS_W
+    TRY(build_records(x, held, end_position, shifted, q_end));
     HIP_TRY(hipStreamSynchronize(CTX.stream));                       // a borrowed share may go back to its owner
     x->blen.release(); x->block_start.release(); x->gcum.release(); x->data.release();          // a window keeps its records and super rows only
     x->borrowed = nullptr;

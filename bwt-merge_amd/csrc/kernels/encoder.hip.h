@@ -593,15 +593,20 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 4) k_enc_emit(const uint4* recs
     }
     else
     {
-      // Some runs of >= 42 end in this chunk.  Their sizes depend on their byte offsets, so they are resolved
-      // in order (a handful per chunk); every other event is one byte at (its event index + the extra bytes
-      // of the long events before it), and all lanes write their tiles in parallel as above.
+      // Some runs of >= 42 end in this chunk.  The sizes of the longest ones depend on their byte offsets, so those are resolved in order (a
+      // handful per chunk); every other event sits at (its event index + the extra bytes of the long events before it).
+      // Round 6: a long event is always the FIRST event of its 32-position half of the tile (a head that ends a run of >= 42 has no head among
+      // the 41 positions before it; if it is not the tile's first head, the head before it lies >= 42 positions back, in the low half, and it
+      // lies in the high half itself).  So a half is [one long event] + one-byte events: the long event is written by the lane on its own and the
+      // one-byte events go through walk_half like those of a chunk without long runs, from the state behind the long event.  Until then the lanes
+      // walked ALL heads of a slow chunk one by one in a divergent loop of three cases: on reads of a genome -- a long run in nearly every
+      // chunk -- k_enc_emit took 10 ms for a stream of 2 GB where the 7.6 GB of an iid stream take 4.7.
       u8* lds = stage_lds;
       const u32 a = (u32)(off & 15);
       const u64 origin = off - a;                                      // stream offset of lds[0]
       const u32 ev_excl = (u32)(ev_incl - nev);
       // extra bytes of all long events / of those in earlier tiles: one per run of 42 .. 82 (a wave scan), and what the ordered walk over the
-      // longer runs adds (round 6; see tile_event_stats)
+      // longer runs adds (see tile_event_stats)
       const u32 two = (u32)__builtin_popcountll(long_mask) - (dep_len != 0 ? 1u : 0u);
       const u32 two_incl = wave_incl_sum32(two);
       u32 extra = (u32)__builtin_amdgcn_readlane((int)two_incl, WAVE - 1), shift = two_incl - two;
@@ -615,59 +620,91 @@ __global__ void __launch_bounds__(BLOCK_THREADS, 4) k_enc_emit(const uint4* recs
         });
         extra += dep_extra;
       }
-      if(ti.H != 0)
+      const u64 tb = T << 6;
+      const u32 idx0 = a + ev_excl + shift;                             // staging index of the tile's first byte
+      const u32 h_lo = (u32)ti.H, e_lo = (u32)ti.E, e_hi = (u32)(ti.E >> 32);
+      const u32 long_lo = (u32)long_mask, long_hi = (u32)(long_mask >> 32);
+      const bool at_zero = (tb == 0 && (h_lo & 1u) != 0);
+      const int prev_lo0 = (at_zero ? 0 : (int)(u32)(before - 1 - tb));  // as in the branch above
+      int prev_lo = prev_lo0;
+      u32 sym_lo = (at_zero ? ((u32)(ti.p0 & 1) | ((u32)(ti.p1 & 1) << 1) | ((u32)(ti.p2 & 1) << 2)) : ti.prev);
+      int prev_hi = (h_lo != 0 ? 31 - (int)__builtin_clz(h_lo) : prev_lo0) - 32;
+      u32 sym_hi = (u32)((ti.p0 >> 31) & 1) | ((u32)((ti.p1 >> 31) & 1) << 1) | ((u32)((ti.p2 >> 31) & 1) << 2);
+      // The long event at in-tile bit b, whose run began at position prev1 - 1, written at staging index idx; returns its bytes.
+      auto write_long = [&](u32 b, u64 prev1, u32 idx, bool dep) -> u32
       {
-        const u64 tb = T << 6;
-        u32 idx = a + ev_excl + shift;
-        u64 h = ti.H;
-        const u32 b0 = (u32)__builtin_ctzll(h);
-        u64 prev1;                                                     // (previous head) + 1
-        u32 run_sym;
-        if(tb + b0 == 0) { h &= h - 1; prev1 = 1; run_sym = (u32)(ti.p0 & 1) | ((u32)(ti.p1 & 1) << 1) | ((u32)(ti.p2 & 1) << 2); }
-        else { prev1 = before; run_sym = event_symbol(ti, b0); }
-        while(h)
+        const u32 run_sym = event_symbol(ti, b);
+        const u64 len = tb + b + 1 - prev1;
+        if(dep)
         {
-          const u32 b = (u32)__builtin_ctzll(h); h &= h - 1;
-          const u64 pos = tb + b, len = pos + 1 - prev1;
-          if(((long_mask >> b) & 1) && len < DEP_RUN)
+          return (u32)long_run_write_cb(lds, origin + idx, run_sym, len, prev1 - 1, origin, [&](u64 blk, u64 p)
           {
-            // a run of 42 .. 82: head (basic length 42) + one extension byte, or -- when the head is the last byte of its block -- a run of 41
-            // and a run of length - 41 that opens the next block (support.h:267-279; long_run_write_cb for these lengths, written out)
-            const u64 at = origin + idx;
-            const bool edge = ((at & (RLE_BLOCK - 1)) == RLE_BLOCK - 1);
-            if((at & (RLE_BLOCK - 1)) == 0)
-            {
-              block_start[at >> 6] = prev1 - 1;
-              if(CUM) { store_cum_at(at >> 6, prev1 - 1, b, run_sym); }
-            }
-            lds[idx] = (u8)(run_sym + 6 * (edge ? MAX_RUN - 2 : MAX_RUN - 1));
-            lds[idx + 1] = (u8)(edge ? run_sym + 6 * (len - MAX_RUN) : len - MAX_RUN);
-            if(edge)
-            {
-              block_start[(at + 1) >> 6] = prev1 - 1 + (MAX_RUN - 1);
-              if(CUM) { store_cum_at((at + 1) >> 6, prev1 - 1 + (MAX_RUN - 1), b, run_sym); }
-            }
-            idx += 2;
-          }
-          else if((long_mask >> b) & 1)
-          {
-            idx += (u32)long_run_write_cb(lds, origin + idx, run_sym, len, prev1 - 1, origin, [&](u64 blk, u64 p)
-            {
-              block_start[blk] = p;
-              if(CUM) { store_cum_at(blk, p, b, run_sym); }
-            });
-          }
-          else
-          {
-            if(((origin + idx) & (RLE_BLOCK - 1)) == 0)
-            {
-              block_start[(origin + idx) >> 6] = prev1 - 1;
-              if(CUM) { store_cum_at((origin + idx) >> 6, prev1 - 1, b, run_sym); }
-            }
-            lds[idx++] = (u8)(run_sym + 6 * (len - 1));
-          }
-          run_sym = (u32)((ti.p0 >> b) & 1) | ((u32)((ti.p1 >> b) & 1) << 1) | ((u32)((ti.p2 >> b) & 1) << 2);
-          prev1 = pos + 1;
+            block_start[blk] = p;
+            if(CUM) { store_cum_at(blk, p, b, run_sym); }
+          });
+        }
+        // a run of 42 .. 82: head (basic length 42) + one extension byte, or -- when the head is the last byte of its block -- a run of 41
+        // and a run of length - 41 that opens the next block (support.h:267-279; long_run_write_cb for these lengths, written out)
+        const u64 at = origin + idx;
+        const bool edge = ((at & (RLE_BLOCK - 1)) == RLE_BLOCK - 1);
+        if((at & (RLE_BLOCK - 1)) == 0)
+        {
+          block_start[at >> 6] = prev1 - 1;
+          if(CUM) { store_cum_at(at >> 6, prev1 - 1, b, run_sym); }
+        }
+        lds[idx] = (u8)(run_sym + 6 * (edge ? MAX_RUN - 2 : MAX_RUN - 1));
+        lds[idx + 1] = (u8)(edge ? run_sym + 6 * (len - MAX_RUN) : len - MAX_RUN);
+        if(edge)
+        {
+          block_start[(at + 1) >> 6] = prev1 - 1 + (MAX_RUN - 1);
+          if(CUM) { store_cum_at((at + 1) >> 6, prev1 - 1 + (MAX_RUN - 1), b, run_sym); }
+        }
+        return 2u;
+      };
+      u32 w_lo = e_lo, w_hi = e_hi;                                    // the one-byte events of the halves
+      u32 sz_lo = 0, sz_hi = 0;                                        // bytes of the halves' long events
+      if(long_lo != 0)
+      {
+        // the tile's first head (and first event): its run began before the tile
+        const u32 b = (u32)__builtin_ctz(long_lo);
+        sz_lo = write_long(b, before, idx0, dep_len != 0);
+        w_lo = e_lo & ~long_lo; prev_lo = (int)b;
+        sym_lo = (u32)((ti.p0 >> b) & 1) | ((u32)((ti.p1 >> b) & 1) << 1) | ((u32)((ti.p2 >> b) & 1) << 2);
+      }
+      const u32 ns_lo = (u32)__builtin_popcount(w_lo);
+      const u32 bytes_lo = sz_lo + ns_lo;
+      if(long_hi != 0)
+      {
+        // the first event of the high half: its run began at the last head of the low half, or before the tile when that half has none
+        const u32 b = 32u + (u32)__builtin_ctz(long_hi);
+        const u64 prev1 = (h_lo != 0 ? tb + (u64)(31 - (int)__builtin_clz(h_lo)) + 1 : before);
+        sz_hi = write_long(b, prev1, idx0 + bytes_lo, dep_len != 0 && h_lo == 0);
+        w_hi = e_hi & ~long_hi; prev_hi = (int)b - 32;
+        sym_hi = (u32)((ti.p0 >> b) & 1) | ((u32)((ti.p1 >> b) & 1) << 1) | ((u32)((ti.p2 >> b) & 1) << 2);
+      }
+      const u32 ns_hi = (u32)__builtin_popcount(w_hi);
+      const u32 trips_lo = (wave_max32(ns_lo) + (ENC_WALK - 1)) & ~(ENC_WALK - 1), trips_hi = (wave_max32(ns_hi) + (ENC_WALK - 1)) & ~(ENC_WALK - 1);
+      walk_half(w_lo, (u32)ti.p0, (u32)ti.p1, (u32)ti.p2, prev_lo, sym_lo, stage_addr + idx0 + sz_lo, trips_lo);
+      walk_half(w_hi, (u32)(ti.p0 >> 32), (u32)(ti.p1 >> 32), (u32)(ti.p2 >> 32), prev_hi, sym_hi, stage_addr + idx0 + bytes_lo + sz_hi, trips_hi);
+      // The one-byte events that open a 64-byte block (the long events have looked after theirs): the tile's bytes are
+      // [long event of the low half][its one-byte events][long event of the high half][its one-byte events], at most two block starts among them.
+      {
+        const u32 tile_bytes = bytes_lo + sz_hi + ns_hi;
+        const u32 phase = (u32)(origin & (RLE_BLOCK - 1));               // byte (origin + idx) opens a block iff ((phase + idx) & 63) == 0
+        const u64 shorts = (u64)w_lo | ((u64)w_hi << 32);
+        for(u32 k = (0u - (phase + idx0)) & (u32)(RLE_BLOCK - 1); k < tile_bytes; k += (u32)RLE_BLOCK)
+        {
+          u32 rank;
+          if(k < sz_lo) { continue; }
+          else if(k < bytes_lo) { rank = k - sz_lo; }
+          else if(k < bytes_lo + sz_hi) { continue; }
+          else { rank = k - sz_lo - sz_hi; }
+          const u32 ebit = select64(shorts, rank);
+          const u64 hb = ti.H & ((1ull << ebit) - 1);                     // heads before the event
+          const int open_prev = (hb != 0 ? 63 - (int)__builtin_clzll(hb) : prev_lo0);
+          const u64 blk = (origin + idx0 + k) >> 6, p = tb + (u64)(long long)open_prev;
+          block_start[blk] = p;
+          if(CUM) { store_cum_at(blk, p, (open_prev >= 0 ? (u32)open_prev : ebit), ti.prev); }
         }
       }
       flush_chunk(lds, a, a + (u32)chunk_events + extra, origin);

@@ -304,7 +304,11 @@ constexpr u32 BR_FILLS = 256;
 // (Round 6 measured a RUN-parallel deposit for the streams of longer runs -- every lane stores the window-relative end of each byte's run, then
 // the group's 64 x 64 bytes are dealt out round-robin and every run ORs its own edge words into the planes: no accumulators, no divergent
 // flushes.  It lost: 14.8 vs 12.1 ms at 300 x genome reads, 13.6 vs 8.2 at 30 x; four times the LDS atomics at 1.5 waves per SIMD.  So did
-// smaller windows with more waves: 16 384 / 8 192 positions 17.2 / 21.0 vs 12.1 ms.  DESIGN_HISTORY.md, round 6.)
+// smaller windows with more waves: 16 384 / 8 192 positions 17.2 / 21.0 vs 12.1 ms.  And so did a GATHER per record: pass 1 stores for every byte
+// the position its run ends at (64 x 64 entries per wave in LDS), pass 2 gives every lane a record: a binary search for its first entry, then a
+// walk that builds the record's twelve words in registers, one mask per run and word -- no atomics, no planes in LDS.  Bit-exact in all parity
+// tests, and slower everywhere: 13.0 vs 12.3 ms at 300 x, 12.9 vs 8.2 at 30 x, 8.0 vs 1.8 on iid reads (2 x 20 M): the walk is a loop of
+// dependent LDS reads whose trip count differs from lane to lane, at 2 waves per SIMD.  DESIGN_HISTORY.md, round 6.)
 template<u32 BR_WINDOW, int WAVES, bool FILL>
 __global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64 nbytes, const u64* blen, u64* block_start,
   const u64* gcum, u64 gstride, u64 nblocks, u64 ngroups, u64 n, const u64* sup, uint4* recs, u64 nrecs)

@@ -240,7 +240,7 @@ def test_empty_increment_and_empty_base(gpu, oracle):
     assert np.array_equal(gpu.merge(E, A).data(), a.data)
 
 
-@pytest.mark.parametrize("case", ["mixed", "boundaries", "sparse_long", "genome_like", "giant", "tiny", "alternating"])
+@pytest.mark.parametrize("case", ["mixed", "boundaries", "sparse_long", "genome_like", "halves", "giant", "tiny", "alternating"])
 def test_encoder_block_rule(gpu, oracle, case):
     """Run::write's offset-dependent forms (support.h:256-282), including runs that end in
     chunks far from where they start, against the oracle's encoder."""
@@ -262,6 +262,13 @@ def test_encoder_block_rule(gpu, oracle, case):
         syms = [run_symbols(rng, 300000, [3, 5, 9, 14, 20, 30, 41, 42, 50, 64, 82, 83, 84, 100, 169, 170, 300]),
                 run_symbols(rng, 200000, [41, 42, 43, 81, 82, 83, 84, 1, 2]),
                 run_symbols(rng, 150000, [12] * 8 + [20] * 8 + [45, 60, 82] * 2 + [83, 126, 211, 5000])]
+    elif case == "halves":
+        # k_enc_emit writes the long event that opens a 32-position half of a tile on its own and the one-byte events behind it through the
+        # wave-uniform walk: long events in the low half, in the high half (as the tile's first head and behind a head of the low half), tiles
+        # of more than 64 bytes (sixty one-byte events and a long one: two block starts in one tile), every offset mod 64
+        syms = [run_symbols(rng, 500000, [1, 1, 1, 1, 2, 42, 43, 44, 50, 63, 64, 65]),
+                run_symbols(rng, 400000, [1] * 40 + [42, 83, 200]),
+                run_symbols(rng, 300000, [1] * 12 + [2, 3, 31, 32, 33, 42, 52, 62, 82, 83, 90, 1000, 70000])]
     elif case == "giant":
         syms = [np.full(5_000_000, 3, dtype=np.uint8),
                 np.concatenate([np.full(70000, 1, np.uint8), np.full(1, 2, np.uint8), np.full(4096 * 64 * 16 + 5, 4, np.uint8)])]
