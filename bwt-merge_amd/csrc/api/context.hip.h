@@ -94,6 +94,7 @@ struct Tuning
   long long frontier_parts = 0;           // > 1: every step of the frontier search as this many launches over slices of the frontier (a measurement, same results)
   long long part_capacity = 0;            // tests: elements a part of the partitioned merge can hold in a step (0 = 2 m / parts + slack): forces the out-of-room
                                           // paths; negative: only the element steps are held to |value| (the roots and the expansion of the node levels are not)
+  long long recs_uniform = 0;             // k_build_recs: the straight-line deposit for streams of longer runs: 1 always, -1 never, 0 = by the stream's density
   long long recs_window = 0;              // k_build_recs: positions per LDS window (8192 / 16384 / 32768); 0 = by the stream's density (A/B measurements)
   long long ingest_verify = 0;            // 1 = the builder checks every leaf's suffix order against the reads (one extra pass of gathers per leaf)
 #ifdef BWTM_DIAGNOSTICS
@@ -636,6 +637,7 @@ int tune_set(const char* key, long long value)
   else if(k == "frontier_parts") { g_tune.frontier_parts = (value > 0 ? value : 0); }
   else if(k == "ingest_verify") { g_tune.ingest_verify = (value != 0); }
   else if(k == "part_capacity") { g_tune.part_capacity = value; }
+  else if(k == "recs_uniform") { g_tune.recs_uniform = (value > 0 ? 1 : (value < 0 ? -1 : 0)); }
   else if(k == "recs_window") { g_tune.recs_window = (value == 8192 || value == 16384 || value == 32768 ? value : 0); }
   else if(k == "eager_cum_budget") { g_tune.eager_cum_budget = (value > 0 ? value : (16ll << 30)); }
   else if(k == "upload_chunk") { g_tune.upload_chunk = (value > 0 ? value : (256ll << 20)); }

@@ -209,20 +209,22 @@ int upload_validate(bwtm_index* x, u64 sequences, u64 bases, const u64* C, u32 s
 
 // The records of an index (or of a window of it: `held` positions from the share's first one up to n_end, records addressed through a shifted
 // pointer) from its native bytes, block lengths and scanned group tables.  One wave per group; the LDS window is sized to the positions a group
-// covers on average (iid reads: ~5300).  BWTM_TUNE=recs_window=... picks the window.
+// covers on average (iid reads: ~5300).  BWTM_TUNE=recs_window=... picks the window, recs_uniform=1 / -1 forces / forbids the straight-line deposit.
 int build_records(bwtm_index* x, u64 held, u64 n_end, uint4* recs, u64 nrecs)
 {
   const u64 gstride = x->ngroups + 1;
   const u64 per_group = held / x->ngroups;
   const bool long_runs = (x->nblocks > 0 && held / x->nblocks > 400);        // > ~6 positions per byte: cooperative fill of long runs pays
-#define BUILD_RECS(W, WAVES, FILL) LAUNCH("build_recs", (k_build_recs<W, WAVES, FILL>), div_up(x->ngroups, WAVES), WAVES * WAVE, \
+#define BUILD_RECS(W, WAVES, FILL, UNIFORM) LAUNCH("build_recs", (k_build_recs<W, WAVES, FILL, UNIFORM>), div_up(x->ngroups, WAVES), WAVES * WAVE, \
     x->native_bytes(), x->nbytes, x->blen.as<const u64>(), x->block_start.as<u64>(), x->gcum.as<const u64>(), gstride, x->nblocks, x->ngroups, n_end, \
     x->sup.as<const u64>(), recs, nrecs)
   const u64 window = (g_tune.recs_window != 0 ? (u64)g_tune.recs_window : (per_group <= 6500 ? 8192 : (per_group <= 14000 ? 16384 : 32768)));
-  if(window == 8192) { BUILD_RECS(8192, 4, false); }
-  else if(window == 16384) { BUILD_RECS(16384, 4, false); }
-  else if(!long_runs) { BUILD_RECS(32768, 2, false); }
-  else { BUILD_RECS(32768, 2, true); }
+  // the straight-line deposit for streams of longer runs (kernels/transcode.hip.h): from ~3.5 positions per byte on
+  const bool uniform = (g_tune.recs_uniform != 0 ? g_tune.recs_uniform > 0 : window == 32768);
+  if(window == 8192) { if(uniform) { BUILD_RECS(8192, 4, false, true); } else { BUILD_RECS(8192, 4, false, false); } }
+  else if(window == 16384) { if(uniform) { BUILD_RECS(16384, 4, false, true); } else { BUILD_RECS(16384, 4, false, false); } }
+  else if(!long_runs) { if(uniform) { BUILD_RECS(32768, 2, false, true); } else { BUILD_RECS(32768, 2, false, false); } }
+  else { if(uniform) { BUILD_RECS(32768, 2, true, true); } else { BUILD_RECS(32768, 2, true, false); } }
 #undef BUILD_RECS
   return BWTM_OK;
 }

@@ -299,9 +299,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_build_sup(const u8* data, u64
 // FILL (for streams of long runs): the whole plane words in the middle of a long run are not deposited by the lane
 // that decodes the run -- a serial loop of length / 32 steps on a mostly idle wave -- but queued in LDS and written
 // by all 64 lanes after the decode pass.  It costs ~1 ms on read-like streams, hence a template flag.
+// UNIFORM (for streams from ~3.5 positions per byte on, round 6): the blocks inside the window are deposited by straight-line code, the same for
+// every byte class, instead of the word path / per-byte paths that serve read-like streams (see there).
 constexpr u32 BR_FILLS = 256;
 
-// (Round 6 measured a RUN-parallel deposit for the streams of longer runs -- every lane stores the window-relative end of each byte's run, then
+// (Before UNIFORM, round 6 measured a RUN-parallel deposit for the streams of longer runs -- every lane stores the window-relative end of each byte's run, then
 // the group's 64 x 64 bytes are dealt out round-robin and every run ORs its own edge words into the planes: no accumulators, no divergent
 // flushes.  It lost: 14.8 vs 12.1 ms at 300 x genome reads, 13.6 vs 8.2 at 30 x; four times the LDS atomics at 1.5 waves per SIMD.  So did
 // smaller windows with more waves: 16 384 / 8 192 positions 17.2 / 21.0 vs 12.1 ms.  And so did a GATHER per record: pass 1 stores for every byte
@@ -309,7 +311,7 @@ constexpr u32 BR_FILLS = 256;
 // walk that builds the record's twelve words in registers, one mask per run and word -- no atomics, no planes in LDS.  Bit-exact in all parity
 // tests, and slower everywhere: 13.0 vs 12.3 ms at 300 x, 12.9 vs 8.2 at 30 x, 8.0 vs 1.8 on iid reads (2 x 20 M): the walk is a loop of
 // dependent LDS reads whose trip count differs from lane to lane, at 2 waves per SIMD.  DESIGN_HISTORY.md, round 6.)
-template<u32 BR_WINDOW, int WAVES, bool FILL>
+template<u32 BR_WINDOW, int WAVES, bool FILL, bool UNIFORM = false>
 __global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64 nbytes, const u64* blen, u64* block_start,
   const u64* gcum, u64 gstride, u64 nblocks, u64 ngroups, u64 n, const u64* sup, uint4* recs, u64 nrecs)
 {
@@ -361,7 +363,69 @@ __global__ void __launch_bounds__(WAVES * WAVE) k_build_recs(const u8* data, u64
       fill_list[wave][slot] = word | ((nwords - 1) << 10) | (sym << 20);      // word < 1024, nwords <= 1024
       return nwords;
     };
-    if(inside)
+    if(inside && UNIFORM)
+    {
+      // Streams of longer runs (round 6; reads of a genome at 300 x coverage: 5 positions per byte).  The loop below serves them badly: hardly a
+      // word passes the test of the word path, and behind it the lanes split by byte class at every word -- words of four short runs, words with
+      // a run of >= 32 or a varint -- so that the wave runs both bodies, with a flush check behind every byte and a loop of 32-bit appends for
+      // every long run: 167 VALU instructions per byte position (PMC, profiles/r06_pmc_per_kernel_genome300.txt) where an iid stream takes 27.
+      // Here every lane runs the same straight-line code for every byte -- the varint state machine as selects; a completed run (length 0 when
+      // the byte completes none) gives its first min(length, room) bits to the current word, whole words of the rest are STORED (they lie
+      // inside the lane's own run: nobody else writes them; >= 4 of them go to the cooperative fill), and the remainder opens the next word.
+      u32 lo0 = 0, lo1 = 0, lo2 = 0;
+      u32 fill = (u32)(bstart - ws) & 31u, wi = (u32)(bstart - ws) >> 5;
+      u32 rsym = 0, rshift = 0, rlen = 0, cont = 0;                 // (a block inside the window: run lengths fit 32 bits)
+      const u32* row = rows + lane * STAGE_WORDS;
+#pragma unroll 1
+      for(int w = 0; w < 16; w++)
+      {
+        const u32 word = row[w];
+#pragma unroll
+        for(int k = 0; k < 4; k++)
+        {
+          const u32 byte = (word >> (8 * k)) & 0xFF;
+          const u32 q = (byte * 171u) >> 10, s = byte - 6 * q;
+          const u32 more = byte >> 7;
+          const u32 head_long = (cont == 0 && q + 1 >= MAX_RUN ? 1u : 0u);
+          const u32 grown = rlen + ((byte & 0x7Fu) << (rshift & 31u));
+          u32 len = (cont != 0 ? (more != 0 ? 0u : grown) : (head_long != 0 ? 0u : q + 1));
+          const u32 sym = (cont != 0 ? rsym : s);
+          rlen = (cont != 0 ? grown : q + 1); rshift = (cont != 0 ? rshift + 7 : 0u);
+          rsym = sym;
+          cont = (cont != 0 ? more : head_long);
+          const u32 s0 = (u32)__builtin_amdgcn_sbfe((int)sym, 0, 1), s1 = (u32)__builtin_amdgcn_sbfe((int)sym, 1, 1), s2 = (u32)__builtin_amdgcn_sbfe((int)sym, 2, 1);
+          // the first bits complete the current word (fill < 32)
+          const u32 room = 32u - fill, take = (len < room ? len : room);
+          const u32 upto = fill + take;                               // <= 32
+          const u32 m = (upto >= 32u ? ~0u : (1u << upto) - 1u) & (~0u << fill);
+          lo0 |= s0 & m; lo1 |= s1 & m; lo2 |= s2 & m;
+          fill = upto; len -= take;
+          if(fill == 32u)
+          {
+            atomicOr(&pl[wi], lo0); atomicOr(&pl[PW + wi], lo1); atomicOr(&pl[2 * PW + wi], lo2);       // edge words are shared with the neighbours
+            lo0 = 0; lo1 = 0; lo2 = 0; fill = 0; wi++;
+          }
+          if(len >= 32u)
+          {
+            // whole words inside the run (fill == 0)
+            u32 n = len >> 5;
+            len &= 31u;
+            if(sym != 0)
+            {
+              const u32 done = (FILL && n >= 4 ? queue_fill(sym, wi, n) : 0u);
+              for(u32 j = done; j < n; j++) { pl[wi + j] = s0; pl[PW + wi + j] = s1; pl[2 * PW + wi + j] = s2; }
+            }
+            wi += n;
+          }
+          // what is left opens the next word (fill == 0 whenever len != 0)
+          const u32 mt = (1u << len) - 1u;
+          lo0 |= s0 & mt; lo1 |= s1 & mt; lo2 |= s2 & mt;
+          fill += len;
+        }
+      }
+      if(fill > 0 && wi < BR_WINDOW / 32) { atomicOr(&pl[wi], lo0); atomicOr(&pl[PW + wi], lo1); atomicOr(&pl[2 * PW + wi], lo2); }
+    }
+    else if(inside)
     {
       // The block lies inside the LDS window (the common case): its runs are appended to three bit
       // streams, one per plane, through a pair of 32-bit accumulators per plane (current word, spill-over) that release a

@@ -53,8 +53,19 @@ def check_index(ix, sym, rng, nq=4000):
         assert np.array_equal(r.astype(np.int64), cum[sym[ipos.astype(np.int64)], ipos.astype(np.int64)])
 
 
-def test_upload_builds_exact_rank_structure(gpu, oracle):
+@pytest.mark.parametrize("deposit", ["by_density", "straight_line", "branching"])
+def test_upload_builds_exact_rank_structure(gpu, oracle, deposit):
+    """k_build_recs against plain symbols.  `deposit`: the kernel's two ways to lay a block's runs into the bit planes -- chosen by the stream's
+    density, or forced on every stream (all three window sizes take both)."""
     rng = np.random.default_rng(1)
+    gpu.tune("recs_uniform", {"by_density": 0, "straight_line": 1, "branching": -1}[deposit])
+    try:
+        upload_cases(gpu, oracle, rng)
+    finally:
+        gpu.tune("recs_uniform", 0)
+
+
+def upload_cases(gpu, oracle, rng):
     # run-length mixes chosen so that all three LDS window sizes of the transcode are used (positions per 62-block group); the last three
     # are streams of the long-window kind: runs around the one-byte limit (9 .. 41), long-event mixes, and a few giant runs between short ones
     for lengths in ([1, 1, 1, 2, 3], [2, 3, 4], [1, 2, 41, 42, 43, 169, 170, 5000], [16425, 16426, 100000, 1, 7], [9, 12, 17, 23, 31, 32, 33, 41],

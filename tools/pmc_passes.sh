@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM-traffic and SQ counter passes over one merge step of bench.py (config 2), aggregated per kernel on the GPU box.
 # Separate rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass); no tracing options combined.
-# Usage (on the GPU box): bash tools/pmc_passes.sh <out-subdir-of-gpurun_out> [sq]
+# Usage (on the GPU box): bash tools/pmc_passes.sh <out-subdir-of-gpurun_out> [sq]      (PMC_BENCH_ARGS="--workload genome --coverage 300": another workload than config 2)
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$1; mkdir -p $out; : > $out/pmc.txt
 sets=("FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_sum")
 if [ "$2" = "sq" ]; then
@@ -11,7 +11,7 @@ cd /tmp
 i=0
 for set in "${sets[@]}"; do
   i=$((i+1)); rm -rf /tmp/pmc_$i
-  timeout 900 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc_$i -- python3 $R/bench.py --no-cpu-baseline --no-verify --no-host --target off --steps 1 --warmup 0 > /tmp/pmc_$i.log 2>&1
+  timeout 900 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc_$i -- python3 $R/bench.py $PMC_BENCH_ARGS --no-cpu-baseline --no-verify --no-host --target off --steps 1 --warmup 0 > /tmp/pmc_$i.log 2>&1
   f=$(find /tmp/pmc_$i -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then python3 $R/tools/pmc_aggregate.py $f >> $out/pmc.txt; else echo "pass $i ($set) failed" >> $out/pmc.txt; tail -5 /tmp/pmc_$i.log >> $out/pmc.txt; fi
 done
