@@ -373,7 +373,7 @@ struct PartSearch
   // local
   DevBuf seg_len_in, seg_phys_in, seg_prefix_in, first_seg_in, tiles_in; u64 seg_in_cap = 0;
   DevBuf out_prefix, out_first_seg, tiles_out, dummy_emit;
-  DevBuf cuts_dev, srcs, plan_dev[2];
+  DevBuf cuts_dev, srcs;
   DevBuf emit16, emit_base, bound; u64 emit_cap = 0, EPOCH = 1, in_epoch = 0, epoch_used = 0, ntiles = 0, tile_first = 0;      // (the tiles of the part's window of the bitvector)
   // page-locked staging
   PullPlan* plan_host[2] = {nullptr, nullptr}; CutEntry* cut_host = nullptr; u64* small_host = nullptr;
@@ -443,7 +443,7 @@ int search_setup(PartSearch& S, bool node_phase)
   static_assert(sizeof(PullPlan) <= 4096 && 5 * (PART_MAX + 1) * sizeof(CutEntry) <= 4096 && 5 * PART_MAX * sizeof(NodePiece) <= 4096 && GROUP_PINNED_BYTES >= 5 * 4096 + 2048, "the group's page-locked block");
   char* pinned = nullptr;
   TRY(group_pinned(S.G, &pinned));
-  for(int k = 0; k < 2; k++) { TRY(S.plan_dev[k].alloc(sizeof(PullPlan))); S.plan_host[k] = (PullPlan*)(pinned + 4096 * k); }
+  for(int k = 0; k < 2; k++) { S.plan_host[k] = (PullPlan*)(pinned + 4096 * k); }
   S.cut_host = (CutEntry*)(pinned + 8192); S.small_host = (u64*)(pinned + 12288); S.node_pieces_host = (NodePiece*)(pinned + 16384);
   // The cut search stores its triples straight into page-locked host memory (2 KB of posted writes): a copy command behind the kernel costs more
   // idle device than the transfer (the search's frontier size travels the same way, api/search.hip.h).  The plan goes the other way as a copy:
@@ -714,16 +714,15 @@ int part_search(PartSearch& S)
       TRY(S.tiles_in.alloc(div_up(S.seg_in_cap + 1, (u64)SCAN_TILE) * 8, true));
     }
     TURN(S.G);
-    HIP_TRY(hipMemcpyAsync(S.plan_dev[par].p, plan, sizeof(PullPlan), hipMemcpyHostToDevice, CTX.stream));
     if(div_up(nseg_in + 1, (u64)SCAN_TILE) <= CTX.pull_scan1_tiles && g_tune.frontier_unfused == 0)
     {
       // the pulled table and its scan in one launch
-      LAUNCH("pull_scan", k_pull_scan1, div_up(nseg_in + 1, (u64)SCAN_TILE), BLOCK_THREADS, S.plan_dev[par].as<const PullPlan>(), S.tiles_in.as<unsigned long long>(), S.tag_in,
+      LAUNCH("pull_scan", k_pull_scan1, div_up(nseg_in + 1, (u64)SCAN_TILE), BLOCK_THREADS, *plan, S.tiles_in.as<unsigned long long>(), S.tag_in,
         S.seg_phys_in.as<u64>(), S.seg_prefix_in.as<u64>(), S.first_seg_in.as<u32>(), S.emit_base.as<u64>(), S.in_epoch);
     }
     else
     {
-      LAUNCH("pull_tables", k_pull_tables, div_up(nseg_in + 1, BLOCK_THREADS), BLOCK_THREADS, S.plan_dev[par].as<const PullPlan>(), S.seg_len_in.as<u64>(), S.seg_phys_in.as<u64>());
+      LAUNCH("pull_tables", k_pull_tables, div_up(nseg_in + 1, BLOCK_THREADS), BLOCK_THREADS, *plan, S.seg_len_in.as<u64>(), S.seg_phys_in.as<u64>());
       TRY(frontier_table_scan(S.seg_len_in.as<const u64>(), nseg_in, S.seg_prefix_in.as<u64>(), S.first_seg_in.as<u32>(), S.emit_base.as<u64>(), S.in_epoch, S.tiles_in, S.tag_in));
     }
     S.tag_in = (S.tag_in == 0x7FFFFFFFu ? 1 : S.tag_in + 1);

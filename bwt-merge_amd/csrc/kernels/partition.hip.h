@@ -120,21 +120,32 @@ struct PullPlan
   u32 npieces, nseg;                                                // runs; entries of this part's table (the entry behind them is set to 0)
 };
 
-__global__ void __launch_bounds__(BLOCK_THREADS) k_pull_tables(const PullPlan* plan, u64* seg_len, u64* seg_phys)
+// The plan travels as a kernel ARGUMENT (2.8 KB of the 4 KB a launch may carry): no copy to the device ahead of the launch -- one stream
+// operation less in every step (round 6: a step with nothing to do takes 59 us, every operation of it counts) -- and the runs are staged in
+// LDS once per workgroup, so that a thread's look-up of its run is not one more dependent load from memory.
+struct PullPieces { PullPiece piece[5 * PART_MAX]; u64 table[2][PART_MAX]; };
+
+__device__ inline void stage_plan(const PullPlan& plan, PullPieces& s)
 {
-  __shared__ u32 s_first[5 * PART_MAX];
-  const u32 np = plan->npieces, nseg = plan->nseg;
-  if(threadIdx.x < np) { s_first[threadIdx.x] = plan->piece[threadIdx.x].dst_first; }
+  if(threadIdx.x < plan.npieces) { s.piece[threadIdx.x] = plan.piece[threadIdx.x]; }
+  if(threadIdx.x < PART_MAX) { s.table[0][threadIdx.x] = (u64)(uintptr_t)plan.seg_len[threadIdx.x]; s.table[1][threadIdx.x] = (u64)(uintptr_t)plan.seg_phys[threadIdx.x]; }
   __syncthreads();
+}
+
+__global__ void __launch_bounds__(BLOCK_THREADS) k_pull_tables(const PullPlan plan, u64* seg_len, u64* seg_phys)
+{
+  __shared__ PullPieces sp;
+  const u32 np = plan.npieces, nseg = plan.nseg;
+  stage_plan(plan, sp);
   const u64 idx = (u64)blockIdx.x * BLOCK_THREADS + threadIdx.x;
   if(idx == nseg) { seg_len[idx] = 0; seg_phys[idx] = 0; }
   if(idx >= nseg) { return; }
   u32 q = 0;
-  for(u32 step = 64; step != 0; step >>= 1) { if(q + step < np && s_first[q + step] <= idx) { q += step; } }      // the runs are sorted by dst_first
-  const PullPiece pc = plan->piece[q];
+  for(u32 step = 64; step != 0; step >>= 1) { if(q + step < np && sp.piece[q + step].dst_first <= idx) { q += step; } }      // the runs are sorted by dst_first
+  const PullPiece pc = sp.piece[q];
   const u32 j = (u32)idx - pc.dst_first;
   const u64 e = pc.src_first + j;
-  u64 len = peer_load(&plan->seg_len[pc.src][e]), at = peer_load(&plan->seg_phys[pc.src][e]);
+  u64 len = peer_load((const u64*)(uintptr_t)sp.table[0][pc.src] + e), at = peer_load((const u64*)(uintptr_t)sp.table[1][pc.src] + e);
   if(j + 1 == pc.count && pc.last_len != PULL_ALL && len > pc.last_len) { len = pc.last_len; }
   if(j == 0) { const u64 skip = (pc.clip_first < len ? pc.clip_first : len); len -= skip; at += skip; }
   seg_len[idx] = len;
@@ -143,22 +154,21 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_pull_tables(const PullPlan* p
 
 // k_pull_tables and the scan of the pulled table (k_frontier_scan1) in ONE launch: every workgroup pulls the 2048 entries of its tile, publishes
 // the tile's total as a tagged word and waits for the tiles before it, as k_frontier_scan1 does (at most FRONTIER_SCAN1_TILES tiles, all resident).
-__global__ void __launch_bounds__(BLOCK_THREADS) k_pull_scan1(const PullPlan* plan, unsigned long long* tile_total, u32 tag, u64* seg_phys, u64* seg_prefix, u32* first_seg,
+__global__ void __launch_bounds__(BLOCK_THREADS) k_pull_scan1(const PullPlan plan, unsigned long long* tile_total, u32 tag, u64* seg_phys, u64* seg_prefix, u32* first_seg,
   u64* emit_base, u64 step)
 {
-  __shared__ u32 s_first[5 * PART_MAX];
+  __shared__ PullPieces sp;
   __shared__ u64 lds[BLOCK_THREADS / WAVE];
-  const u32 np = plan->npieces;
-  const u64 nseg = plan->nseg, n = nseg + 1;                          // the entry after the last segment holds 0 and receives N_t
-  if(threadIdx.x < np) { s_first[threadIdx.x] = plan->piece[threadIdx.x].dst_first; }
-  __syncthreads();
+  const u32 np = plan.npieces;
+  const u64 nseg = plan.nseg, n = nseg + 1;                           // the entry after the last segment holds 0 and receives N_t
+  stage_plan(plan, sp);
   const u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
   u64 item[SCAN_ITEMS], at[SCAN_ITEMS];
   u64 acc = 0;
   // the thread's eight consecutive entries: the run of the first one by binary search, the following ones by stepping
   u32 q = 0;
-  if(base < nseg) { for(u32 st = 64; st != 0; st >>= 1) { if(q + st < np && s_first[q + st] <= base) { q += st; } } }
-  PullPiece pc = plan->piece[q];
+  if(base < nseg) { for(u32 st = 64; st != 0; st >>= 1) { if(q + st < np && sp.piece[q + st].dst_first <= base) { q += st; } } }
+  PullPiece pc = sp.piece[q];
 #pragma unroll
   for(int k = 0; k < SCAN_ITEMS; k++)
   {
@@ -166,10 +176,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS) k_pull_scan1(const PullPlan* pl
     item[k] = 0; at[k] = 0;
     if(idx < nseg)
     {
-      while(q + 1 < np && s_first[q + 1] <= idx) { q++; pc = plan->piece[q]; }
+      while(q + 1 < np && sp.piece[q + 1].dst_first <= idx) { q++; pc = sp.piece[q]; }
       const u32 j = (u32)idx - pc.dst_first;
       const u64 e = pc.src_first + j;
-      u64 len = peer_load(&plan->seg_len[pc.src][e]), a = peer_load(&plan->seg_phys[pc.src][e]);
+      u64 len = peer_load((const u64*)(uintptr_t)sp.table[0][pc.src] + e), a = peer_load((const u64*)(uintptr_t)sp.table[1][pc.src] + e);
       if(j + 1 == pc.count && pc.last_len != PULL_ALL && len > pc.last_len) { len = pc.last_len; }
       if(j == 0) { const u64 skip = (pc.clip_first < len ? pc.clip_first : len); len -= skip; a += skip; }
       item[k] = len; at[k] = a | ((u64)pc.src << PULL_SRC_SHIFT);
