@@ -11,8 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def run_bench(cmd):
-    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+def run_bench(cmd, timeout=900, env=None):
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     return json.loads(line)
@@ -25,10 +25,11 @@ def run_bench_shared_gpu(cmd, tries=3):
     builds, verification); the merges themselves must overlap.  A run that dies or does not verify is repeated (three runs in all) before it
     counts as a failure of the path under test."""
     last = None
+    env = dict(os.environ, BWTM_GROUP_TIMEOUT="60")                    # a part that lost its peers gives up after a minute, not five
     for _ in range(tries):
         try:
-            d = run_bench(cmd)
-        except AssertionError as e:
+            d = run_bench(cmd, timeout=240, env=env)                     # (a run takes ~15 s)
+        except (AssertionError, subprocess.TimeoutExpired) as e:
             last = e
             continue
         if d["verified"] is True:
